@@ -1,0 +1,452 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the *real* reference.
+
+Runs ONLY in the build container (needs /root/reference, read-only).  The reference's Python never
+travels to the GPU box: what is committed is data — inputs and (reduced) expected outputs — plus
+this script.  Recipe: the reference package cannot be imported as-is (h5py,
+pytorch_lightning, omegaconf, torchvision, imageio, skvideo are absent), so five small stand-ins
+are registered *for third-party modules only* before importing `mebt.transformer`:
+
+  1. empty namespace packages `mebt`, `mebt.modules` whose __path__ points at the reference dirs,
+     so their __init__.py (which pulls h5py/torchvision/lpips) never runs;
+  2. a fake `pytorch_lightning` exposing `LightningModule(nn.Module)`;
+  3. empty `imageio`, `skvideo`, `skvideo.io` (import-time only, mebt/utils.py:3,8);
+  4. a fake `mebt.download.load_vqgan` (imported unconditionally at transformer.py:181, never
+     called under vtokens=True);
+  5. attribute+item config objects (OmegaConf is absent).
+
+Randomness is made machine-independent by replacing the three torch RNG entry points the path
+uses (`Tensor.exponential_`, `torch.randn_like`, `torch.randperm`) and `random.random` with the
+closed-form streams of oracle/closed_form.py, numbered in call order.
+
+Usage:  python tests/golden/make_golden.py          (rewrites tests/golden/*.npz)
+"""
+import os
+import sys
+import types
+import random
+
+sys.dont_write_bytecode = True            # never write __pycache__ into /root/reference
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from oracle import closed_form as cf
+from oracle import mebt_oracle as orc
+
+
+# ------------------------------------------------------------------------------------------------
+# stubs
+# ------------------------------------------------------------------------------------------------
+def install_stubs():
+    for name, path in (("mebt", [f"{REF}/mebt"]), ("mebt.modules", [f"{REF}/mebt/modules"])):
+        m = types.ModuleType(name)
+        m.__path__ = path
+        sys.modules[name] = m
+
+    pl = types.ModuleType("pytorch_lightning")
+
+    class LightningModule(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.global_step = 0
+            self.current_epoch = 0
+            self._logged = {}
+
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, name, value, **k):
+            self._logged[name] = value
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+    pl.LightningModule = LightningModule
+    sys.modules["pytorch_lightning"] = pl
+    for name in ("imageio", "skvideo", "skvideo.io"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["skvideo"].io = sys.modules["skvideo.io"]
+    dl = types.ModuleType("mebt.download")
+    dl.load_vqgan = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("vtokens only"))
+    sys.modules["mebt.download"] = dl
+    sys.path.insert(0, REF)               # top-level `utils.instantiate_from_config`
+
+
+class Cfg(dict):
+    """attr + item access, `in`, `.get` — what the reference needs from OmegaConf."""
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+class ClosedFormRNG:
+    """Numbered closed-form streams standing in for torch's global RNG."""
+    def __init__(self):
+        self.k = 0
+        self.log = []
+
+    def _next(self, kind, shape):
+        k = self.k
+        self.k += 1
+        self.log.append((kind, tuple(shape)))
+        return k
+
+    def exponential_(self, tensor):
+        k = self._next("exp", tensor.shape)
+        tensor.copy_(torch.from_numpy(cf.exp1_noise("noise", tuple(tensor.shape), stream=k)))
+        return tensor
+
+    def randn_like(self, t):
+        k = self._next("randn", t.shape)
+        return torch.from_numpy(cf.pseudo_normal("noise", tuple(t.shape), std=1.0, stream=k))
+
+    def randperm(self, n):
+        k = self._next("perm", (n,))
+        return torch.from_numpy(cf.permutation("noise", n, stream=k))
+
+
+def patch_rng(rng):
+    torch.Tensor.exponential_ = lambda self, *a, **k: rng.exponential_(self)
+    torch.randn_like = lambda t, *a, **k: rng.randn_like(t)
+    torch.randperm = lambda n, *a, **k: rng.randperm(n)
+
+
+def oracle_noise_fns(start=0):
+    """The same numbered streams, for replaying through the oracle (used by the tests too)."""
+    state = {"k": start}
+
+    def nxt():
+        k = state["k"]
+        state["k"] += 1
+        return k
+
+    def noise_fn(tag, shape):
+        if tag == "randn":
+            return torch.from_numpy(cf.pseudo_normal("noise", tuple(shape), std=1.0, stream=nxt()))
+        return torch.from_numpy(cf.exp1_noise("noise", tuple(shape), stream=nxt()))
+
+    def perm_fn(tag, B, N):
+        return torch.stack([torch.from_numpy(cf.permutation("noise", N, stream=nxt())) for _ in range(B)])
+
+    return noise_fn, perm_fn, state
+
+
+# ------------------------------------------------------------------------------------------------
+# model construction
+# ------------------------------------------------------------------------------------------------
+CONFIGS = {
+    # BASELINE.json configs[0] / SURVEY.md §8 "C1": one block of each routing mode
+    "c1": dict(n_layer=4, n_head=4, n_embd=256, block_size=256, sos_emb=64,
+               mode=["latent_enc", "latent_self", "latent_dec", "lt2l"], shape=[2, 8, 8], budget=128),
+    # micro config for per-block hidden states (SURVEY.md §8c fixture design)
+    "micro": dict(n_layer=6, n_head=2, n_embd=64, block_size=32, sos_emb=8,
+                  mode=["latent_enc", "latent_self", "latent_enc", "latent_dec", "lt2l", "latent_dec"],
+                  shape=[2, 4, 4], budget=32),
+    # micro config with a binding target budget and label smoothing
+    "micro_budget": dict(n_layer=4, n_head=2, n_embd=64, block_size=32, sos_emb=8,
+                         mode=["latent_enc", "latent_self", "latent_dec", "lt2l"],
+                         shape=[2, 4, 4], budget=8, label_smoothing=0.1),
+    # mode list shorter than n_layer -> padded with full-attention 'maskgit' blocks (gpt.py:208-209)
+    "micro_maskgit": dict(n_layer=3, n_head=2, n_embd=64, block_size=32, sos_emb=8,
+                          mode=["latent_enc", "latent_dec"], shape=[2, 4, 4], budget=32),
+}
+
+
+def oracle_cfg(name, schedule="linear"):
+    c = CONFIGS[name]
+    return orc.OracleConfig(c["n_layer"], c["n_head"], c["n_embd"], c["block_size"], c["sos_emb"],
+                            c["mode"], shape=c["shape"], schedule=schedule, budget=c["budget"],
+                            avg_loss=1.0, label_smoothing=c.get("label_smoothing", 0.0))
+
+
+def build_reference(name, schedule="linear"):
+    from mebt.transformer import Net2NetTransformer
+    c = CONFIGS[name]
+    tcfg = Cfg(unconditional=True, vocab_size=16384, first_stage_vocab_size=16384,
+               block_size=c["block_size"], n_layer=c["n_layer"], n_head=c["n_head"],
+               n_embd=c["n_embd"], n_unmasked=0, embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0,
+               sample_every_n_latent_frames=0, first_stage_key="video", cond_stage_key="label",
+               vtokens=True, vtokens_pos=False, vis_epoch=100, sos_emb=c["sos_emb"], avg_loss=True,
+               mode=list(c["mode"]), class_cond_dim=None)
+    if "label_smoothing" in c:
+        tcfg["label_smoothing"] = c["label_smoothing"]
+    mcfg = Cfg(target="mebt.mask_sampler.MaskGen",
+               params=Cfg(iid=False, schedule=schedule, max_token=c["block_size"], method="mlm",
+                          shape=c["shape"], t_range=[0.0, 1.0], budget=c["budget"]))
+    model = Net2NetTransformer(tcfg, Cfg(params=Cfg(ckpt_path=None)), mcfg, cond_stage_key="label")
+    ocfg = oracle_cfg(name, schedule)
+    sd = {k: torch.from_numpy(v) for k, v in cf.state_dict_numpy(orc.param_shapes(ocfg)).items()}
+    missing, unexpected = model.load_state_dict(sd, strict=True), None
+    return model, ocfg
+
+
+def inputs(name, B, tag):
+    c = CONFIGS[name]
+    N = int(np.prod(c["shape"]))
+    x = torch.from_numpy(cf.randint(f"x/{name}/{tag}", (B, *c["shape"]), 16384))
+    idx = torch.stack([torch.from_numpy(cf.permutation(f"perm/{name}/{tag}", N, stream=b)) for b in range(B)])
+    return x, idx
+
+
+def digest(logits, cols):
+    """Reduced description of a [B,NT,V] logits tensor (SURVEY.md §8c 'reduced outputs')."""
+    lg = logits.detach().to(torch.float64)
+    top_v, top_i = logits.detach().topk(5, dim=-1)
+    return dict(lse=torch.logsumexp(lg, -1).numpy(), argmax=logits.argmax(-1).numpy(),
+                top5_ids=top_i.numpy(), top5_vals=top_v.numpy(),
+                cols=logits.detach()[..., cols].numpy(), mean=lg.mean(-1).numpy(),
+                sqsum=(lg * lg).sum(-1).numpy())
+
+
+COLS = cf.permutation("digest-cols", 16384)[:64].copy()
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        out[k] = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------------------------------
+# fixtures
+# ------------------------------------------------------------------------------------------------
+def gen_forward():
+    """Net2NetTransformer.forward + shared_step loss/acc (transformer.py:216-286, 717-732)."""
+    for name, B in (("c1", 2), ("micro", 3), ("micro_budget", 3), ("micro_maskgit", 2)):
+        model, _ = build_reference(name)
+        x, idx = inputs(name, B, "fwd")
+        out = {"x": x, "indices": idx, "cols": COLS}
+        cases = [("train", 0.5), ("train", 0.13), ("eval", 0.71), ("train", 0.999), ("train", 0.0)]
+        out["case_mode"] = np.array([c[0] for c in cases])
+        out["case_t"] = np.array([c[1] for c in cases])
+        for ci, (mode, t) in enumerate(cases):
+            model.train(mode == "train")
+            with torch.no_grad():
+                logits, z_t, ntw, seq_len = model(x, None, t=t, indices=idx)
+                # shared_step body (:723-731) on the same logits
+                from mebt.utils import accuracy
+                ratio = ntw / float(seq_len)
+                ls = model.label_smoothing
+                loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.size(-1)), z_t.reshape(-1),
+                                                         reduction="sum", label_smoothing=ls)
+                loss = loss / (B * seq_len * ratio ** model.config.avg_loss)
+                a1, a5 = accuracy(logits.reshape(-1, logits.shape[-1]), z_t.reshape(-1), topk=(1, 5))
+            d = digest(logits, COLS)
+            for k, v in d.items():
+                out[f"c{ci}_{k}"] = v
+            out[f"c{ci}_z_targets"] = z_t
+            out[f"c{ci}_meta"] = np.array([ntw, seq_len, float(loss), float(a1), float(a5)], dtype=np.float64)
+        save(f"forward_{name}", **out)
+
+
+def gen_hidden():
+    """Per-block hidden states of the micro config (gpt.py:243-248)."""
+    model, _ = build_reference("micro")
+    model.eval()
+    x, idx = inputs("micro", 2, "hidden")
+    ci, ti = idx[:, :11], idx[:, 11:]
+    hs = []
+    hooks = [blk.register_forward_hook(lambda m, i, o: hs.append((o[0].detach().clone(), o[2].detach().clone())))
+             for blk in model.transformer.blocks]
+    with torch.no_grad():
+        logits, _ = model.reconstruct_mask(x, ci, ti)
+    for h in hooks:
+        h.remove()
+    out = {"x": x, "ci": ci, "ti": ti, "logits_cols": logits[..., COLS], "cols": COLS,
+           "lse": torch.logsumexp(logits.double(), -1)}
+    for i, (s, t) in enumerate(hs):
+        out[f"sos{i}"] = s
+        out[f"tgt{i}"] = t
+    save("hidden_micro", **out)
+    # NC = 0 edge (first sampling step) and NT = 1
+    with torch.no_grad():
+        l0, _ = model.reconstruct_mask(x, idx[:, :0], idx)
+        l1, _ = model.reconstruct_mask(x, idx[:, :-1], idx[:, -1:])
+    save("edges_micro", x=x, indices=idx, cols=COLS, nc0_cols=l0[..., COLS],
+         nc0_lse=torch.logsumexp(l0.double(), -1), nt1_cols=l1[..., COLS],
+         nt1_lse=torch.logsumexp(l1.double(), -1))
+
+
+def gen_divide():
+    """MaskGen.divide_indices incl. the sliced-window (video-length curriculum) branch
+    (mask_sampler.py:75-115).  The two numpy draws are forced by patching np.random."""
+    from mebt.mask_sampler import MaskGen
+    out = {}
+    shape = (4, 2, 2)
+    N = 16
+    idx = torch.stack([torch.from_numpy(cf.permutation("perm/divide", N, stream=b)) for b in range(3)])
+    out["indices"] = idx
+    cases = []
+    k = 0
+    for sched in ("linear", "cosine", "quadratic", "sqrt", "square", "cube", "cosine_plus", "convex"):
+        for t in (0.0, 0.3, 0.77):
+            for (T, start, training, budget) in ((4, 0, True, 16), (2, 1, True, 16), (1, 3, True, 16),
+                                                 (4, 0, False, 5), (3, 0, True, 5)):
+                mg = MaskGen(schedule=sched, shape=shape, budget=budget)
+                mg.train(training)
+                orig_choice, orig_randint = np.random.choice, np.random.randint
+                np.random.choice = lambda a, p=None, _T=T: _T
+                np.random.randint = lambda lo, hi=None, _s=start: _s
+                try:
+                    c, tg, sl = mg.divide_indices(idx, torch.tensor(t), np.arange(4) + 1, np.ones(4))
+                finally:
+                    np.random.choice, np.random.randint = orig_choice, orig_randint
+                out[f"k{k}_ctx"], out[f"k{k}_tgt"] = c, tg
+                cases.append((sched, t, T, start, int(training), budget, int(sl)))
+                k += 1
+    out["case_sched"] = np.array([c[0] for c in cases])
+    out["case_num"] = np.array([c[1:] for c in cases], dtype=np.float64)
+    save("divide_indices", **out)
+
+
+def gen_sampler_ops():
+    """sample_from_logits / top-k / top-p (transformer.py:826-910) and generate_next_mask
+    (mask_sampler.py:178-246) on small tensors."""
+    import mebt.transformer as T
+    from mebt.mask_sampler import MaskGen
+    rng = ClosedFormRNG()
+    patch_rng(rng)
+    out = {}
+    V = 512
+    logits = torch.from_numpy(cf.pseudo_normal("sfl/logits", (2, 5, V), std=2.0))
+    logits[0, 0, 7] = logits[0, 0, 9]                     # a tie inside top-k
+    out["logits"] = logits
+    cases = [(1.0, None, None), (0.7, 8, None), (1.0, None, 0.9), (0.3, 16, 0.5), (0.0, None, None), (2.0, 1, None)]
+    out["cases"] = np.array([[c[0], -1 if c[1] is None else c[1], -1 if c[2] is None else c[2]] for c in cases])
+    for i, (temp, k, p) in enumerate(cases):
+        out[f"s{i}_stream"] = np.array(rng.k)
+        ids, probs = T.sample_from_logits(logits, temp, k, p, return_probs=True)
+        out[f"s{i}_ids"], out[f"s{i}_probs"] = ids, probs
+    # generate_next_mask
+    mg = MaskGen(schedule="cosine", shape=(2, 4, 4))
+    idx = torch.stack([torch.from_numpy(cf.permutation("perm/gnm", 32, stream=b)) for b in range(3)])
+    score = torch.from_numpy(cf.uniform01("gnm/score", (3, 20)).astype(np.float32))
+    ci, ti = idx[:, :12], idx[:, 12:]
+    gcases = [("maskgit", 4.5, 15), ("maskgit", 0.0, 10), ("maskgit", 2.0, 25), ("random", 4.5, 12),
+              ("bootstrap", 1.0, 3), ("mlm", 1.0, 0)]
+    out["g_ci"], out["g_ti"], out["g_score"] = ci, ti, score
+    out["g_cases"] = np.array([[c[1], c[2]] for c in gcases])
+    out["g_strategy"] = np.array([c[0] for c in gcases])
+    for i, (strategy, ctemp, nm) in enumerate(gcases):
+        out[f"g{i}_stream"] = np.array(rng.k)
+        nc, nt = mg.generate_next_mask(ci, ti, score, 0.5, strategy=strategy, context_temperature=ctemp,
+                                       n_masked_toks=torch.full((3,), float(nm)))
+        out[f"g{i}_ctx"], out[f"g{i}_tgt"] = nc, nt
+    save("sampler_ops", **out)
+
+
+def gen_sample_loops():
+    """sample() (transformer.py:353-447) and draft_and_revise() (:632-663) on the micro config."""
+    out = {}
+    runs = [("maskgit", 6, 1.0, None, None, 6.0, "cosine"), ("maskgit", 4, 0.8, 32, None, 2.0, "linear"),
+            ("random", 5, 1.0, None, 0.95, 4.5, "cosine"), ("bootstrap", 3, 1.0, None, None, 1.0, "cosine")]
+    out["runs"] = np.array([[r[1], r[2], -1 if r[3] is None else r[3], -1 if r[4] is None else r[4], r[5]] for r in runs])
+    out["run_strategy"] = np.array([r[0] for r in runs])
+    out["run_schedule"] = np.array([r[6] for r in runs])
+    for i, (strategy, n_steps, temp, k, p, ctemp, sched) in enumerate(runs):
+        model, _ = build_reference("micro", schedule=sched)
+        model.eval()
+        rng = ClosedFormRNG()
+        patch_rng(rng)
+        x = torch.zeros(2, 2, 4, 4, dtype=torch.long)
+        with torch.no_grad():
+            xs, ci, ti = model.sample(x, None, temp, k, p, n_steps, None, None, strategy=strategy,
+                                      context_temperature=ctemp, skips=False)
+        out[f"r{i}_x"], out[f"r{i}_ci"], out[f"r{i}_ti"] = xs, ci, ti
+        out[f"r{i}_ndraws"] = np.array(rng.k)
+    # sample() continuing from given context/target sets (sliding-window style call,
+    # sample_vqgan_transformer_videos.py:65) with edit=False
+    model, _ = build_reference("micro", schedule="cosine")
+    model.eval()
+    rng = ClosedFormRNG()
+    patch_rng(rng)
+    x0, idx = inputs("micro", 2, "cont")
+    with torch.no_grad():
+        xs, ci, ti = model.sample(x0, None, 1.0, None, None, 4, idx[:, :10], idx[:, 10:], context_temperature=3.0, skips=False)
+    out["cont_x0"], out["cont_idx"], out["cont_x"], out["cont_ci"], out["cont_ti"] = x0, idx, xs, ci, ti
+    # draft_and_revise
+    dnr = [(4, 1.0, None, None, 2, 0.7, None, None, 2, False), (8, 0.0, None, None, 4, 0.3, 16, 0.9, 1, False),
+           (4, 1.0, None, None, 8, 1.0, None, None, 2, True)]
+    out["dnr"] = np.array([[-1 if v is None else float(v) for v in r] for r in dnr])
+    for i, r in enumerate(dnr):
+        model, _ = build_reference("micro")
+        model.eval()
+        rng = ClosedFormRNG()
+        patch_rng(rng)
+        x0, _ = inputs("micro", 2, f"dnr{i}")
+        with torch.no_grad():
+            xs = model.draft_and_revise(x0, None, *r)
+        out[f"d{i}_x0"], out[f"d{i}_x"] = x0, xs
+        out[f"d{i}_ndraws"] = np.array(rng.k)
+    save("sample_loops", **out)
+
+
+def gen_train():
+    """Three optimiser steps of the reference training step (shared_step :717-732, backward,
+    configure_optimizers :749-798, optimizer_step :665-681) on the micro configs."""
+    for name in ("micro", "micro_budget"):
+        model, ocfg = build_reference(name)
+        model.train()
+        model.learning_rate, model.weight_decay = 1e-3, 0.05
+        opt = model.configure_optimizers()
+        ts = [0.5, 0.21, 0.83]
+        out = {"ts": np.array(ts), "lr": np.array(1e-3), "wd": np.array(0.05)}
+        out["group_sizes"] = np.array([len(list(g["params"])) for g in opt.param_groups])
+        out["group_wd"] = np.array([g["weight_decay"] for g in opt.param_groups])
+        names = sorted(orc.param_shapes(ocfg).keys())
+        probe = cf.permutation("train-probe", 4096)[:16]
+        for s, t in enumerate(ts):
+            x, idx = inputs(name, 3, f"train{s}")
+            out[f"s{s}_x"], out[f"s{s}_indices"] = x, idx
+            opt.zero_grad()
+            acc1, acc5, loss, ratio = _shared_step_with_t(model, x, idx, t)
+            loss.backward()
+            sd = dict(model.named_parameters())
+            out[f"s{s}_meta"] = np.array([float(loss), float(acc1), float(acc5)])
+            out[f"s{s}_gradnorm"] = np.array([float(sd[n].grad.double().norm()) if sd[n].grad is not None else 0.0 for n in names])
+            opt.step()
+            out[f"s{s}_pnorm"] = np.array([float(sd[n].detach().double().norm()) for n in names])
+            out[f"s{s}_pprobe"] = np.stack([sd[n].detach().reshape(-1)[probe % sd[n].numel()].numpy() for n in names])
+        out["names"] = np.array(names)
+        out["probe"] = probe
+        save(f"train_{name}", **out)
+
+
+def _shared_step_with_t(model, x, idx, t):
+    """shared_step (:717-732) with the python RNG draw `t` (:228) forced."""
+    orig = random.random
+    random.random = lambda: t
+    try:
+        return model.shared_step({"video": x, "label": x, "indices": idx}, 0)
+    finally:
+        random.random = orig
+
+
+def main():
+    install_stubs()
+    torch.manual_seed(0)
+    gen_forward()
+    gen_hidden()
+    gen_divide()
+    gen_sampler_ops()
+    gen_sample_loops()
+    gen_train()
+
+
+if __name__ == "__main__":
+    main()
