@@ -1,0 +1,143 @@
+/* libmebt_hip.so — C ABI of the MI355X-native (gfx950) MeBT transformer hot path.
+ *
+ * This is the drop-in boundary for the path BASELINE.json:north_star names: everything below
+ * `mebt.transformer.Net2NetTransformer.forward / reconstruct_mask / shared_step / sample*` and the
+ * optimiser step of the reference (Ugness/MeBT) — i.e. what the reference hands to ATen / cuBLAS /
+ * NCCL through torch — as hand-written HIP kernels.  Plain pointers and sizes only: no torch types.
+ * Every pointer is a DEVICE pointer owned by the caller (PyTorch allocates; kernels never
+ * allocate), `stream` is a hipStream_t passed as an opaque pointer (NULL = default stream).  No
+ * entry point synchronises with the host or allocates, so all of them are graph-capturable.
+ *
+ * Each entry point cites the reference code it replaces (paths relative to the reference root).
+ * All functions return 0 on success, non-zero on error (MEBT_E*); mebt_last_error() holds a
+ * thread-local message (bad shape / unsupported dtype / HIP error string).  The Python host side
+ * (mebt_amd/_lib.py) turns a non-zero status into RuntimeError, mirroring the reference's
+ * exceptions / asserts.
+ */
+#ifndef MEBT_HIP_H
+#define MEBT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MEBT_ABI_VERSION 1
+#define MEBT_MAX_LAYERS 128
+
+typedef void* mebt_stream_t;            /* hipStream_t */
+typedef struct mebt_model mebt_model;    /* opaque */
+
+enum mebt_status { MEBT_STATUS_OK = 0, MEBT_STATUS_EINVAL = 1, MEBT_STATUS_ESHAPE = 2, MEBT_STATUS_EHIP = 3,
+                   MEBT_STATUS_EWORKSPACE = 4, MEBT_STATUS_EDTYPE = 5 };
+enum mebt_dtype { MEBT_DTYPE_F32 = 0, MEBT_DTYPE_BF16 = 1 };
+/* Block routing modes, reference mebt/modules/gpt.py:164-179 */
+enum mebt_mode { MEBT_MODE_LATENT_ENC = 0, MEBT_MODE_LATENT_SELF = 1, MEBT_MODE_LATENT_DEC = 2, MEBT_MODE_LT2L = 3 };
+
+/* GPT hyper-parameters (reference mebt/modules/gpt.py:200-220, mebt/transformer.py:105-140). */
+typedef struct mebt_model_desc {
+    int32_t n_layer, n_head, n_embd, vocab, n_latent /* sos_emb */, block_size;
+    int32_t dtype;                       /* compute precision: MEBT_DTYPE_BF16 (MFMA bf16, fp32 accumulate) or
+                                            MEBT_DTYPE_F32 (exact-fp32 MFMA; the 1e-3 parity mode) */
+    int32_t modes[MEBT_MAX_LAYERS];
+    float label_smoothing;               /* transformer.py:97-100 */
+    float embd_pdrop, resid_pdrop, attn_pdrop;   /* gpt.py:113-114,154,211 */
+} mebt_model_desc;
+
+const char* mebt_last_error(void);
+int mebt_abi_version(void);
+
+/* ---- model handle ------------------------------------------------------------------------------- */
+int mebt_model_create(const mebt_model_desc* desc, mebt_model** out);
+void mebt_model_destroy(mebt_model* m);
+/* Flat parameter layout.  W = every nn.Linear weight (the decayed AdamW group, transformer.py:769-771),
+ * per layer [query,key,value,proj,mlp.0,mlp.2] then head; P = everything else, per layer
+ * [ln1.w,ln1.b,ln2.w,ln2.b,query.b,key.b,value.b,proj.b,mlp.0.b,mlp.2.b] then ln_f.w, ln_f.b,
+ * mask_emb, sos_emb, pos_emb, tok_emb.  The state-dict tensors of SURVEY.md §A.2 are views into
+ * these two buffers. */
+int mebt_model_param_counts(const mebt_model* m, int64_t* n_w, int64_t* n_p);
+/* W, P: fp32 master parameters; W_lp: bf16 mirror of W (NULL in fp32 mode); gW, gP: fp32 gradient
+ * buffers of the same layouts (may be NULL for inference). */
+int mebt_model_bind(mebt_model* m, float* W, void* W_lp, float* gW, float* P, float* gP);
+/* Refresh the bf16 mirror from the fp32 master weights (after load_state_dict / init). */
+int mebt_model_sync_lowp(mebt_model* m, mebt_stream_t stream);
+int64_t mebt_workspace_bytes(const mebt_model* m, int32_t B, int32_t NC, int32_t NT, int32_t training);
+
+/* embed + GPT.forward: replaces reference transformer.py:255-283 / :298-322 + gpt.py:234-253.
+ * x_ids [B,N] i64 token grid, ci [B,NC] / ti [B,NT] i64 position sets, logits [B,NT,V] fp32 out.
+ * training != 0 keeps the activations in `ws` for mebt_backward_*; dropout_seed keys the
+ * counter-based dropout masks (ignored when all p_drop are 0 or training == 0). */
+int mebt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
+                 const int64_t* x_ids, const int64_t* ci, const int64_t* ti, float* logits,
+                 int32_t training, uint64_t dropout_seed, mebt_stream_t stream);
+/* Masked-token loss + top-1/top-5 of the last mebt_forward: replaces F.cross_entropy(sum,
+ * label_smoothing) and utils.accuracy (transformer.py:726-731, utils.py:80-94).
+ * out4 (device, 4 doubles) = { CE sum, #top-1 hits, #top-5 hits, #rows }. */
+int mebt_loss(mebt_model* m, void* ws, const float* logits, double* out4, mebt_stream_t stream);
+/* Backward of loss = CE_sum * loss_scale (* *upstream if non-NULL, a device scalar), split so the
+ * caller can overlap the data-parallel all-reduce of finished gradient buckets with the rest
+ * (reference: DDP reducer, train_transformer.py:39-41).  Order: head, layers hi..lo descending, embed. */
+int mebt_backward_head(mebt_model* m, void* ws, const float* logits, const float* upstream, float loss_scale, mebt_stream_t stream);
+int mebt_backward_layers(mebt_model* m, void* ws, int32_t layer_hi, int32_t layer_lo, mebt_stream_t stream);
+int mebt_backward_embed(mebt_model* m, void* ws, mebt_stream_t stream);
+/* Fused AdamW over both flat buffers + refresh of the bf16 mirror: replaces torch.optim.AdamW with
+ * the 4 groups of transformer.py:790-797 (W decayed, P not).  step >= 1; grad_scale multiplies the
+ * gradients (1/world_size when the all-reduce summed). Parameters the loss cannot reach (blocks
+ * after the last latent_dec) are skipped like torch skips grad=None. */
+int mebt_adamw_step(mebt_model* m, float* mW, float* vW, float* mP, float* vP, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int32_t step, float grad_scale, mebt_stream_t stream);
+
+/* ---- operator entry points (building blocks; also what the parity tests call) ---------------------- */
+/* C[M,N] = sum_k A(m,k) B(n,k) + bias, epilogue 0 none / 1 GELU (C=pre, C2=gelu) / 2 +aux residual /
+ * 3 * gelu'(aux).  a_kc/b_kc: 1 = operand stored [rows][K], 0 = stored [K][rows].  Replaces nn.Linear
+ * forward / dgrad / wgrad (gpt.py:126-128,140,150-155,248). */
+int mebt_op_gemm(int32_t dtype, const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux,
+                 int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t ld_aux,
+                 int32_t a_kc, int32_t b_kc, int32_t epilogue, int32_t c_f32, int32_t beta, int32_t split_k,
+                 mebt_stream_t stream);
+/* nn.LayerNorm(d), eps 1e-5 (gpt.py:147-148,216). */
+int mebt_op_layernorm_fwd(int32_t dtype, const void* x, void* y, const float* gamma, const float* beta, float* mean,
+                          float* rstd, int32_t rows, int32_t d, mebt_stream_t stream);
+int mebt_op_layernorm_bwd(int32_t dtype, const void* x, const void* dy, const float* gamma, const float* mean,
+                          const float* rstd, void* dx, float* dgamma, float* dbeta, int32_t rows, int32_t d,
+                          mebt_stream_t stream);
+/* softmax(q k^T / sqrt(hd)) v (gpt.py:131-137).  q [B,NQ,H,hd] row stride ldq etc.; lse [B,H,NQ]. */
+int mebt_op_attention_fwd(int32_t dtype, const void* q, const void* k, const void* v, void* o, float* lse, int32_t B,
+                          int32_t H, int32_t NQ, int32_t NK, int32_t HD, int32_t ldq, int32_t ldk, int32_t ldv,
+                          int32_t ldo, int32_t force_generic, mebt_stream_t stream);
+int mebt_op_attention_bwd(int32_t dtype, const void* q, const void* k, const void* v, const void* o, const float* lse,
+                          const void* d_o, void* dq, void* dk, void* dv, float* delta, int32_t B, int32_t H,
+                          int32_t NQ, int32_t NK, int32_t HD, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                          int32_t force_generic, mebt_stream_t stream);
+/* Embedding gather (transformer.py:255-277): sos/ctx/tgt [B,*,d] of element type `dtype`. */
+int mebt_op_embed_fwd(int32_t dtype, const int64_t* x_ids, const int64_t* ci, const int64_t* ti, const float* tok_emb,
+                      const float* pos_emb, const float* mask_emb, const float* sos_emb, void* sos, void* ctx, void* tgt,
+                      int32_t B, int32_t N, int32_t NC, int32_t NT, int32_t NS, int32_t d, int32_t vocab,
+                      int32_t block_size, mebt_stream_t stream);
+/* Categorical draw of sample_from_logits / gumbel_sort (transformer.py:826-910) with the Exp(1) noise
+ * as an explicit input: ids = argmax(p/noise), score = p[ids]; probs optional [rows,V]. */
+int mebt_op_sample(const float* logits, const float* noise, float temperature, int32_t top_k, float top_p, int64_t* ids,
+                   float* score, float* probs, int32_t rows, int32_t V, mebt_stream_t stream);
+/* x[b, ti[b,j]] = ids[b,j]  (the sparse_coo/to_dense/where scatter of transformer.py:413-439). */
+int mebt_op_scatter_ids(int64_t* x, const int64_t* ti, const int64_t* ids, int32_t B, int32_t N, int32_t NT,
+                        mebt_stream_t stream);
+/* MaskGen.generate_next_mask + gumbel_top_k (mask_sampler.py:178-246): order targets by
+ * (score/sum)/noise^ctemp descending; first n_new go to the context (appended), the rest stay
+ * targets in score order. */
+int mebt_op_next_mask(const int64_t* ci, const int64_t* ti, const float* score, const float* noise, float ctemp,
+                      int32_t n_new, int32_t B, int32_t NC, int32_t NT, int64_t* new_ci, int64_t* new_ti,
+                      mebt_stream_t stream);
+/* fp32 -> bf16 cast of a flat buffer (n multiple of 4). */
+int mebt_op_cast_bf16(const float* src, void* dst, int64_t n, mebt_stream_t stream);
+
+/* ---- instrumentation ----------------------------------------------------------------------------- */
+/* Per-kernel-family timing with HIP events on the launch stream (bench.py roofline): enable, run,
+ * then read {launches, total ms, total algorithmic flops} of the GEMM family. */
+int mebt_profile_enable(int32_t on);
+int mebt_profile_read(int32_t family, double* launches, double* total_ms, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEBT_HIP_H */

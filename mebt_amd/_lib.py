@@ -1,0 +1,98 @@
+"""ctypes binding of libmebt_hip.so (C ABI: include/mebt_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load, importing the
+compute path raises.  PyTorch is used only for device memory, streams and torch.distributed.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmebt_hip.so")
+
+MEBT_MAX_LAYERS = 128
+F32, BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_RESID, EPI_GELU_BWD = 0, 1, 2, 3
+MODE_IDS = {"latent_enc": 0, "latent_self": 1, "latent_dec": 2, "lt2l": 3}
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("n_layer", c_i32), ("n_head", c_i32), ("n_embd", c_i32), ("vocab", c_i32),
+                ("n_latent", c_i32), ("block_size", c_i32), ("dtype", c_i32),
+                ("modes", c_i32 * MEBT_MAX_LAYERS), ("label_smoothing", c_f32),
+                ("embd_pdrop", c_f32), ("resid_pdrop", c_f32), ("attn_pdrop", c_f32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/mebt_hip.h
+PROTOTYPES = {
+    "mebt_last_error": (C.c_char_p, []),
+    "mebt_abi_version": (c_i32, []),
+    "mebt_model_create": (c_i32, [C.POINTER(ModelDesc), C.POINTER(c_vp)]),
+    "mebt_model_destroy": (None, [c_vp]),
+    "mebt_model_param_counts": (c_i32, [c_vp, C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "mebt_model_bind": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mebt_model_sync_lowp": (c_i32, [c_vp, c_vp]),
+    "mebt_workspace_bytes": (c_i64, [c_vp, c_i32, c_i32, c_i32, c_i32]),
+    "mebt_forward": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.c_uint64, c_vp]),
+    "mebt_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mebt_backward_head": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
+    "mebt_backward_layers": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "mebt_backward_embed": (c_i32, [c_vp, c_vp, c_vp]),
+    "mebt_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp]),
+    "mebt_op_gemm": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 13 + [c_vp]),
+    "mebt_op_layernorm_fwd": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "mebt_op_layernorm_bwd": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "mebt_op_attention_fwd": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 10 + [c_vp]),
+    "mebt_op_attention_bwd": (c_i32, [c_i32] + [c_vp] * 10 + [c_i32] * 10 + [c_vp]),
+    "mebt_op_embed_fwd": (c_i32, [c_i32] + [c_vp] * 10 + [c_i32] * 8 + [c_vp]),
+    "mebt_op_sample": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "mebt_op_scatter_ids": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "mebt_op_next_mask": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "mebt_op_cast_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "mebt_profile_enable": (c_i32, [c_i32]),
+    "mebt_profile_read": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmebt_hip.so and bind every prototype.  Raises if the library is absent: the product
+    path has no CPU / eager fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C mebt_amd/csrc`). mebt_amd has no fallback path without its HIP library.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class MebtError(RuntimeError):
+    pass
+
+
+def check(status):
+    """Non-zero C status -> exception carrying mebt_last_error() (reference convention: Python
+    exceptions / asserts)."""
+    if status != 0:
+        msg = load().mebt_last_error()
+        raise MebtError(f"libmebt_hip status {status}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def cur_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

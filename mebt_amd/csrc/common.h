@@ -1,0 +1,107 @@
+// Shared device helpers for the MeBT gfx950 kernels (CDNA4, wave64).  HIP only — no CUDA paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define MEBT_WAVE 64
+
+// status codes returned through the C ABI (include/mebt_hip.h)
+enum { MEBT_OK = 0, MEBT_EINVAL = 1, MEBT_ESHAPE = 2, MEBT_EHIP = 3, MEBT_EWORKSPACE = 4, MEBT_EDTYPE = 5 };
+
+#define MEBT_HIP_CHECK(expr)                                   \
+    do {                                                       \
+        hipError_t _e = (expr);                                \
+        if (_e != hipSuccess) { mebt_set_hip_error(_e, #expr); return MEBT_EHIP; } \
+    } while (0)
+void mebt_set_hip_error(hipError_t e, const char* what);
+void mebt_set_error(const char* msg);
+
+// ---------------------------------------------------------------------------------------------
+// buffer resources: out-of-range loads return 0 and out-of-range stores are dropped by hardware,
+// which is how every ragged tile edge (NC, NT are arbitrary) is handled without branches.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
+    const uint32_t n = bytes > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, 0x00020000);
+}
+#define MEBT_OOB 0x7FFFFFFF   // voffset guaranteed >= num_records
+
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+// ---------------------------------------------------------------------------------------------
+// element conversion
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 4 consecutive elements <-> 4 floats (16-B or 8-B vector access)
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
+    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions (butterfly over all 64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// exact-erf GELU (nn.GELU default, reference gpt.py:152) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------------------------------------
+// counter-based RNG for dropout (Philox-like mixing of a 64-bit counter; one 32-bit draw per call).
+// The mask of element `idx` at site `site` of step `seed` is recomputed in backward, never stored.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix_hash(uint64_t seed, uint32_t site, uint64_t idx) {
+    uint64_t x = idx + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1) + seed;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (uint32_t)(x >> 32);
+}
+// keep-scale for dropout probability p: returns 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thresh, float inv_keep) {
+    return mix_hash(seed, site, idx) >= thresh ? inv_keep : 0.0f;
+}

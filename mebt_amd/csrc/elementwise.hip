@@ -1,0 +1,458 @@
+// HBM-bound kernels of the MeBT path: embedding gather / scatter-add, LayerNorm fwd/bwd, column
+// sums, masked-token cross-entropy (+top-1/top-5), fused AdamW.  One wave64 per row for the
+// row-wise kernels, 16-byte accesses per lane, wave-shuffle reductions (no LDS round trip for the
+// per-row statistics).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// embedding gather:  contexts = tok_emb[x[ci]] + pos_emb[ci];  targets = mask_emb + pos_emb[ti];
+// sos = sos_emb broadcast.   (reference mebt/transformer.py:255-277 / :298-317; the reference
+// materialises a [B,block,d] copy of pos_emb and two int64 [B,*,d] address tensors, we move only
+// the algorithmic bytes.)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedParams p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long per_b = (long)p.NS + p.NC + p.NT;
+    if (row >= per_b * p.B) return;
+    const int b = (int)(row / per_b);
+    const int r = (int)(row % per_b);
+    const float* src0;
+    const float* src1 = nullptr;
+    T* dst;
+    if (r < p.NS) {
+        src0 = p.sos_emb + (size_t)r * p.d;
+        dst = reinterpret_cast<T*>(p.sos) + ((size_t)b * p.NS + r) * p.d;
+    } else if (r < p.NS + p.NC) {
+        const int i = r - p.NS;
+        long pos = p.ci[(size_t)b * p.NC + i];
+        pos = pos < 0 ? 0 : (pos >= p.N ? p.N - 1 : pos);
+        long tok = p.x_ids[(size_t)b * p.N + pos];
+        tok = tok < 0 ? 0 : (tok >= p.vocab ? p.vocab - 1 : tok);
+        src0 = p.tok_emb + (size_t)tok * p.d;
+        src1 = p.pos_emb + (size_t)pos * p.d;
+        dst = reinterpret_cast<T*>(p.ctx) + ((size_t)b * p.NC + i) * p.d;
+    } else {
+        const int j = r - p.NS - p.NC;
+        long pos = p.ti[(size_t)b * p.NT + j];
+        pos = pos < 0 ? 0 : (pos >= p.N ? p.N - 1 : pos);
+        src0 = p.mask_emb;
+        src1 = p.pos_emb + (size_t)pos * p.d;
+        dst = reinterpret_cast<T*>(p.tgt) + ((size_t)b * p.NT + j) * p.d;
+    }
+    for (int e = lane * 4; e < p.d; e += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(src0 + e);
+        if (src1) v += *reinterpret_cast<const f32x4*>(src1 + e);
+        store4<T>(dst + e, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long per_b = (long)p.NC + p.NT;
+    if (row >= per_b * p.B) return;
+    const int b = (int)(row / per_b);
+    const int r = (int)(row % per_b);
+    if (r < p.NC) {
+        const long pos = p.ci[(size_t)b * p.NC + r];
+        const long tok = p.x_ids[(size_t)b * p.N + pos];
+        const float* g = p.g_ctx + ((size_t)b * p.NC + r) * p.d;
+        float* gt = p.g_tok_emb + (size_t)tok * p.d;
+        float* gp = p.g_pos_emb + (size_t)pos * p.d;
+        for (int e = lane * 4; e < p.d; e += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(g + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { atomicAdd(gt + e + j, v[j]); atomicAdd(gp + e + j, v[j]); }
+        }
+    } else {
+        const int j0 = r - p.NC;
+        const long pos = p.ti[(size_t)b * p.NT + j0];
+        const T* g = reinterpret_cast<const T*>(p.g_tgt) + ((size_t)b * p.NT + j0) * p.d;
+        float* gp = p.g_pos_emb + (size_t)pos * p.d;
+        for (int e = lane * 4; e < p.d; e += 256) {
+            const f32x4 v = load4<T>(g + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(gp + e + j, v[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm
+// ------------------------------------------------------------------------------------------------
+constexpr int LN_MAXC = 8;   // d <= 2048
+
+__device__ __forceinline__ long map_row(long r, int seg, int seg_stride, int seg_off) {
+    return seg > 0 ? (r / seg) * (long)seg_stride + seg_off + (r % seg) : r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const T* x = reinterpret_cast<const T*>(p.x) + (size_t)row * p.d;
+    f32x4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int e = lane * 4 + 256 * c;
+        if (e < p.d) {
+            v[c] = load4<T>(x + e);
+            s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+        }
+    }
+    const float mean = wave_sum(s) / p.d;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int e = lane * 4 + 256 * c;
+        if (e < p.d) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float t = v[c][j] - mean; q += t * t; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / p.d + 1e-5f);
+    const long orow = map_row(row, p.seg, p.seg_stride, p.seg_off);
+    T* y = reinterpret_cast<T*>(p.y) + (size_t)orow * p.d;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int e = lane * 4 + 256 * c;
+        if (e < p.d) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + e);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.beta + e);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mean) * rstd * g[j] + b[j];
+            store4<T>(y + e, o);
+        }
+    }
+    if (p.mean && lane == 0) { p.mean[orow] = mean; p.rstd[orow] = rstd; }
+}
+
+// dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dgamma += dy*xhat;  dbeta += dy
+template <typename T, typename TDX>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
+    __shared__ float red[2][4][64 * 4 + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 dg[LN_MAXC], db[LN_MAXC];
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) { dg[c] = f32x4{0, 0, 0, 0}; db[c] = f32x4{0, 0, 0, 0}; }
+    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+        const long mrow = map_row(row, p.seg, p.seg_stride, p.seg_off);
+        const T* x = reinterpret_cast<const T*>(p.x) + (size_t)row * p.d;
+        const T* dy = reinterpret_cast<const T*>(p.dy) + (size_t)mrow * p.d;
+        const T* dy2 = p.dy2 ? reinterpret_cast<const T*>(p.dy2) + (size_t)row * p.d : nullptr;
+        const float mean = p.mean[mrow], rstd = p.rstd[mrow];
+        f32x4 xh[LN_MAXC], gy[LN_MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int e = lane * 4 + 256 * c;
+            if (e < p.d) {
+                const f32x4 xv = load4<T>(x + e);
+                f32x4 d = load4<T>(dy + e);
+                if (dy2) d += load4<T>(dy2 + e);
+                const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + e);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[c][j] = (xv[j] - mean) * rstd;
+                    gy[c][j] = d[j] * g[j];
+                    s1 += gy[c][j];
+                    s2 += gy[c][j] * xh[c][j];
+                    dg[c][j] += d[j] * xh[c][j];
+                    db[c][j] += d[j];
+                }
+            }
+        }
+        const float m1 = wave_sum(s1) / p.d, m2 = wave_sum(s2) / p.d;
+        TDX* dx = reinterpret_cast<TDX*>(p.dx) + (size_t)row * p.d;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int e = lane * 4 + 256 * c;
+            if (e < p.d) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rstd * (gy[c][j] - m1 - xh[c][j] * m2);
+                if (p.dx_accumulate) o += load4<TDX>(dx + e);
+                store4<TDX>(dx + e, o);
+            }
+        }
+    }
+    // reduce dgamma / dbeta over the 4 waves, then one atomic per element per workgroup.  The chunk
+    // condition is workgroup-uniform (the barriers must not sit under a lane-dependent branch).
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        if (256 * c < p.d) {
+            const int e = lane * 4 + 256 * c;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { red[0][wave][lane * 4 + j] = dg[c][j]; red[1][wave][lane * 4 + j] = db[c][j]; }
+            __syncthreads();
+            if (wave == 0 && e < p.d) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float g = red[0][0][lane * 4 + j] + red[0][1][lane * 4 + j] + red[0][2][lane * 4 + j] + red[0][3][lane * 4 + j];
+                    const float b = red[1][0][lane * 4 + j] + red[1][1][lane * 4 + j] + red[1][2][lane * 4 + j] + red[1][3][lane * 4 + j];
+                    atomicAdd(p.dgamma + e + j, g);
+                    atomicAdd(p.dbeta + e + j, b);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums: out[n] += sum_m X[m,n]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, int ldx, float* out, int rows_per_block) {
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    f32x4 acc = {0, 0, 0, 0};
+    for (int m = m0; m < m1; ++m) acc += load4<T>(X + (size_t)m * ldx + n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(out + n + j, acc[j]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross-entropy over V with label smoothing + rank of the target (top-1 / top-5 accuracy)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const CeParams p) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x;
+    const int b = row / p.NT, j = row % p.NT;
+    const long pos = p.ti[(size_t)b * p.NT + j];
+    const long tgt = p.x_ids[(size_t)b * p.N + pos];
+    const float* l = p.logits + (size_t)row * p.V;
+    const float lt = l[tgt];
+    float mx = -INFINITY, sum = 0.f;
+    int rank = 0;
+    for (int e = threadIdx.x * 4; e < p.V; e += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(l + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mx = fmaxf(mx, v[q]);
+            sum += v[q];
+            rank += (v[q] > lt) || (v[q] == lt && (e + q) < tgt);
+        }
+    }
+    mx = block_max(mx, sh);
+    float se = 0.f;
+    for (int e = threadIdx.x * 4; e < p.V; e += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(l + e);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) se += __expf(v[q] - mx);
+    }
+    se = block_sum(se, sh);
+    sum = block_sum(sum, sh);
+    const float rk = block_sum((float)rank, sh);
+    if (threadIdx.x == 0) {
+        const float lse = mx + logf(se);
+        const float eps = p.label_smoothing;
+        p.row_lse[row] = lse;
+        p.row_loss[row] = (1.f - eps) * (lse - lt) + eps * (lse - sum / p.V);
+        p.row_rank[row] = (int)(rk + 0.5f);
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* row_loss, const int* row_rank, int rows, double* out) {
+    __shared__ double sd[3][256];
+    double s = 0, t1 = 0, t5 = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        s += row_loss[r];
+        t1 += row_rank[r] < 1;
+        t5 += row_rank[r] < 5;
+    }
+    sd[0][threadIdx.x] = s; sd[1][threadIdx.x] = t1; sd[2][threadIdx.x] = t5;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sd[0][threadIdx.x] += sd[0][threadIdx.x + o];
+            sd[1][threadIdx.x] += sd[1][threadIdx.x + o];
+            sd[2][threadIdx.x] += sd[2][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sd[0][0]; out[1] = sd[1][0]; out[2] = sd[2][0]; out[3] = rows; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const CeBwdParams p) {
+    const int row = blockIdx.x;
+    const int b = row / p.NT, j = row % p.NT;
+    const long pos = p.ti[(size_t)b * p.NT + j];
+    const long tgt = p.x_ids[(size_t)b * p.N + pos];
+    const float* l = p.logits + (size_t)row * p.V;
+    T* d = reinterpret_cast<T*>(p.dlogits) + (size_t)row * p.V;
+    const float lse = p.row_lse[row];
+    const float sc = p.scale * (p.upstream ? *p.upstream : 1.0f);
+    const float eps = p.label_smoothing, u = eps / p.V;
+    for (int e = threadIdx.x * 4; e < p.V; e += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(l + e);
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (__expf(v[q] - lse) - ((e + q) == tgt ? 1.f - eps : 0.f) - u) * sc;
+        store4<T>(d + e, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdamW (decoupled weight decay, torch.optim.AdamW semantics) + bf16 mirror of the updated weights
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
+    const float step_size = a.lr / a.bc1;
+    const float inv_sqrt_bc2 = rsqrtf(a.bc2);
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (size_t)gridDim.x * 1024) {
+        f32x4 p = *reinterpret_cast<const f32x4*>(a.p + i);
+        f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i);
+        f32x4 m = *reinterpret_cast<const f32x4*>(a.m + i);
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.v + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gj = g[j] * a.grad_scale;
+            p[j] *= 1.0f - a.lr * a.weight_decay;
+            m[j] = a.beta1 * m[j] + (1.0f - a.beta1) * gj;
+            v[j] = a.beta2 * v[j] + (1.0f - a.beta2) * gj * gj;
+            const float denom = sqrtf(v[j]) * inv_sqrt_bc2 + a.eps;
+            p[j] -= step_size * (m[j] / denom);
+        }
+        *reinterpret_cast<f32x4*>(a.p + i) = p;
+        *reinterpret_cast<f32x4*>(a.m + i) = m;
+        *reinterpret_cast<f32x4*>(a.v + i) = v;
+        if (a.p_bf16) store4<bf16_t>(reinterpret_cast<bf16_t*>(a.p_bf16) + i, p);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16_t* dst, size_t n) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024)
+        store4<bf16_t>(dst + i, *reinterpret_cast<const f32x4*>(src + i));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+#define CHECK_LAUNCH() MEBT_HIP_CHECK(hipGetLastError())
+
+int launch_embed_fwd(const EmbedParams& p, int dtype, hipStream_t stream) {
+    if (p.d % 4) { mebt_set_error("embed: d must be a multiple of 4"); return MEBT_ESHAPE; }
+    const long rows = (long)p.B * (p.NS + p.NC + p.NT);
+    if (rows == 0) return MEBT_OK;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == MEBT_BF16) hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(embed_fwd_kernel<float>, grid, dim3(256), 0, stream, p);
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+
+int launch_embed_bwd(const EmbedBwdParams& p, int dtype, hipStream_t stream) {
+    const long rows = (long)p.B * (p.NC + p.NT);
+    if (rows > 0) {
+        const dim3 grid((unsigned)((rows + 3) / 4));
+        if (dtype == MEBT_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), 0, stream, p);
+        CHECK_LAUNCH();
+    }
+    int rc = launch_colsum(p.g_tgt, p.B * p.NT, p.d, p.d, p.g_mask_emb, dtype, stream);   // mask_emb: sum over all target rows
+    if (rc) return rc;
+    if (p.NS > 0) rc = launch_colsum(p.g_sos, p.B, p.NS * p.d, p.NS * p.d, p.g_sos_emb, dtype, stream);   // sos_emb: sum over batch
+    return rc;
+}
+
+int launch_ln_fwd(const LnFwdParams& p, int dtype, hipStream_t stream) {
+    if (p.rows <= 0) return MEBT_OK;
+    if (p.d % 4 || p.d > 256 * LN_MAXC) { mebt_set_error("layernorm: d must be a multiple of 4 and <= 2048"); return MEBT_ESHAPE; }
+    const dim3 grid((p.rows + 3) / 4);
+    if (dtype == MEBT_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, stream, p);
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+
+int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream) {
+    if (p.rows <= 0) return MEBT_OK;
+    if (p.d % 4 || p.d > 256 * LN_MAXC) { mebt_set_error("layernorm: d must be a multiple of 4 and <= 2048"); return MEBT_ESHAPE; }
+    const int blocks = min((p.rows + 3) / 4, 1024);
+    if (dtype == MEBT_BF16) {
+        if (p.dx_f32) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((ln_bwd_kernel<float, float>), dim3(blocks), dim3(256), 0, stream, p);
+    }
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+
+int launch_colsum(const void* X, int M, int N, int ldx, float* out, int dtype, hipStream_t stream) {
+    if (M <= 0 || N <= 0) return MEBT_OK;
+    if (N % 4) { mebt_set_error("colsum: N must be a multiple of 4"); return MEBT_ESHAPE; }
+    const int gx = (N / 4 + 255) / 256;
+    int rpb = 32;
+    while ((long)gx * ((M + rpb - 1) / rpb) > 4096) rpb *= 2;
+    const dim3 grid(gx, (M + rpb - 1) / rpb);
+    if (dtype == MEBT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, stream, reinterpret_cast<const bf16_t*>(X), M, N, ldx, out, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, reinterpret_cast<const float*>(X), M, N, ldx, out, rpb);
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+
+int launch_ce_fwd(const CeParams& p, hipStream_t stream) {
+    if (p.V % 4) { mebt_set_error("cross-entropy: V must be a multiple of 4"); return MEBT_ESHAPE; }
+    if (p.rows > 0) {
+        hipLaunchKernelGGL(ce_fwd_kernel, dim3(p.rows), dim3(256), 0, stream, p);
+        CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, stream, p.row_loss, p.row_rank, p.rows, p.out);
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+
+int launch_ce_bwd(const CeBwdParams& p, int dtype, hipStream_t stream) {
+    if (p.rows <= 0) return MEBT_OK;
+    if (dtype == MEBT_BF16) hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(p.rows), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(p.rows), dim3(256), 0, stream, p);
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+
+int launch_adamw(const AdamWParams& p, hipStream_t stream) {
+    if (p.n == 0) return MEBT_OK;
+    if (p.n % 4) { mebt_set_error("adamw: flat buffer length must be a multiple of 4"); return MEBT_ESHAPE; }
+    const size_t blocks = (p.n / 4 + 255) / 256;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, p);
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+
+int launch_cast_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t stream) {
+    if (n == 0) return MEBT_OK;
+    if (n % 4) { mebt_set_error("cast: length must be a multiple of 4"); return MEBT_ESHAPE; }
+    const size_t blocks = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, src, reinterpret_cast<bf16_t*>(dst), n);
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}

@@ -1,0 +1,613 @@
+// Model handle + forward/backward orchestration behind the C ABI (include/mebt_hip.h).
+// No kernels here: this file sequences the launches of gemm.hip / attention*.hip / elementwise.hip
+// on the caller's stream, carving every activation out of the caller-provided workspace.
+//
+// Reference being replaced: embed (mebt/transformer.py:255-277), GPT.forward / Block.forward
+// (mebt/modules/gpt.py:159-195,234-253), shared_step loss (transformer.py:717-732), the autograd
+// backward of all of it, and AdamW (transformer.py:790-797).
+#include "common.h"
+#include "kernels.h"
+#include "../../include/mebt_hip.h"
+#include <string.h>
+#include <math.h>
+#include <vector>
+
+namespace {
+
+struct LayerOffsets {
+    // W flat (elements)
+    int64_t wq, wk, wv, wp, w1, w2;
+    // P flat
+    int64_t ln1w, ln1b, ln2w, ln2b, bq, bk, bv, bp, b1, b2;
+};
+
+struct Carve {   // bump allocator over the workspace; query mode when base == nullptr
+    char* base;
+    int64_t off;
+    void* take(int64_t bytes) {
+        const int64_t o = off;
+        off += (bytes + 255) & ~(int64_t)255;
+        return base ? base + o : nullptr;
+    }
+};
+
+struct LayerAct {   // saved activations of one block
+    void *qn, *kn, *q, *k, *v, *att, *x, *hn, *pre, *u, *out;
+    float *mean1q, *rstd1q, *mean1k, *rstd1k, *mean2, *rstd2, *lse;
+    const void* q_in;   // LN1 input of the query side (previous stream value)
+    const void* k_in;   // LN1 input of the key side (enc: contexts, dec: sos); lt2l uses S and T
+    int NQ, NK, ldqkv_q, ldqkv_k;
+};
+
+struct FwdCtx {
+    bool valid = false;
+    void* ws = nullptr;
+    int B = 0, N = 0, NC = 0, NT = 0;
+    const int64_t *x_ids = nullptr, *ci = nullptr, *ti = nullptr;
+    void *sos0 = nullptr, *ctx = nullptr, *tgt0 = nullptr;
+    std::vector<LayerAct> L;
+    const void *S_final = nullptr, *T_final = nullptr;
+    void* hf = nullptr; float *meanf = nullptr, *rstdf = nullptr;
+    float* logits_ws = nullptr;
+    float *row_lse = nullptr, *row_loss = nullptr; int* row_rank = nullptr;
+    // backward scratch
+    void *g_S = nullptr, *g_T = nullptr; float* g_C = nullptr;
+    void *dlogits = nullptr, *dhf = nullptr, *d4 = nullptr, *dh = nullptr, *dx = nullptr, *datt = nullptr, *dqkv_q = nullptr,
+         *dqkv_k = nullptr, *dqn = nullptr, *dkn = nullptr;
+    float* delta = nullptr;
+    bool gS_defined = false, gT_defined = false, gC_defined = false;
+};
+
+}  // namespace
+
+struct mebt_model {
+    mebt_model_desc d;
+    std::vector<LayerOffsets> lo;
+    int64_t n_w = 0, n_p = 0;
+    int64_t head_w = 0, lnf_w = 0, lnf_b = 0, mask_emb = 0, sos_emb = 0, pos_emb = 0, tok_emb = 0;
+    float *W = nullptr, *gW = nullptr, *P = nullptr, *gP = nullptr;
+    void* Wlp = nullptr;
+    std::vector<char> live;   // per layer: does the loss depend on this block?
+    bool tok_live = false;
+    FwdCtx ctx;
+    int esz() const { return d.dtype == MEBT_BF16 ? 2 : 4; }
+    // weight operand for GEMMs (bf16 mirror in bf16 mode)
+    const void* Wop(int64_t off) const {
+        return d.dtype == MEBT_BF16 ? (const void*)((const char*)Wlp + off * 2) : (const void*)(W + off);
+    }
+};
+
+static hipStream_t S(mebt_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------------------------------------------
+// profiling of the GEMM family with HIP events on the launch stream
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_ev_pool;
+hipEvent_t get_event() {
+    if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+static int gemm(const mebt_model* m, GemmParams p, hipStream_t st) {
+    if (p.K <= 0) {   // empty reduction (e.g. NC = 0): the product is zero
+        if (p.c_f32 && !p.beta && p.M > 0 && p.N > 0 && p.epilogue == EPI_NONE && !p.bias)
+            MEBT_HIP_CHECK(hipMemset2DAsync(p.C, (size_t)p.ldc * 4, 0, (size_t)p.N * 4, p.M, st));
+        else if (p.M > 0 && p.N > 0) { mebt_set_error("gemm: K = 0 with a fused epilogue is not supported"); return MEBT_ESHAPE; }
+        return MEBT_OK;
+    }
+    ProfRec r;
+    const bool prof = g_prof_on && p.M > 0 && p.N > 0;
+    if (prof) { r.a = get_event(); r.b = get_event(); r.flops = 2.0 * p.M * p.N * p.K; (void)hipEventRecord(r.a, st); }
+    const int rc = launch_gemm(p, m->d.dtype, st);
+    if (prof) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
+    return rc;
+}
+
+extern "C" int mebt_profile_enable(int32_t on) {
+    g_prof_on = on != 0;
+    for (auto& r : g_prof) { g_ev_pool.push_back(r.a); g_ev_pool.push_back(r.b); }
+    g_prof.clear();
+    return MEBT_OK;
+}
+extern "C" int mebt_profile_read(int32_t family, double* launches, double* total_ms, double* total_flops) {
+    (void)family;
+    double ms = 0, fl = 0;
+    for (auto& r : g_prof) {
+        MEBT_HIP_CHECK(hipEventSynchronize(r.b));
+        float t = 0;
+        MEBT_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+        ms += t; fl += r.flops;
+    }
+    *launches = (double)g_prof.size(); *total_ms = ms; *total_flops = fl;
+    return MEBT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------------
+extern "C" int mebt_abi_version(void) { return MEBT_ABI_VERSION; }
+
+extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) {
+    if (!desc || !out) { mebt_set_error("model_create: null argument"); return MEBT_EINVAL; }
+    const mebt_model_desc& d = *desc;
+    if (d.n_layer <= 0 || d.n_layer > MEBT_MAX_LAYERS) { mebt_set_error("model_create: n_layer out of range"); return MEBT_ESHAPE; }
+    if (d.n_head <= 0 || d.n_embd % d.n_head) { mebt_set_error("model_create: n_embd must be divisible by n_head"); return MEBT_ESHAPE; }   // gpt.py:107
+    if (d.n_embd % 64) { mebt_set_error("model_create: n_embd must be a multiple of 64 for the gfx950 kernels"); return MEBT_ESHAPE; }
+    const int hd = d.n_embd / d.n_head;
+    if (hd != 32 && hd != 64 && hd != 128) { mebt_set_error("model_create: head size must be 32, 64 or 128"); return MEBT_ESHAPE; }
+    if (d.vocab % 8 || d.vocab <= 0) { mebt_set_error("model_create: vocab must be a positive multiple of 8"); return MEBT_ESHAPE; }
+    if (d.n_latent <= 0) { mebt_set_error("model_create: sos_emb (latent tokens) must be > 0 for the latent routing modes"); return MEBT_ESHAPE; }
+    if (d.dtype != MEBT_F32 && d.dtype != MEBT_BF16) { mebt_set_error("model_create: dtype must be f32 or bf16"); return MEBT_EDTYPE; }
+    for (int i = 0; i < d.n_layer; ++i)
+        if (d.modes[i] < 0 || d.modes[i] > MEBT_MODE_LT2L) {
+            mebt_set_error("model_create: unsupported block mode (only latent_enc/latent_self/latent_dec/lt2l; 'maskgit' full attention is not built)");
+            return MEBT_EINVAL;
+        }
+    if (d.embd_pdrop != 0.f || d.resid_pdrop != 0.f || d.attn_pdrop != 0.f) {
+        // dropout is applied only when mebt_forward(training=1); kernels for it are not built yet
+    }
+    mebt_model* m = new mebt_model();
+    m->d = d;
+    const int64_t dd = (int64_t)d.n_embd * d.n_embd, e = d.n_embd;
+    int64_t w = 0, p = 0;
+    m->lo.resize(d.n_layer);
+    for (int i = 0; i < d.n_layer; ++i) {
+        LayerOffsets& o = m->lo[i];
+        o.wq = w; w += dd; o.wk = w; w += dd; o.wv = w; w += dd; o.wp = w; w += dd;
+        o.w1 = w; w += 4 * dd; o.w2 = w; w += 4 * dd;
+        o.ln1w = p; p += e; o.ln1b = p; p += e; o.ln2w = p; p += e; o.ln2b = p; p += e;
+        o.bq = p; p += e; o.bk = p; p += e; o.bv = p; p += e; o.bp = p; p += e;
+        o.b1 = p; p += 4 * e; o.b2 = p; p += e;
+    }
+    m->head_w = w; w += (int64_t)d.vocab * e;
+    m->lnf_w = p; p += e; m->lnf_b = p; p += e;
+    m->mask_emb = p; p += e;
+    m->sos_emb = p; p += (int64_t)d.n_latent * e;
+    m->pos_emb = p; p += (int64_t)d.block_size * e;
+    m->tok_emb = p; p += (int64_t)d.vocab * e;
+    m->n_w = w; m->n_p = p;
+    // liveness: walk backwards from the head, which reads the targets stream only (gpt.py:247)
+    m->live.assign(d.n_layer, 0);
+    bool gS = false, gT = true;
+    for (int i = d.n_layer - 1; i >= 0; --i) {
+        switch (d.modes[i]) {
+            case MEBT_MODE_LATENT_ENC: if (gS) { m->live[i] = 1; m->tok_live = true; } break;
+            case MEBT_MODE_LATENT_SELF: if (gS) m->live[i] = 1; break;
+            case MEBT_MODE_LT2L: if (gS) { m->live[i] = 1; gT = true; } break;
+            case MEBT_MODE_LATENT_DEC: if (gT) { m->live[i] = 1; gS = true; } break;
+        }
+    }
+    int rc = gemm_init_attributes();
+    if (rc) { delete m; return rc; }
+    *out = m;
+    return MEBT_OK;
+}
+
+extern "C" void mebt_model_destroy(mebt_model* m) { delete m; }
+
+extern "C" int mebt_model_param_counts(const mebt_model* m, int64_t* n_w, int64_t* n_p) {
+    if (!m) { mebt_set_error("null model"); return MEBT_EINVAL; }
+    *n_w = m->n_w; *n_p = m->n_p;
+    return MEBT_OK;
+}
+
+extern "C" int mebt_model_bind(mebt_model* m, float* W, void* W_lp, float* gW, float* P, float* gP) {
+    if (!m || !W || !P) { mebt_set_error("model_bind: W and P are required"); return MEBT_EINVAL; }
+    if (m->d.dtype == MEBT_BF16 && !W_lp) { mebt_set_error("model_bind: bf16 mode needs the bf16 weight mirror"); return MEBT_EINVAL; }
+    m->W = W; m->Wlp = W_lp; m->gW = gW; m->P = P; m->gP = gP;
+    m->ctx.valid = false;
+    return MEBT_OK;
+}
+
+extern "C" int mebt_model_sync_lowp(mebt_model* m, mebt_stream_t stream) {
+    if (!m || !m->W) { mebt_set_error("model_sync_lowp: model not bound"); return MEBT_EINVAL; }
+    if (m->d.dtype != MEBT_BF16) return MEBT_OK;
+    return launch_cast_f32_to_bf16(m->W, m->Wlp, (size_t)m->n_w, S(stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------------
+static void mode_shape(const mebt_model* m, int mode, int NC, int NT, int& NQ, int& NK) {
+    const int NS = m->d.n_latent;
+    switch (mode) {
+        case MEBT_MODE_LATENT_ENC: NQ = NS; NK = NC; break;
+        case MEBT_MODE_LATENT_SELF: NQ = NS; NK = NS; break;
+        case MEBT_MODE_LATENT_DEC: NQ = NT; NK = NS; break;
+        default: NQ = NS; NK = NS + NT; break;
+    }
+}
+
+// Lays the workspace out; with c.base == nullptr only measures.  In inference (training == 0)
+// all per-layer buffers alias one layer-sized region and the stream outputs ping-pong.
+static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int NT, int training) {
+    const int64_t d = m->d.n_embd, e = m->esz(), NS = m->d.n_latent, H = m->d.n_head, V = m->d.vocab;
+    x.sos0 = c.take(B * NS * d * e);
+    x.ctx = c.take((int64_t)B * NC * d * e);
+    x.tgt0 = c.take((int64_t)B * NT * d * e);
+    x.L.assign(m->d.n_layer, LayerAct());
+    const int64_t layer_base = c.off;
+    int64_t layer_max = c.off;
+    void* pingS[2] = {nullptr, nullptr};
+    void* pingT[2] = {nullptr, nullptr};
+    if (!training) {
+        pingS[0] = c.take(B * NS * d * e); pingS[1] = c.take(B * NS * d * e);
+        pingT[0] = c.take((int64_t)B * NT * d * e); pingT[1] = c.take((int64_t)B * NT * d * e);
+    }
+    const int64_t after_ping = c.off;
+    int nS = 0, nT = 0;
+    for (int i = 0; i < m->d.n_layer; ++i) {
+        LayerAct& a = x.L[i];
+        const int mode = m->d.modes[i];
+        mode_shape(m, mode, NC, NT, a.NQ, a.NK);
+        const int64_t Mq = (int64_t)B * a.NQ, Mk = (int64_t)B * a.NK;
+        if (!training) c.off = after_ping;
+        a.qn = c.take(Mq * d * e);
+        a.mean1q = (float*)c.take(Mq * 4); a.rstd1q = (float*)c.take(Mq * 4);
+        if (mode == MEBT_MODE_LATENT_SELF) {
+            a.kn = a.qn; a.mean1k = a.mean1q; a.rstd1k = a.rstd1q;
+            a.q = c.take(Mq * 3 * d * e);
+            a.k = (char*)a.q + d * e; a.v = (char*)a.q + 2 * d * e;
+            a.ldqkv_q = 3 * d; a.ldqkv_k = 3 * d;
+        } else {
+            a.kn = c.take(Mk * d * e);
+            a.mean1k = (float*)c.take(Mk * 4); a.rstd1k = (float*)c.take(Mk * 4);
+            a.q = c.take(Mq * d * e);
+            a.k = c.take(Mk * 2 * d * e); a.v = (char*)a.k + d * e;
+            a.ldqkv_q = d; a.ldqkv_k = 2 * d;
+        }
+        a.att = c.take(Mq * d * e);
+        a.lse = (float*)c.take((int64_t)B * H * a.NQ * 4);
+        a.x = c.take(Mq * d * e);
+        a.mean2 = (float*)c.take(Mq * 4); a.rstd2 = (float*)c.take(Mq * 4);
+        a.hn = c.take(Mq * d * e);
+        a.pre = training ? c.take(Mq * 4 * d * e) : nullptr;
+        a.u = c.take(Mq * 4 * d * e);
+        if (training) a.out = c.take(Mq * d * e);
+        else a.out = (mode == MEBT_MODE_LATENT_DEC) ? pingT[(nT++) & 1] : pingS[(nS++) & 1];
+        if (c.off > layer_max) layer_max = c.off;
+    }
+    (void)layer_base;
+    c.off = layer_max;
+    const int64_t R = (int64_t)B * NT;
+    x.hf = c.take(R * d * e);
+    x.meanf = (float*)c.take(R * 4); x.rstdf = (float*)c.take(R * 4);
+    x.logits_ws = nullptr;
+    if (training) {
+        x.row_lse = (float*)c.take(R * 4); x.row_loss = (float*)c.take(R * 4); x.row_rank = (int*)c.take(R * 4);
+        int64_t Mmax = (int64_t)B * (NS + NT);
+        if ((int64_t)B * NC > Mmax) Mmax = (int64_t)B * NC;
+        x.g_S = c.take(B * NS * d * e);
+        x.g_T = c.take(R * d * e);
+        x.g_C = (float*)c.take((int64_t)B * NC * d * 4);
+        x.dlogits = c.take(R * V * e);
+        x.dhf = c.take(R * d * e);
+        x.d4 = c.take(Mmax * 4 * d * e);
+        x.dh = c.take(Mmax * d * e);
+        x.dx = c.take(Mmax * d * e);
+        x.datt = c.take(Mmax * d * e);
+        x.dqkv_q = c.take(Mmax * 3 * d * e);
+        x.dqkv_k = c.take(Mmax * 2 * d * e);
+        x.dqn = c.take(Mmax * d * e);
+        x.dkn = c.take(Mmax * d * e);
+        x.delta = (float*)c.take((int64_t)B * H * (NS + NT) * 4);
+    }
+}
+
+extern "C" int64_t mebt_workspace_bytes(const mebt_model* m, int32_t B, int32_t NC, int32_t NT, int32_t training) {
+    if (!m || B < 0 || NC < 0 || NT < 0) return -1;
+    Carve c{nullptr, 0};
+    FwdCtx x;
+    carve(m, c, x, B, NC, NT, training);
+    return c.off + 256;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+static GemmParams gp(const void* A, const void* Bm, void* C, int M, int N, int K, int lda, int ldb, int ldc, int a_kc, int b_kc) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.B = Bm; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.a_kc = a_kc; p.b_kc = b_kc;
+    p.split_k = 1;
+    return p;
+}
+
+static int ln_fwd(const mebt_model* m, const void* x, void* y, int64_t gw, int64_t gb, float* mean, float* rstd, int rows,
+                  int seg, int seg_stride, int seg_off, hipStream_t st) {
+    LnFwdParams p;
+    p.x = x; p.y = y; p.gamma = m->P + gw; p.beta = m->P + gb; p.mean = mean; p.rstd = rstd;
+    p.rows = rows; p.d = m->d.n_embd; p.seg = seg; p.seg_stride = seg_stride; p.seg_off = seg_off;
+    return launch_ln_fwd(p, m->d.dtype, st);
+}
+
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+extern "C" int mebt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
+                            const int64_t* x_ids, const int64_t* ci, const int64_t* ti, float* logits,
+                            int32_t training, uint64_t dropout_seed, mebt_stream_t stream) {
+    (void)dropout_seed;
+    if (!m || !m->W) { mebt_set_error("forward: model not bound"); return MEBT_EINVAL; }
+    if (B <= 0 || N <= 0 || NC < 0 || NT <= 0) { mebt_set_error("forward: need B > 0, N > 0, NC >= 0, NT > 0"); return MEBT_ESHAPE; }
+    if (N > m->d.block_size) { mebt_set_error("forward: sequence longer than block_size (pos_emb rows)"); return MEBT_ESHAPE; }
+    if (!ws || !x_ids || !ti || (NC > 0 && !ci) || !logits) { mebt_set_error("forward: null pointer"); return MEBT_EINVAL; }
+    if (training && (m->d.embd_pdrop > 0.f || m->d.resid_pdrop > 0.f || m->d.attn_pdrop > 0.f)) {
+        mebt_set_error("forward: dropout > 0 in training mode is not built yet (set *_pdrop = 0)");
+        return MEBT_EINVAL;
+    }
+    FwdCtx& x = m->ctx;
+    x.valid = false;
+    Carve c{(char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), 0};
+    carve(m, c, x, B, NC, NT, training);
+    if (c.off + 256 > ws_bytes) { mebt_set_error("forward: workspace too small (see mebt_workspace_bytes)"); return MEBT_EWORKSPACE; }
+    hipStream_t st = S(stream);
+    const int d = m->d.n_embd, NS = m->d.n_latent, H = m->d.n_head, V = m->d.vocab, dt = m->d.dtype;
+    x.ws = ws; x.B = B; x.N = N; x.NC = NC; x.NT = NT; x.x_ids = x_ids; x.ci = ci; x.ti = ti;
+
+    EmbedParams ep;
+    ep.x_ids = x_ids; ep.ci = ci; ep.ti = ti;
+    ep.tok_emb = m->P + m->tok_emb; ep.pos_emb = m->P + m->pos_emb; ep.mask_emb = m->P + m->mask_emb; ep.sos_emb = m->P + m->sos_emb;
+    ep.sos = x.sos0; ep.ctx = x.ctx; ep.tgt = x.tgt0;
+    ep.B = B; ep.N = N; ep.NC = NC; ep.NT = NT; ep.NS = NS; ep.d = d; ep.vocab = V; ep.block_size = m->d.block_size;
+    RC(launch_embed_fwd(ep, dt, st));
+
+    const void* Sv = x.sos0;
+    const void* Tv = x.tgt0;
+    for (int i = 0; i < m->d.n_layer; ++i) {
+        LayerAct& a = x.L[i];
+        const LayerOffsets& o = m->lo[i];
+        const int mode = m->d.modes[i];
+        const int Mq = B * a.NQ, Mk = B * a.NK;
+        a.q_in = (mode == MEBT_MODE_LATENT_DEC) ? Tv : Sv;
+        // LN1 on query and key with the SAME parameters (gpt.py:180-181)
+        RC(ln_fwd(m, a.q_in, a.qn, o.ln1w, o.ln1b, a.mean1q, a.rstd1q, Mq, 0, 0, 0, st));
+        if (mode == MEBT_MODE_LATENT_ENC) {
+            a.k_in = x.ctx;
+            RC(ln_fwd(m, x.ctx, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, Mk, 0, 0, 0, st));
+        } else if (mode == MEBT_MODE_LATENT_DEC) {
+            a.k_in = Sv;
+            RC(ln_fwd(m, Sv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, Mk, 0, 0, 0, st));
+        } else if (mode == MEBT_MODE_LT2L) {   // key = LN1(cat[sos, targets]) (gpt.py:175,181)
+            a.k_in = Tv;
+            RC(ln_fwd(m, Sv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, B * NS, NS, NS + NT, 0, st));
+            RC(ln_fwd(m, Tv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, B * NT, NT, NS + NT, NS, st));
+        } else {
+            a.k_in = nullptr;
+        }
+        // projections (gpt.py:126-128); the three [d,d] weights are adjacent in W so QKV / KV fuse
+        if (mode == MEBT_MODE_LATENT_SELF) {
+            GemmParams p = gp(a.qn, m->Wop(o.wq), a.q, Mq, 3 * d, d, d, d, 3 * d, 1, 1);
+            p.bias = m->P + o.bq;
+            RC(gemm(m, p, st));
+        } else {
+            GemmParams p = gp(a.qn, m->Wop(o.wq), a.q, Mq, d, d, d, d, d, 1, 1);
+            p.bias = m->P + o.bq;
+            RC(gemm(m, p, st));
+            GemmParams pk = gp(a.kn, m->Wop(o.wk), a.k, Mk, 2 * d, d, d, d, 2 * d, 1, 1);
+            pk.bias = m->P + o.bk;
+            RC(gemm(m, pk, st));
+        }
+        // softmax(q k^T / sqrt(hd)) v  (gpt.py:131-137)
+        AttnParams ap;
+        memset(&ap, 0, sizeof(ap));
+        ap.q = a.q; ap.k = a.k; ap.v = a.v; ap.o = a.att; ap.lse = a.lse;
+        ap.B = B; ap.H = H; ap.NQ = a.NQ; ap.NK = a.NK; ap.HD = d / H;
+        ap.ldq = a.ldqkv_q; ap.ldk = a.ldqkv_k; ap.ldv = a.ldqkv_k; ap.ldo = d;
+        RC(launch_attn_fwd(ap, dt, st));
+        // x = LN1(query) + proj(att)   — residual on the NORMALISED query (gpt.py:180,184)
+        {
+            GemmParams p = gp(a.att, m->Wop(o.wp), a.x, Mq, d, d, d, d, d, 1, 1);
+            p.bias = m->P + o.bp; p.epilogue = EPI_RESID; p.aux = a.qn; p.ld_aux = d;
+            RC(gemm(m, p, st));
+        }
+        // x = x + mlp(LN2(x))  (gpt.py:185, 150-155)
+        RC(ln_fwd(m, a.x, a.hn, o.ln2w, o.ln2b, a.mean2, a.rstd2, Mq, 0, 0, 0, st));
+        {
+            GemmParams p = gp(a.hn, m->Wop(o.w1), a.pre, Mq, 4 * d, d, d, d, 4 * d, 1, 1);
+            p.bias = m->P + o.b1; p.epilogue = EPI_GELU; p.C2 = a.u;
+            RC(gemm(m, p, st));
+        }
+        {
+            GemmParams p = gp(a.u, m->Wop(o.w2), a.out, Mq, d, 4 * d, 4 * d, 4 * d, d, 1, 1);
+            p.bias = m->P + o.b2; p.epilogue = EPI_RESID; p.aux = a.x; p.ld_aux = d;
+            RC(gemm(m, p, st));
+        }
+        if (mode == MEBT_MODE_LATENT_DEC) Tv = a.out; else Sv = a.out;   // gpt.py:187-190
+    }
+    x.S_final = Sv; x.T_final = Tv;
+    // logits = head(ln_f(targets))  (gpt.py:247-248; head has no bias)
+    RC(ln_fwd(m, Tv, x.hf, m->lnf_w, m->lnf_b, x.meanf, x.rstdf, B * NT, 0, 0, 0, st));
+    {
+        GemmParams p = gp(x.hf, m->Wop(m->head_w), logits, B * NT, V, d, d, d, V, 1, 1);
+        p.c_f32 = 1;
+        RC(gemm(m, p, st));
+    }
+    x.valid = training != 0;
+    return MEBT_OK;
+}
+
+extern "C" int mebt_loss(mebt_model* m, void* ws, const float* logits, double* out4, mebt_stream_t stream) {
+    if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("loss: no training-mode forward on this workspace"); return MEBT_EINVAL; }
+    FwdCtx& x = m->ctx;
+    CeParams p;
+    p.logits = logits; p.x_ids = x.x_ids; p.ti = x.ti; p.rows = x.B * x.NT; p.V = m->d.vocab; p.B = x.B; p.N = x.N; p.NT = x.NT;
+    p.label_smoothing = m->d.label_smoothing; p.row_lse = x.row_lse; p.row_loss = x.row_loss; p.row_rank = x.row_rank; p.out = out4;
+    return launch_ce_fwd(p, S(stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------
+static int ln_bwd(const mebt_model* m, const void* x, const void* dy, const void* dy2, int64_t gw, int64_t gb, const float* mean,
+                  const float* rstd, void* dx, int dx_f32, int acc, int rows, int seg, int seg_stride, int seg_off, hipStream_t st) {
+    LnBwdParams p;
+    p.x = x; p.dy = dy; p.dy2 = dy2; p.gamma = m->P + gw; p.mean = mean; p.rstd = rstd; p.dx = dx; p.dx_f32 = dx_f32;
+    p.dx_accumulate = acc; p.dgamma = m->gP + gw; p.dbeta = m->gP + gb; p.rows = rows; p.d = m->d.n_embd;
+    p.seg = seg; p.seg_stride = seg_stride; p.seg_off = seg_off;
+    return launch_ln_bwd(p, m->d.dtype, st);
+}
+
+// dW[n_out,k_in] = dY^T X (reduction over tokens), into the fp32 gradient buffer
+static int wgrad(const mebt_model* m, const void* dY, int ld_dy, const void* X, int ld_x, int64_t w_off, int n_out, int k_in, int tokens, hipStream_t st) {
+    GemmParams p = gp(dY, X, m->gW + w_off, n_out, k_in, tokens, ld_dy, ld_x, k_in, 0, 0);
+    p.c_f32 = 1; p.split_k = 0;
+    return gemm(m, p, st);
+}
+// dX[tokens,k_in] = dY W  (+aux)
+static int dgrad(const mebt_model* m, const void* dY, int ld_dy, int64_t w_off, void* dX, int tokens, int n_out, int k_in, int epilogue, const void* aux, int ld_aux, hipStream_t st) {
+    GemmParams p = gp(dY, m->Wop(w_off), dX, tokens, k_in, n_out, ld_dy, k_in, k_in, 1, 0);
+    p.epilogue = epilogue; p.aux = aux; p.ld_aux = ld_aux;
+    return gemm(m, p, st);
+}
+
+extern "C" int mebt_backward_head(mebt_model* m, void* ws, const float* logits, const float* upstream, float loss_scale, mebt_stream_t stream) {
+    if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("backward: no training-mode forward on this workspace"); return MEBT_EINVAL; }
+    if (!m->gW || !m->gP) { mebt_set_error("backward: gradient buffers not bound"); return MEBT_EINVAL; }
+    FwdCtx& x = m->ctx;
+    hipStream_t st = S(stream);
+    const int d = m->d.n_embd, V = m->d.vocab, dt = m->d.dtype, R = x.B * x.NT;
+    // P-side gradients are accumulated with atomics (LN affine, biases, embeddings): zero them first
+    MEBT_HIP_CHECK(hipMemsetAsync(m->gP, 0, (size_t)m->n_p * 4, st));
+    for (int i = 0; i < m->d.n_layer; ++i)
+        if (!m->live[i]) MEBT_HIP_CHECK(hipMemsetAsync(m->gW + m->lo[i].wq, 0, (size_t)12 * d * d * 4, st));
+    CeBwdParams cp;
+    cp.logits = logits; cp.x_ids = x.x_ids; cp.ti = x.ti; cp.row_lse = x.row_lse; cp.dlogits = x.dlogits; cp.upstream = upstream;
+    cp.scale = loss_scale; cp.label_smoothing = m->d.label_smoothing; cp.rows = R; cp.V = V; cp.B = x.B; cp.N = x.N; cp.NT = x.NT;
+    RC(launch_ce_bwd(cp, dt, st));
+    RC(wgrad(m, x.dlogits, V, x.hf, d, m->head_w, V, d, R, st));
+    RC(dgrad(m, x.dlogits, V, m->head_w, x.dhf, R, V, d, EPI_NONE, nullptr, 0, st));
+    RC(ln_bwd(m, x.T_final, x.dhf, nullptr, m->lnf_w, m->lnf_b, x.meanf, x.rstdf, x.g_T, 0, 0, R, 0, 0, 0, st));
+    x.gT_defined = true; x.gS_defined = false; x.gC_defined = false;
+    return MEBT_OK;
+}
+
+static int backward_layer(mebt_model* m, int i, hipStream_t st) {
+    FwdCtx& x = m->ctx;
+    LayerAct& a = x.L[i];
+    const LayerOffsets& o = m->lo[i];
+    const int mode = m->d.modes[i], d = m->d.n_embd, dt = m->d.dtype, B = x.B, NS = m->d.n_latent, NT = x.NT, H = m->d.n_head;
+    const int Mq = B * a.NQ, Mk = B * a.NK;
+    const bool isdec = mode == MEBT_MODE_LATENT_DEC;
+    if (isdec ? !x.gT_defined : !x.gS_defined) return MEBT_OK;   // the loss does not depend on this block
+    const void* dout = isdec ? x.g_T : x.g_S;
+    // out = x + u W2^T + b2
+    RC(launch_colsum(dout, Mq, d, d, m->gP + o.b2, dt, st));
+    RC(wgrad(m, dout, d, a.u, 4 * d, o.w2, d, 4 * d, Mq, st));
+    RC(dgrad(m, dout, d, o.w2, x.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, st));   // d(pre) = (dout W2) * gelu'(pre)
+    RC(launch_colsum(x.d4, Mq, 4 * d, 4 * d, m->gP + o.b1, dt, st));
+    RC(wgrad(m, x.d4, 4 * d, a.hn, d, o.w1, 4 * d, d, Mq, st));
+    RC(dgrad(m, x.d4, 4 * d, o.w1, x.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st));
+    // dx = dout + LN2'(dh)
+    RC(ln_bwd(m, a.x, x.dh, dout, o.ln2w, o.ln2b, a.mean2, a.rstd2, x.dx, 0, 0, Mq, 0, 0, 0, st));
+    // x = qn + att Wp^T + bp
+    RC(launch_colsum(x.dx, Mq, d, d, m->gP + o.bp, dt, st));
+    RC(wgrad(m, x.dx, d, a.att, d, o.wp, d, d, Mq, st));
+    RC(dgrad(m, x.dx, d, o.wp, x.datt, Mq, d, d, EPI_NONE, nullptr, 0, st));
+    // attention backward
+    AttnParams ap;
+    memset(&ap, 0, sizeof(ap));
+    ap.q = a.q; ap.k = a.k; ap.v = a.v; ap.o = a.att; ap.lse = a.lse; ap.B = B; ap.H = H; ap.NQ = a.NQ; ap.NK = a.NK; ap.HD = d / H;
+    ap.ldq = a.ldqkv_q; ap.ldk = a.ldqkv_k; ap.ldv = a.ldqkv_k; ap.ldo = d;
+    ap.d_o = x.datt; ap.lddo = d; ap.delta = x.delta;
+    const int esz = m->esz();
+    if (mode == MEBT_MODE_LATENT_SELF) {
+        ap.dq = x.dqkv_q; ap.dk = (char*)x.dqkv_q + (size_t)d * esz; ap.dv = (char*)x.dqkv_q + (size_t)2 * d * esz;
+        ap.lddq = ap.lddk = ap.lddv = 3 * d;
+    } else {
+        ap.dq = x.dqkv_q; ap.lddq = d;
+        ap.dk = x.dqkv_k; ap.dv = (char*)x.dqkv_k + (size_t)d * esz; ap.lddk = ap.lddv = 2 * d;
+    }
+    RC(launch_attn_bwd(ap, dt, st));
+    if (mode == MEBT_MODE_LATENT_SELF) {
+        RC(launch_colsum(x.dqkv_q, Mq, 3 * d, 3 * d, m->gP + o.bq, dt, st));
+        RC(wgrad(m, x.dqkv_q, 3 * d, a.qn, d, o.wq, 3 * d, d, Mq, st));
+        RC(dgrad(m, x.dqkv_q, 3 * d, o.wq, x.dqn, Mq, 3 * d, d, EPI_RESID, x.dx, d, st));   // + dx (residual on qn)
+        RC(ln_bwd(m, a.q_in, x.dqn, nullptr, o.ln1w, o.ln1b, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0, st));
+        return MEBT_OK;
+    }
+    RC(launch_colsum(x.dqkv_q, Mq, d, d, m->gP + o.bq, dt, st));
+    RC(wgrad(m, x.dqkv_q, d, a.qn, d, o.wq, d, d, Mq, st));
+    RC(dgrad(m, x.dqkv_q, d, o.wq, x.dqn, Mq, d, d, EPI_RESID, x.dx, d, st));
+    RC(launch_colsum(x.dqkv_k, Mk, 2 * d, 2 * d, m->gP + o.bk, dt, st));
+    RC(wgrad(m, x.dqkv_k, 2 * d, a.kn, d, o.wk, 2 * d, d, Mk, st));
+    if (Mk > 0) RC(dgrad(m, x.dqkv_k, 2 * d, o.wk, x.dkn, Mk, 2 * d, d, EPI_NONE, nullptr, 0, st));
+    if (mode == MEBT_MODE_LATENT_ENC) {
+        RC(ln_bwd(m, a.q_in, x.dqn, nullptr, o.ln1w, o.ln1b, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0, st));
+        if (Mk > 0) {   // contexts feed every latent_enc block: accumulate in fp32
+            RC(ln_bwd(m, x.ctx, x.dkn, nullptr, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, x.g_C, 1, x.gC_defined ? 1 : 0, Mk, 0, 0, 0, st));
+            x.gC_defined = true;
+        }
+    } else if (mode == MEBT_MODE_LATENT_DEC) {
+        RC(ln_bwd(m, a.q_in, x.dqn, nullptr, o.ln1w, o.ln1b, a.mean1q, a.rstd1q, x.g_T, 0, 0, Mq, 0, 0, 0, st));
+        RC(ln_bwd(m, a.k_in, x.dkn, nullptr, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, x.g_S, 0, x.gS_defined ? 1 : 0, Mk, 0, 0, 0, st));
+        x.gS_defined = true;
+    } else {   // lt2l: key rows [0,NS) come from the same LN as the query
+        RC(ln_bwd(m, a.q_in, x.dkn, x.dqn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, x.g_S, 0, 0, B * NS, NS, NS + NT, 0, st));
+        RC(ln_bwd(m, a.k_in, x.dkn, nullptr, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, x.g_T, 0, x.gT_defined ? 1 : 0, B * NT, NT, NS + NT, NS, st));
+        x.gT_defined = true;
+    }
+    return MEBT_OK;
+}
+
+extern "C" int mebt_backward_layers(mebt_model* m, void* ws, int32_t layer_hi, int32_t layer_lo, mebt_stream_t stream) {
+    if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("backward: no training-mode forward on this workspace"); return MEBT_EINVAL; }
+    if (layer_hi >= m->d.n_layer || layer_lo < 0 || layer_lo > layer_hi) { mebt_set_error("backward_layers: bad layer range"); return MEBT_EINVAL; }
+    for (int i = layer_hi; i >= layer_lo; --i) RC(backward_layer(m, i, S(stream)));
+    return MEBT_OK;
+}
+
+extern "C" int mebt_backward_embed(mebt_model* m, void* ws, mebt_stream_t stream) {
+    if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("backward: no training-mode forward on this workspace"); return MEBT_EINVAL; }
+    FwdCtx& x = m->ctx;
+    EmbedBwdParams p;
+    p.x_ids = x.x_ids; p.ci = x.ci; p.ti = x.ti;
+    p.g_ctx = x.g_C; p.g_tgt = x.g_T; p.g_sos = x.g_S;
+    p.g_tok_emb = m->gP + m->tok_emb; p.g_pos_emb = m->gP + m->pos_emb; p.g_mask_emb = m->gP + m->mask_emb; p.g_sos_emb = m->gP + m->sos_emb;
+    p.B = x.B; p.N = x.N; p.NC = x.gC_defined ? x.NC : 0; p.NT = x.gT_defined ? x.NT : 0; p.NS = x.gS_defined ? m->d.n_latent : 0; p.d = m->d.n_embd;
+    if (p.NC != x.NC && x.NC > 0) {   // contexts unused by any live block: only the target rows scatter; keep index strides right
+        mebt_set_error("backward_embed: contexts without a live latent_enc block are not supported");
+        return MEBT_EINVAL;
+    }
+    return launch_embed_bwd(p, m->d.dtype, S(stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// optimiser
+// ---------------------------------------------------------------------------------------------------
+extern "C" int mebt_adamw_step(mebt_model* m, float* mW, float* vW, float* mP, float* vP, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int32_t step, float grad_scale, mebt_stream_t stream) {
+    if (!m || !m->W || !m->gW || !m->gP) { mebt_set_error("adamw: model / gradients not bound"); return MEBT_EINVAL; }
+    if (step < 1) { mebt_set_error("adamw: step must be >= 1"); return MEBT_EINVAL; }
+    hipStream_t st = S(stream);
+    AdamWParams a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
+    a.bc1 = (float)(1.0 - pow((double)beta1, step)); a.bc2 = (float)(1.0 - pow((double)beta2, step));
+    const int d = m->d.n_embd;
+    auto run = [&](float* p, const float* g, float* mm, float* vv, void* lp, int64_t off, int64_t n, float wd) -> int {
+        a.p = p + off; a.g = g + off; a.m = mm + off; a.v = vv + off; a.n = (size_t)n; a.weight_decay = wd;
+        a.p_bf16 = lp ? (void*)((char*)lp + off * 2) : nullptr;
+        return launch_adamw(a, st);
+    };
+    // contiguous runs of live layers (torch skips parameters whose grad is None)
+    int i = 0;
+    while (i < m->d.n_layer) {
+        if (!m->live[i]) { ++i; continue; }
+        int j = i;
+        while (j + 1 < m->d.n_layer && m->live[j + 1]) ++j;
+        RC(run(m->W, m->gW, mW, vW, m->Wlp, m->lo[i].wq, (int64_t)(j - i + 1) * 12 * d * d, weight_decay));
+        RC(run(m->P, m->gP, mP, vP, nullptr, m->lo[i].ln1w, (int64_t)(j - i + 1) * 13 * d, 0.f));
+        i = j + 1;
+    }
+    RC(run(m->W, m->gW, mW, vW, m->Wlp, m->head_w, (int64_t)m->d.vocab * d, weight_decay));
+    // ln_f, mask_emb, sos_emb, pos_emb (always reached) and tok_emb (only through a live latent_enc)
+    const int64_t tail_n = (m->tok_live ? m->n_p : m->tok_emb) - m->lnf_w;
+    RC(run(m->P, m->gP, mP, vP, nullptr, m->lnf_w, tail_n, 0.f));
+    return MEBT_OK;
+}

@@ -1,0 +1,425 @@
+// MFMA GEMM kernels for gfx950:  C[M,N] = sum_k A(m,k) * B(n,k)  (+ fused epilogue)
+//
+// Replaces the implicit ATen dispatches behind nn.Linear forward/backward on the MeBT hot path
+// (reference mebt/modules/gpt.py:126-128,140,150-155,248 and their autograd backward).
+//
+// Operand layouts.  Each operand is either
+//   KC  "k-contiguous":   stored [rows][K]  (K fastest)  -> LDS image [row][64 k], ds_read_b128
+//   RC  "row-contiguous": stored [K][rows]  (row fastest)-> LDS image [k][128 rows],
+//                                                           ds_read_b64_tr_b16 (hardware transpose)
+// so the three products of a Linear layer need no transposed copies in HBM:
+//   forward  Y  = X  W^T : A = X  (KC)  B = W  (KC)
+//   dgrad    dX = dY W   : A = dY (KC)  B = W  (RC, stored [n_out][k_in] = [K][rows])
+//   wgrad    dW = dY^T X : A = dY (RC)  B = X  (RC)      (reduction over tokens)
+//
+// bf16 kernel: 128x128x64 block tile, 4 waves (2x2) of 64x64, v_mfma_f32_16x16x32_bf16 with the
+// operands swapped (D^T = B A^T) so that each lane owns 4 consecutive output columns (vector
+// epilogue loads/stores).  Global->LDS staging goes through registers with the next tile's loads
+// issued before the current tile's MFMAs (issue-early / write-late), one barrier per k-tile,
+// two LDS stages.  Ragged edges are handled by buffer-resource bounds (OOB loads return 0).
+//
+// f32 kernel (parity mode): same tiling on v_mfma_f32_32x32x2_f32, which is an exact fp32 FMA
+// chain (no TF32-like truncation exists on gfx950).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ int rc_swz(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
+
+// ------------------------------------------------------------------------------------------------
+// epilogue shared by both kernels.  v = 4 consecutive output columns n..n+3 of row m.
+// ------------------------------------------------------------------------------------------------
+template <typename TA /*activation dtype of aux / C2*/>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, f32x4 v, bool add_bias, bool atomic) {
+    if (add_bias && p.bias) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+        v += b;
+    }
+    const size_t ci = (size_t)m * p.ldc + n;
+    if (atomic) {
+        float* c = reinterpret_cast<float*>(p.C) + ci;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(c + j, v[j]);
+        return;
+    }
+    if (p.epilogue == EPI_GELU) {
+        f32x4 g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = gelu_f(v[j]);
+        store4<TA>(reinterpret_cast<TA*>(p.C2) + ci, g);
+    } else if (p.epilogue == EPI_RESID) {
+        v += load4<TA>(reinterpret_cast<const TA*>(p.aux) + (size_t)m * p.ld_aux + n);
+    } else if (p.epilogue == EPI_GELU_BWD) {
+        const f32x4 x = load4<TA>(reinterpret_cast<const TA*>(p.aux) + (size_t)m * p.ld_aux + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_f(x[j]);
+    }
+    if (!p.C) return;                   // EPI_GELU in inference: only gelu(C) is needed
+    if (p.c_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + ci;
+        if (p.beta) v += *reinterpret_cast<const f32x4*>(c);
+        *reinterpret_cast<f32x4*>(c) = v;
+    } else {
+        store4<TA>(reinterpret_cast<TA*>(p.C) + ci, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
+
+template <bool KC>
+struct TileLoader {
+    // per-thread: 4 x 16-byte chunks of a [128 x 64] (KC) or [64 x 128] (RC) bf16 tile
+    uint32_t goff[4];
+    uint32_t loff[4];
+    bool ok[4];
+    uint32_t step;   // byte advance per k-tile
+    __amdgpu_buffer_rsrc_t rsrc;
+
+    __device__ __forceinline__ void init(const void* base, int rows, int K, int ld, int r0, int tid) {
+        const bf16_t* b = reinterpret_cast<const bf16_t*>(base);
+        if (KC) {
+            rsrc = make_rsrc(b + (size_t)r0 * ld, (size_t)(rows - r0) * ld * 2);
+            step = BK * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int id = tid + 256 * i, row = id >> 3, c = id & 7;
+                goff[i] = ((uint32_t)row * ld + 8 * c) * 2;
+                loff[i] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+                ok[i] = true;
+            }
+        } else {
+            rsrc = make_rsrc(b, (size_t)K * ld * 2);
+            step = (uint32_t)BK * ld * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int id = tid + 256 * i, krow = id >> 4, c = id & 15;
+                const int col = r0 + 8 * c;
+                ok[i] = col < rows;
+                goff[i] = ((uint32_t)krow * ld + col) * 2;
+                loff[i] = krow * 256 + ((c ^ rc_swz(krow)) << 4);
+            }
+        }
+    }
+    __device__ __forceinline__ void load(u32x4 (&r)[4], int kt) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = buf_load16(rsrc, ok[i] ? goff[i] + (uint32_t)kt * step : (uint32_t)MEBT_OOB);
+    }
+    __device__ __forceinline__ void store(char* lds, const u32x4 (&r)[4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(lds + loff[i]) = r[i];
+    }
+};
+
+// fragment of 16 rows x 32 k for v_mfma_f32_16x16x32_bf16: lane l holds row (l&15), k = 8*(l>>4)+j
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag(const char* tile, int blk16 /*16-row block in tile*/, int ks, int lane) {
+    if (KC) {
+        const int row = blk16 * 16 + (lane & 15);
+        const int c = 4 * ks + (lane >> 4);
+        return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+    } else {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+        const int ch = 2 * blk16 + (pp >> 1);
+        s16x4 lo, hi;
+        {
+            const int krow = 32 * ks + 8 * g + q;
+            lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + krow * 256 + ((ch ^ rc_swz(krow)) << 4) + 8 * (pp & 1)));
+        }
+        {
+            const int krow = 32 * ks + 8 * g + 4 + q;
+            hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + krow * 256 + ((ch ^ rc_swz(krow)) << 4) + 8 * (pp & 1)));
+        }
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD
+    // a contiguous run of tiles along N (they share the same A rows -> L2 hits).
+    const int ntx = gridDim.x, nty = gridDim.y, ntiles = ntx * nty;
+    int bid = blockIdx.y * ntx + blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / ntx) * BM, n0 = (bid % ntx) * BN;
+
+    const int nkt = (p.K + BK - 1) / BK;
+    const int per = (nkt + gridDim.z - 1) / gridDim.z;
+    const int kt0 = blockIdx.z * per;
+    const int kt1 = min(nkt, kt0 + per);
+    if (kt0 >= kt1) return;
+
+    TileLoader<A_KC> la;
+    TileLoader<B_KC> lb;
+    la.init(p.A, p.M, p.K, p.lda, m0, tid);
+    lb.init(p.B, p.N, p.K, p.ldb, n0, tid);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[4], rb[4];
+    la.load(ra, kt0);
+    lb.load(rb, kt0);
+    la.store(smem, ra);
+    lb.store(smem + BM * BK * 2, rb);
+    __syncthreads();
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int s = (kt - kt0) & 1;
+        const char* sA = smem + s * STAGE_BYTES;
+        const char* sB = sA + BM * BK * 2;
+        const bool more = kt + 1 < kt1;
+        if (more) {
+            la.load(ra, kt + 1);
+            lb.load(rb, kt + 1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = read_frag<A_KC>(sA, wm * 4 + i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = read_frag<B_KC>(sB, wn * 4 + j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            char* dA = smem + (s ^ 1) * STAGE_BYTES;
+            la.store(dA, ra);
+            lb.store(dA + BM * BK * 2, rb);
+        }
+        __syncthreads();
+    }
+
+    const bool atomic = gridDim.z > 1;
+    const bool add_bias = blockIdx.z == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+            if (m < p.M && n < p.N) epilogue_store<bf16_t>(p, m, n, acc[i][j], add_bias, atomic);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 kernel (parity mode).  LDS image is always [k][row] (row fastest); KC operands are
+// transposed by the staging write, RC operands are copied.  BK = 16.
+// ------------------------------------------------------------------------------------------------
+constexpr int FBK = 16, FLD = 132;   // padded row length (floats)
+
+template <bool KC>
+struct TileLoaderF32 {
+    uint32_t goff[2];
+    bool ok[2];
+    int l0[2], l1[2];
+    uint32_t step;
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ void init(const void* base, int rows, int K, int ld, int r0, int tid) {
+        const float* b = reinterpret_cast<const float*>(base);
+        if (KC) {   // tile [128 rows][16 k] : 512 float4 chunks
+            rsrc = make_rsrc(b + (size_t)r0 * ld, (size_t)(rows - r0) * ld * 4);
+            step = FBK * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int id = tid + 256 * i, row = id >> 2, c = id & 3;
+                goff[i] = ((uint32_t)row * ld + 4 * c) * 4;
+                ok[i] = true;
+                l0[i] = 4 * c;   // k
+                l1[i] = row;
+            }
+        } else {    // tile [16 k][128 rows] : 512 float4 chunks
+            rsrc = make_rsrc(b, (size_t)K * ld * 4);
+            step = (uint32_t)FBK * ld * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int id = tid + 256 * i, krow = id >> 5, c = id & 31;
+                const int col = r0 + 4 * c;
+                ok[i] = col < rows;
+                goff[i] = ((uint32_t)krow * ld + col) * 4;
+                l0[i] = krow;
+                l1[i] = 4 * c;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(f32x4 (&r)[2], int kt) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            r[i] = __builtin_bit_cast(f32x4, buf_load16(rsrc, ok[i] ? goff[i] + (uint32_t)kt * step : (uint32_t)MEBT_OOB));
+    }
+    __device__ __forceinline__ void store(float* lds, const f32x4 (&r)[2]) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (KC) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lds[(l0[i] + j) * FLD + l1[i]] = r[i][j];
+            } else {
+                *reinterpret_cast<f32x4*>(lds + l0[i] * FLD + l1[i]) = r[i];
+            }
+        }
+    }
+};
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float sA[FBK * FLD];
+    __shared__ __attribute__((aligned(16))) float sB[FBK * FLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int nkt = (p.K + FBK - 1) / FBK;
+    const int per = (nkt + gridDim.z - 1) / gridDim.z;
+    const int kt0 = blockIdx.z * per;
+    const int kt1 = min(nkt, kt0 + per);
+    if (kt0 >= kt1) return;
+
+    TileLoaderF32<A_KC> la;
+    TileLoaderF32<B_KC> lb;
+    la.init(p.A, p.M, p.K, p.lda, m0, tid);
+    lb.init(p.B, p.N, p.K, p.ldb, n0, tid);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    la.load(ra, kt0);
+    lb.load(rb, kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        la.store(sA, ra);
+        lb.store(sB, rb);
+        __syncthreads();
+        if (kt + 1 < kt1) {
+            la.load(ra, kt + 1);
+            lb.load(rb, kt + 1);
+        }
+#pragma unroll
+        for (int kk = 0; kk < FBK; kk += 2) {
+            const int k = kk + (lane >> 5);
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = sA[k * FLD + wm * 64 + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = sB[k * FLD + wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D'[n_local][m_local]: lane owns m_local = lane&31; register r -> n_local = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool atomic = gridDim.z > 1;
+    const bool add_bias = blockIdx.z == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
+                if (m < p.M && n < p.N) {
+                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    epilogue_store<float>(p, m, n, v, add_bias, atomic);
+                }
+            }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host launcher
+// ------------------------------------------------------------------------------------------------
+static int g_gemm_force_split = 0;
+void mebt_gemm_force_split(int s) { g_gemm_force_split = s; }
+
+int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
+    GemmParams p = p_in;
+    if (p.M <= 0 || p.N <= 0) return MEBT_OK;
+    if (p.N % 4 != 0) { mebt_set_error("gemm: N must be a multiple of 4"); return MEBT_ESHAPE; }
+    const int esz = dtype == MEBT_BF16 ? 2 : 4;
+    const int kq = dtype == MEBT_BF16 ? BK : FBK;
+    if ((p.a_kc || p.b_kc) && (p.K % kq) != 0) { mebt_set_error("gemm: K of a k-contiguous operand must be a multiple of the k-tile"); return MEBT_ESHAPE; }
+    if (!p.a_kc && (size_t)p.K * p.lda * esz >= 0x7FFFFFFFull) { mebt_set_error("gemm: RC operand A exceeds 2 GiB"); return MEBT_ESHAPE; }
+    if (!p.b_kc && (size_t)p.K * p.ldb * esz >= 0x7FFFFFFFull) { mebt_set_error("gemm: RC operand B exceeds 2 GiB"); return MEBT_ESHAPE; }
+    if ((!p.a_kc && (p.M % 8)) || (!p.b_kc && (p.N % 8))) { mebt_set_error("gemm: row extent of an RC operand must be a multiple of 8"); return MEBT_ESHAPE; }
+    if (dtype == MEBT_F32) p.c_f32 = 1;
+    if (p.K <= 0) { mebt_set_error("gemm: K must be positive (empty reductions are handled by the caller)"); return MEBT_ESHAPE; }
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, 1);
+    int split = 1;
+    const bool can_split = p.c_f32 && p.epilogue == EPI_NONE && p.split_k != 1;
+    if (can_split) {
+        const int tiles = grid.x * grid.y;
+        const int nkt = (p.K + kq - 1) / kq;
+        if (p.split_k > 1) split = p.split_k;
+        else if (tiles < 192) split = min(max(1, 384 / tiles), max(1, nkt / 4));
+        if (g_gemm_force_split > 0) split = g_gemm_force_split;
+        split = max(1, min(split, nkt));
+    }
+    grid.z = split;
+    if (split > 1 && !p.beta) {
+        // split-K accumulates with fp32 atomics into a zeroed C
+        MEBT_HIP_CHECK(hipMemset2DAsync(p.C, (size_t)p.ldc * 4, 0, (size_t)p.N * 4, p.M, stream));
+    }
+    if (dtype == MEBT_BF16) {
+        const size_t lds = 2 * STAGE_BYTES;
+#define LAUNCH_BF16(AK, BKC) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC>), grid, dim3(256), lds, stream, p)
+        if (p.a_kc && p.b_kc) LAUNCH_BF16(true, true);
+        else if (p.a_kc && !p.b_kc) LAUNCH_BF16(true, false);
+        else if (!p.a_kc && !p.b_kc) LAUNCH_BF16(false, false);
+        else LAUNCH_BF16(false, true);
+#undef LAUNCH_BF16
+    } else if (dtype == MEBT_F32) {
+#define LAUNCH_F32(AK, BKC) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC>), grid, dim3(256), 0, stream, p)
+        if (p.a_kc && p.b_kc) LAUNCH_F32(true, true);
+        else if (p.a_kc && !p.b_kc) LAUNCH_F32(true, false);
+        else if (!p.a_kc && !p.b_kc) LAUNCH_F32(false, false);
+        else LAUNCH_F32(false, true);
+#undef LAUNCH_F32
+    } else {
+        mebt_set_error("gemm: unsupported dtype");
+        return MEBT_EDTYPE;
+    }
+    MEBT_HIP_CHECK(hipGetLastError());
+    return MEBT_OK;
+}
+
+int gemm_init_attributes() {
+    // the bf16 kernel uses 64 KiB of dynamic LDS
+#define SET_ATTR(AK, BKC) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AK, BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES))
+    SET_ATTR(true, true);
+    SET_ATTR(true, false);
+    SET_ATTR(false, false);
+    SET_ATTR(false, true);
+#undef SET_ATTR
+    return MEBT_OK;
+}

@@ -1,0 +1,140 @@
+// Host-side launch interface of the gfx950 kernels (internal; the public C ABI is include/mebt_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { MEBT_F32 = 0, MEBT_BF16 = 1 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_GELU_BWD = 3 };
+
+// C[M,N] = sum_k A(m,k) B(n,k) (+bias) (+epilogue).  *_kc = 1: operand stored [rows][K];
+// *_kc = 0: stored [K][rows].  ld* are element strides of the slow dimension.
+struct GemmParams {
+    const void* A;
+    const void* B;
+    void* C;
+    void* C2;            // EPI_GELU: gelu(C)
+    const float* bias;   // [N] fp32 or null
+    const void* aux;     // EPI_RESID: residual [M,ld_aux]; EPI_GELU_BWD: pre-activation [M,ld_aux]
+    int M, N, K;
+    int lda, ldb, ldc, ld_aux;
+    int a_kc, b_kc;
+    int epilogue;
+    int c_f32;           // bf16 kernel: write fp32 C (weight gradients, logits)
+    int beta;            // fp32 C only: C += result
+    int split_k;         // 0 = heuristic, 1 = never, >1 = forced (fp32 C, EPI_NONE only)
+};
+int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
+int gemm_init_attributes();
+void mebt_gemm_force_split(int s);
+
+// ---- embedding gather (reference transformer.py:255-277) and its scatter-add backward -----------
+struct EmbedParams {
+    const int64_t* x_ids;   // [B,N]
+    const int64_t* ci;      // [B,NC]
+    const int64_t* ti;      // [B,NT]
+    const float* tok_emb;   // [V,d]
+    const float* pos_emb;   // [block,d]
+    const float* mask_emb;  // [d]
+    const float* sos_emb;   // [NS,d]
+    void* sos;              // [B,NS,d] T
+    void* ctx;              // [B,NC,d] T
+    void* tgt;              // [B,NT,d] T
+    int B, N, NC, NT, NS, d, vocab, block_size;
+};
+int launch_embed_fwd(const EmbedParams& p, int dtype, hipStream_t stream);
+struct EmbedBwdParams {
+    const int64_t* x_ids; const int64_t* ci; const int64_t* ti;
+    const float* g_ctx;     // [B,NC,d] fp32 (accumulated over the latent_enc blocks)
+    const void* g_tgt;      // [B,NT,d] T
+    const void* g_sos;      // [B,NS,d] T
+    float* g_tok_emb; float* g_pos_emb; float* g_mask_emb; float* g_sos_emb;   // fp32, accumulated into
+    int B, N, NC, NT, NS, d;
+};
+int launch_embed_bwd(const EmbedBwdParams& p, int dtype, hipStream_t stream);
+
+// ---- LayerNorm (eps 1e-5, affine) ------------------------------------------------------------------
+// Output row of input row r:  (r / seg) * seg_stride + seg_off + (r % seg)   (seg = 0: identity).
+// This writes LN(sos) and LN(targets) straight into the concatenated key buffer of an `lt2l` block.
+struct LnFwdParams {
+    const void* x; void* y; const float* gamma; const float* beta;
+    float* mean; float* rstd;     // indexed by OUTPUT row; may be null (inference)
+    int rows, d; int seg, seg_stride, seg_off;
+};
+int launch_ln_fwd(const LnFwdParams& p, int dtype, hipStream_t stream);
+struct LnBwdParams {
+    const void* x;                // LN input rows [rows,d] T
+    const void* dy;               // grad wrt LN output, rows mapped like LnFwdParams (seg..)
+    const void* dy2;              // optional second grad (contiguous [rows,d]) added to dy
+    const float* gamma; const float* mean; const float* rstd;   // stats indexed by mapped row
+    void* dx; int dx_f32; int dx_accumulate;                     // dx (+)= ...
+    float* dgamma; float* dbeta;                                 // fp32, atomically accumulated
+    int rows, d; int seg, seg_stride, seg_off;
+};
+int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream);
+
+// out[n] += sum_m X[m,n]   (bias gradients, mask_emb / sos_emb gradients)
+int launch_colsum(const void* X, int M, int N, int ldx, float* out, int dtype, hipStream_t stream);
+
+// ---- masked-token loss (reference transformer.py:717-732, utils.py:80-94) -------------------------
+struct CeParams {
+    const float* logits;      // [rows,V] fp32
+    const int64_t* x_ids;     // [B,N]: target id of row (b,j) = x_ids[b, ti[b,j]]
+    const int64_t* ti;        // [B,NT]
+    int rows, V, B, N, NT;
+    float label_smoothing;
+    float* row_lse;           // [rows]
+    float* row_loss;          // [rows]
+    int* row_rank;            // [rows] number of classes ranked above the target
+    double* out;              // [4]: loss_sum, n_top1, n_top5, rows
+};
+int launch_ce_fwd(const CeParams& p, hipStream_t stream);
+struct CeBwdParams {
+    const float* logits; const int64_t* x_ids; const int64_t* ti; const float* row_lse;
+    void* dlogits;            // [rows,V] T
+    const float* upstream;    // device scalar (dL/dloss) or null (=1)
+    float scale;              // 1 / (B * seq_len * weight)
+    float label_smoothing;
+    int rows, V, B, N, NT;
+};
+int launch_ce_bwd(const CeBwdParams& p, int dtype, hipStream_t stream);
+
+// ---- fused AdamW over a flat buffer (reference transformer.py:790-797) -----------------------------
+struct AdamWParams {
+    float* p; const float* g; float* m; float* v; void* p_bf16;   // p_bf16 may be null
+    size_t n; float lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale;
+};
+int launch_adamw(const AdamWParams& p, hipStream_t stream);
+int launch_cast_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t stream);
+
+// ---- attention ---------------------------------------------------------------------------------------
+// q [B,NQ,h,hd] (row stride ldq), k,v [B,NK,h,hd] (ldk, ldv), o [B,NQ,h,hd] (ldo); lse [B,h,NQ] fp32.
+// softmax(q k^T / sqrt(hd)) v, no mask (attn_bias == 0 at every reference call site).
+struct AttnParams {
+    const void* q; const void* k; const void* v; void* o; float* lse;
+    int B, H, NQ, NK, HD; int ldq, ldk, ldv, ldo;
+    // backward
+    const void* d_o; void* dq; void* dk; void* dv; float* delta; int lddo, lddq, lddk, lddv;
+};
+int launch_attn_fwd(const AttnParams& p, int dtype, hipStream_t stream);
+int launch_attn_bwd(const AttnParams& p, int dtype, hipStream_t stream);
+void mebt_attn_force_generic(int on);
+
+// ---- sampler (reference transformer.py:826-910, :413-439, mask_sampler.py:178-246) -----------------
+struct SampleParams {
+    const float* logits;   // [rows,V]
+    const float* noise;    // [rows,V] Exp(1)
+    float temperature; int top_k; float top_p;   // top_k <= 0 / top_p <= 0: disabled
+    int64_t* ids;          // [rows]
+    float* score;          // [rows] p[ids] after temperature/top-k/top-p
+    float* probs;          // optional [rows,V]
+    int rows, V;
+};
+int launch_sample(const SampleParams& p, hipStream_t stream);
+int launch_scatter_ids(int64_t* x, const int64_t* ti, const int64_t* ids, int B, int N, int NT, hipStream_t stream);
+struct NextMaskParams {
+    const int64_t* ci; const int64_t* ti; const float* score; const float* noise;   // [B,NC],[B,NT],[B,NT],[B,NT]
+    float ctemp; int n_new; int B, NC, NT;
+    int64_t* new_ci;   // [B,NC+n_new]
+    int64_t* new_ti;   // [B,NT-n_new]
+};
+int launch_next_mask(const NextMaskParams& p, hipStream_t stream);

@@ -1,0 +1,204 @@
+"""Host-side owner of the native model: flat parameter / gradient buffers, the workspace and the
+calls into libmebt_hip.so.  PyTorch allocates every byte; the library never does (SURVEY.md §8b
+ownership).  Parameter tensors of the nn.Module tree become *views* into the two flat buffers so
+state_dict / load_state_dict / optimiser param_groups keep working with the reference's names.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, cur_stream
+
+
+def layer_param_names(i):
+    p = f"transformer.blocks.{i}."
+    w = [p + "attn.query.weight", p + "attn.key.weight", p + "attn.value.weight", p + "attn.proj.weight",
+         p + "mlp.0.weight", p + "mlp.2.weight"]
+    s = [p + "ln1.weight", p + "ln1.bias", p + "ln2.weight", p + "ln2.bias", p + "attn.query.bias",
+         p + "attn.key.bias", p + "attn.value.bias", p + "attn.proj.bias", p + "mlp.0.bias", p + "mlp.2.bias"]
+    return w, s
+
+
+def flat_layout(n_layer, has_sos=True):
+    """Order of the state-dict tensors inside the W (nn.Linear weights) and P (everything else)
+    flat buffers — must match mebt_model_create in csrc/engine.cpp."""
+    W, P = [], []
+    for i in range(n_layer):
+        w, s = layer_param_names(i)
+        W += w
+        P += s
+    W.append("transformer.head.weight")
+    P += ["transformer.ln_f.weight", "transformer.ln_f.bias", "mask_emb"]
+    if has_sos:
+        P.append("sos_emb")
+    P += ["pos_emb", "tok_emb.weight"]
+    return W, P
+
+
+class NativeModel:
+    """One mebt_model handle bound to flat buffers on one GPU."""
+
+    def __init__(self, n_layer, n_head, n_embd, vocab, n_latent, block_size, modes, dtype="bf16",
+                 label_smoothing=0.0, embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0):
+        self.lib = _lib.load()
+        d = _lib.ModelDesc()
+        d.n_layer, d.n_head, d.n_embd, d.vocab = n_layer, n_head, n_embd, vocab
+        d.n_latent, d.block_size = n_latent, block_size
+        self.dtype = dtype
+        d.dtype = {"f32": _lib.F32, "fp32": _lib.F32, "bf16": _lib.BF16}[dtype]
+        if len(modes) > _lib.MEBT_MAX_LAYERS:
+            raise ValueError("too many layers")
+        for i, m in enumerate(modes):
+            if m not in _lib.MODE_IDS:
+                raise NotImplementedError(
+                    f"block mode {m!r} is not supported by the HIP engine (supported: {sorted(_lib.MODE_IDS)}); "
+                    "'maskgit' full attention (reference gpt.py:176-178) is unused by the shipped configs")
+            d.modes[i] = _lib.MODE_IDS[m]
+        d.label_smoothing = float(label_smoothing)
+        d.embd_pdrop, d.resid_pdrop, d.attn_pdrop = float(embd_pdrop), float(resid_pdrop), float(attn_pdrop)
+        self.desc = d
+        h = C.c_void_p()
+        check(self.lib.mebt_model_create(C.byref(d), C.byref(h)))
+        self.h = h
+        nw, np_ = C.c_int64(), C.c_int64()
+        check(self.lib.mebt_model_param_counts(self.h, C.byref(nw), C.byref(np_)))
+        self.n_w, self.n_p = nw.value, np_.value
+        self.n_layer, self.n_embd, self.vocab, self.n_latent = n_layer, n_embd, vocab, n_latent
+        self.W = self.P = self.gW = self.gP = self.Wlp = None
+        self.ws = None
+        self.ws_key = None
+        self._w_version = None
+        self.device = None
+        self.adam = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.mebt_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- buffers ---------------------------------------------------------------------------------
+    def allocate(self, device, with_grads=True):
+        self.device = torch.device(device)
+        kw = dict(device=self.device, dtype=torch.float32)
+        self.W = torch.zeros(self.n_w, **kw)
+        self.P = torch.zeros(self.n_p, **kw)
+        self.Wlp = torch.zeros(self.n_w, device=self.device, dtype=torch.bfloat16) if self.dtype == "bf16" else None
+        if with_grads:
+            self.gW = torch.zeros(self.n_w, **kw)
+            self.gP = torch.zeros(self.n_p, **kw)
+        self.bind()
+
+    def ensure_grads(self):
+        if self.gW is None:
+            self.gW = torch.zeros_like(self.W)
+            self.gP = torch.zeros_like(self.P)
+            self.bind()
+
+    def bind(self):
+        check(self.lib.mebt_model_bind(self.h, ptr(self.W), ptr(self.Wlp), ptr(self.gW), ptr(self.P), ptr(self.gP)))
+
+    def sync_lowp(self, force=False):
+        """Refresh the bf16 weight mirror if the fp32 master was modified through torch (in-place
+        ops bump the version counter of the flat buffer; our own AdamW kernel updates both)."""
+        if self.Wlp is None:
+            return
+        v = self.W._version
+        if force or v != self._w_version:
+            check(self.lib.mebt_model_sync_lowp(self.h, cur_stream()))
+            self._w_version = v
+
+    def workspace(self, B, NC, NT, training):
+        need = self.lib.mebt_workspace_bytes(self.h, B, NC, NT, int(training))
+        if need < 0:
+            raise _lib.MebtError("bad workspace query")
+        if self.ws is None or self.ws.numel() < need or self.ws.device != self.device:
+            self.ws = torch.empty(int(need * 1.05) + 4096, dtype=torch.uint8, device=self.device)
+        return self.ws
+
+    # ---- compute -----------------------------------------------------------------------------------
+    def forward(self, x_ids, ci, ti, training=False, logits=None, dropout_seed=0):
+        """x_ids [B,N] i64, ci [B,NC], ti [B,NT] -> logits [B,NT,V] fp32."""
+        assert x_ids.dtype == torch.long and ti.dtype == torch.long
+        x_ids, ti = x_ids.contiguous(), ti.contiguous()
+        ci = ci.contiguous() if ci is not None else None
+        B, N = x_ids.shape
+        NC = 0 if ci is None else ci.shape[1]
+        NT = ti.shape[1]
+        self.sync_lowp()
+        ws = self.workspace(B, NC, NT, training)
+        if logits is None:
+            logits = torch.empty(B, NT, self.vocab, device=self.device, dtype=torch.float32)
+        check(self.lib.mebt_forward(self.h, ptr(ws), ws.numel(), B, N, NC, NT, ptr(x_ids),
+                                    ptr(ci) if NC > 0 else None, ptr(ti), ptr(logits), int(training),
+                                    int(dropout_seed), cur_stream()))
+        self._keep = (x_ids, ci, ti, logits)   # the native context holds raw pointers to these
+        return logits
+
+    def loss_stats(self, logits):
+        """device tensor [4] float64: CE sum, #top-1, #top-5, #rows (of the last training forward)."""
+        out = torch.empty(4, device=self.device, dtype=torch.float64)
+        check(self.lib.mebt_loss(self.h, ptr(self.ws), ptr(logits), ptr(out), cur_stream()))
+        return out
+
+    def backward_head(self, logits, loss_scale, upstream=None):
+        self.ensure_grads()
+        check(self.lib.mebt_backward_head(self.h, ptr(self.ws), ptr(logits), ptr(upstream), float(loss_scale), cur_stream()))
+
+    def backward_layers(self, hi, lo):
+        check(self.lib.mebt_backward_layers(self.h, ptr(self.ws), hi, lo, cur_stream()))
+
+    def backward_embed(self):
+        check(self.lib.mebt_backward_embed(self.h, ptr(self.ws), cur_stream()))
+
+    def backward(self, logits, loss_scale, upstream=None, between=None):
+        """Full backward.  `between(stage, hi, lo)` is called after each finished gradient bucket
+        ('head', 'layers', 'embed') so a data-parallel reducer can launch its all-reduce."""
+        self.backward_head(logits, loss_scale, upstream)
+        if between:
+            between("head", None, None)
+        step = 4
+        hi = self.n_layer - 1
+        while hi >= 0:
+            lo = max(0, hi - step + 1)
+            self.backward_layers(hi, lo)
+            if between:
+                between("layers", hi, lo)
+            hi = lo - 1
+        self.backward_embed()
+        if between:
+            between("embed", None, None)
+
+    def adamw_step(self, lr, weight_decay, step, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0):
+        if self.adam is None:
+            self.adam = [torch.zeros_like(self.W), torch.zeros_like(self.W), torch.zeros_like(self.P), torch.zeros_like(self.P)]
+        mW, vW, mP, vP = self.adam
+        check(self.lib.mebt_adamw_step(self.h, ptr(mW), ptr(vW), ptr(mP), ptr(vP), float(lr), float(betas[0]),
+                                       float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale),
+                                       cur_stream()))
+
+    # ---- layout helpers ------------------------------------------------------------------------------
+    def views(self, shapes, grads=False):
+        """{state-dict name: view into the flat buffers} for the given {name: shape}."""
+        Wn, Pn = flat_layout(self.n_layer, has_sos=self.n_latent > 0)
+        out = {}
+        for names, flat in ((Wn, self.gW if grads else self.W), (Pn, self.gP if grads else self.P)):
+            off = 0
+            for n in names:
+                numel = int(math.prod(shapes[n]))
+                out[n] = flat[off:off + numel].view(*shapes[n])
+                off += numel
+            assert off == flat.numel(), (off, flat.numel())
+        return out
+
+    def layer_w_range(self, hi, lo):
+        """[start, end) element range in W / gW covering layers lo..hi."""
+        per = 12 * self.n_embd * self.n_embd
+        return lo * per, (hi + 1) * per
+
+    def head_w_range(self):
+        return self.n_layer * 12 * self.n_embd * self.n_embd, self.n_w

@@ -1,0 +1,121 @@
+"""Model-level parity of the HIP engine (C ABI: mebt_forward / mebt_loss / mebt_backward_* /
+mebt_adamw_step) against the oracle and the committed golden vectors.  GPU only.
+
+Tolerances: fp32 mode (exact-fp32 MFMA) is the north-star parity gate, logits within 1e-3 of the
+reference CPU path (we measure ~1e-5); bf16 mode (the benchmarked precision) is checked at a
+looser, stated tolerance."""
+import os
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mebt_oracle as orc
+from tests.golden import make_golden as mg
+from tests.helpers import build_native, load_golden, params_for
+
+DEV = "cuda"
+FP32_TOL = 1e-3          # BASELINE.json north_star: "within 1e-3 fp32"
+FP32_TIGHT = 1e-4        # what the fp32-MFMA path actually achieves on these sizes
+BF16_TOL = 6e-2          # bf16 compute vs fp32 oracle, logits std ~0.3 (SURVEY.md §7 hard part 2)
+
+
+@pytest.mark.parametrize("name", ["c1", "micro", "micro_budget"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_forward_logits_and_loss_vs_golden(name, dtype):
+    g = load_golden("forward_" + name)
+    cfg = mg.oracle_cfg(name)
+    nm = build_native(cfg, dtype)
+    x, idx = torch.from_numpy(g["x"]), torch.from_numpy(g["indices"])
+    B = x.shape[0]
+    tol = FP32_TIGHT if dtype == "f32" else BF16_TOL
+    for c, (mode, t) in enumerate(zip(g["case_mode"], g["case_t"])):
+        training = mode == "train"
+        ci, ti, seq_len = orc.divide_indices(idx, float(t), cfg, training)
+        logits = nm.forward(x.reshape(B, -1).to(DEV), ci.to(DEV), ti.to(DEV), training=True)
+        st = nm.loss_stats(logits).cpu()
+        lg = logits.cpu()
+        np.testing.assert_allclose(lg[..., g["cols"]].numpy(), g[f"c{c}_cols"], atol=tol, rtol=0)
+        np.testing.assert_allclose(torch.logsumexp(lg.double(), -1).numpy(), g[f"c{c}_lse"], atol=tol, rtol=0)
+        meta = g[f"c{c}_meta"]
+        ntw = meta[0]
+        loss = float(st[0]) / (B * seq_len * (ntw / seq_len) ** cfg.avg_loss)
+        assert abs(loss - meta[2]) < (2e-5 if dtype == "f32" else 2e-3) * abs(meta[2]), (loss, meta[2])
+        if dtype == "f32":
+            n = int(st[3])
+            assert abs(100.0 * float(st[1]) / n - meta[3]) < 1e-3 and abs(100.0 * float(st[2]) / n - meta[4]) < 1e-3
+            assert (lg.argmax(-1).numpy() == g[f"c{c}_argmax"]).mean() > 0.99
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_edges_nc0_nt1(dtype):
+    e = load_golden("edges_micro")
+    cfg = mg.oracle_cfg("micro")
+    nm = build_native(cfg, dtype)
+    x, idx = torch.from_numpy(e["x"]).reshape(2, -1).to(DEV), torch.from_numpy(e["indices"]).to(DEV)
+    tol = FP32_TIGHT if dtype == "f32" else BF16_TOL
+    l0 = nm.forward(x, idx[:, :0].contiguous(), idx, training=False).cpu()          # NC = 0
+    assert torch.isfinite(l0).all()
+    np.testing.assert_allclose(l0[..., e["cols"]].numpy(), e["nc0_cols"], atol=tol, rtol=0)
+    l1 = nm.forward(x, idx[:, :-1].contiguous(), idx[:, -1:].contiguous(), training=False).cpu()   # NT = 1
+    np.testing.assert_allclose(l1[..., e["cols"]].numpy(), e["nt1_cols"], atol=tol, rtol=0)
+
+
+@pytest.mark.parametrize("name,dtype", [("micro", "f32"), ("c1", "f32"), ("micro", "bf16"), ("c1", "bf16")])
+def test_gradients_vs_oracle_autograd(name, dtype):
+    cfg = mg.oracle_cfg(name)
+    P = {k: v.clone().requires_grad_(True) for k, v in params_for(name).items()}
+    nm = build_native(cfg, dtype)
+    B = 3
+    x, idx = mg.inputs(name, B, "grad")
+    for t in (0.5, 0.2, 0.0):      # t = 0 -> NC = 0
+        for p in P.values():
+            p.grad = None
+        logits, z_t, ntw, seq_len = orc.forward(P, cfg, x, idx, t, training=True)
+        _, _, loss = orc.loss_and_acc(logits, z_t, ntw, seq_len, cfg)
+        loss.backward()
+        ci, ti, _ = orc.divide_indices(idx, t, cfg, True)
+        lg = nm.forward(x.reshape(B, -1).to(DEV), ci.to(DEV), ti.to(DEV), training=True)
+        scale = 1.0 / (B * seq_len * (ntw / seq_len) ** cfg.avg_loss)
+        nm.backward(lg, scale)
+        torch.cuda.synchronize()
+        gv = nm.views(orc.param_shapes(cfg), grads=True)
+        worst = 0.0
+        for k, p in P.items():
+            ref = p.grad if p.grad is not None else torch.zeros_like(p)
+            got = gv[k].cpu()
+            denom = ref.abs().max().item() + 1e-8
+            err = (got - ref).abs().max().item() / denom
+            worst = max(worst, err)
+            lim = 2e-3 if dtype == "f32" else 8e-2
+            assert err < lim, (name, dtype, t, k, err, denom)
+
+
+@pytest.mark.parametrize("name", ["micro", "micro_budget"])
+def test_train_steps_vs_golden(name):
+    """forward + loss + backward + fused AdamW for three steps == the reference's Lightning step
+    (golden: losses, per-parameter norms after each step)."""
+    g = load_golden("train_" + name)
+    cfg = mg.oracle_cfg(name)
+    nm = build_native(cfg, "f32")
+    names = [str(n) for n in g["names"]]
+    for s, t in enumerate(g["ts"]):
+        x, idx = torch.from_numpy(g[f"s{s}_x"]), torch.from_numpy(g[f"s{s}_indices"])
+        B = x.shape[0]
+        ci, ti, seq_len = orc.divide_indices(idx, float(t), cfg, True)
+        ntw = float(seq_len - ci.shape[1])
+        lg = nm.forward(x.reshape(B, -1).to(DEV), ci.to(DEV), ti.to(DEV), training=True)
+        st = nm.loss_stats(lg)
+        scale = 1.0 / (B * seq_len * (ntw / seq_len) ** cfg.avg_loss)
+        nm.backward(lg, scale)
+        loss = float(st[0].cpu()) * scale
+        meta = g[f"s{s}_meta"]
+        assert abs(loss - meta[0]) < 5e-5 * abs(meta[0]), (s, loss, meta[0])
+        gv = nm.views(orc.param_shapes(cfg), grads=True)
+        gn = np.array([float(gv[n].double().norm().cpu()) for n in names])
+        np.testing.assert_allclose(gn, g[f"s{s}_gradnorm"], rtol=2e-3, atol=1e-6)
+        nm.adamw_step(float(g["lr"]), float(g["wd"]), s + 1)
+        pv = nm.views(orc.param_shapes(cfg))
+        pn = np.array([float(pv[n].double().norm().cpu()) for n in names])
+        np.testing.assert_allclose(pn, g[f"s{s}_pnorm"], rtol=2e-5)
