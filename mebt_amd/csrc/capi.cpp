@@ -48,7 +48,7 @@ extern "C" int mebt_op_layernorm_bwd(int32_t dtype, const void* x, const void* d
     if (int rc = check_dtype(dtype)) return rc;
     if (!x || !dy || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) { mebt_set_error("layernorm_bwd: null pointer"); return MEBT_EINVAL; }
     LnBwdParams p;
-    p.x = x; p.dy = dy; p.dy2 = nullptr; p.gamma = gamma; p.mean = mean; p.rstd = rstd; p.dx = dx; p.dx_f32 = dtype == MEBT_F32;
+    p.x = x; p.dy = dy; p.dy2 = nullptr; p.dx_add = nullptr; p.gamma = gamma; p.mean = mean; p.rstd = rstd; p.dx = dx; p.dx_f32 = dtype == MEBT_F32;
     p.dx_accumulate = 0; p.dgamma = dgamma; p.dbeta = dbeta; p.rows = rows; p.d = d; p.seg = 0; p.seg_stride = 0; p.seg_off = 0;
     return launch_ln_bwd(p, dtype, S(stream));
 }

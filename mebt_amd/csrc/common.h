@@ -20,7 +20,7 @@ enum { MEBT_OK = 0, MEBT_EINVAL = 1, MEBT_ESHAPE = 2, MEBT_EHIP = 3, MEBT_EWORKS
 #define MEBT_HIP_CHECK(expr)                                   \
     do {                                                       \
         hipError_t _e = (expr);                                \
-        if (_e != hipSuccess) { mebt_set_hip_error(_e, #expr); return MEBT_EHIP; } \
+        if (_e != hipSuccess) { mebt_set_hip_error(_e, #expr); (void)hipGetLastError(); return MEBT_EHIP; } \
     } while (0)
 void mebt_set_hip_error(hipError_t e, const char* what);
 void mebt_set_error(const char* msg);

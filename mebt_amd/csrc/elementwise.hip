@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = rstd * (gy[c][j] - m1 - xh[c][j] * m2);
+                if (p.dx_add) o += load4<T>(reinterpret_cast<const T*>(p.dx_add) + (size_t)row * p.d + e);
                 if (p.dx_accumulate) o += load4<TDX>(dx + e);
                 store4<TDX>(dx + e, o);
             }

@@ -49,7 +49,8 @@ struct FwdCtx {
     const void *S_final = nullptr, *T_final = nullptr;
     void* hf = nullptr; float *meanf = nullptr, *rstdf = nullptr;
     float* logits_ws = nullptr;
-    float *row_lse = nullptr, *row_loss = nullptr; int* row_rank = nullptr;
+    float *row_lse = nullptr, *row_loss = nullptr; int* row_rank = nullptr; double* loss_out = nullptr;
+    bool loss_done = false;
     // backward scratch
     void *g_S = nullptr, *g_T = nullptr; float* g_C = nullptr;
     void *dlogits = nullptr, *dhf = nullptr, *d4 = nullptr, *dh = nullptr, *dx = nullptr, *datt = nullptr, *dqkv_q = nullptr,
@@ -282,6 +283,7 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
     x.logits_ws = nullptr;
     if (training) {
         x.row_lse = (float*)c.take(R * 4); x.row_loss = (float*)c.take(R * 4); x.row_rank = (int*)c.take(R * 4);
+        x.loss_out = (double*)c.take(32);
         int64_t Mmax = (int64_t)B * (NS + NT);
         if ((int64_t)B * NC > Mmax) Mmax = (int64_t)B * NC;
         x.g_S = c.take(B * NS * d * e);
@@ -430,12 +432,15 @@ extern "C" int mebt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B
         RC(gemm(m, p, st));
     }
     x.valid = training != 0;
+    x.loss_done = false;
     return MEBT_OK;
 }
 
 extern "C" int mebt_loss(mebt_model* m, void* ws, const float* logits, double* out4, mebt_stream_t stream) {
     if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("loss: no training-mode forward on this workspace"); return MEBT_EINVAL; }
     FwdCtx& x = m->ctx;
+    if (!out4) out4 = x.loss_out;
+    x.loss_done = true;
     CeParams p;
     p.logits = logits; p.x_ids = x.x_ids; p.ti = x.ti; p.rows = x.B * x.NT; p.V = m->d.vocab; p.B = x.B; p.N = x.N; p.NT = x.NT;
     p.label_smoothing = m->d.label_smoothing; p.row_lse = x.row_lse; p.row_loss = x.row_loss; p.row_rank = x.row_rank; p.out = out4;
@@ -446,9 +451,10 @@ extern "C" int mebt_loss(mebt_model* m, void* ws, const float* logits, double* o
 // backward
 // ---------------------------------------------------------------------------------------------------
 static int ln_bwd(const mebt_model* m, const void* x, const void* dy, const void* dy2, int64_t gw, int64_t gb, const float* mean,
-                  const float* rstd, void* dx, int dx_f32, int acc, int rows, int seg, int seg_stride, int seg_off, hipStream_t st) {
+                  const float* rstd, void* dx, int dx_f32, int acc, int rows, int seg, int seg_stride, int seg_off, hipStream_t st,
+                  const void* dx_add = nullptr) {
     LnBwdParams p;
-    p.x = x; p.dy = dy; p.dy2 = dy2; p.gamma = m->P + gw; p.mean = mean; p.rstd = rstd; p.dx = dx; p.dx_f32 = dx_f32;
+    p.x = x; p.dy = dy; p.dy2 = dy2; p.dx_add = dx_add; p.gamma = m->P + gw; p.mean = mean; p.rstd = rstd; p.dx = dx; p.dx_f32 = dx_f32;
     p.dx_accumulate = acc; p.dgamma = m->gP + gw; p.dbeta = m->gP + gb; p.rows = rows; p.d = m->d.n_embd;
     p.seg = seg; p.seg_stride = seg_stride; p.seg_off = seg_off;
     return launch_ln_bwd(p, m->d.dtype, st);
@@ -473,6 +479,7 @@ extern "C" int mebt_backward_head(mebt_model* m, void* ws, const float* logits, 
     FwdCtx& x = m->ctx;
     hipStream_t st = S(stream);
     const int d = m->d.n_embd, V = m->d.vocab, dt = m->d.dtype, R = x.B * x.NT;
+    if (!x.loss_done) RC(mebt_loss(m, ws, logits, nullptr, stream));   // the CE backward needs the per-row logsumexp
     // P-side gradients are accumulated with atomics (LN affine, biases, embeddings): zero them first
     MEBT_HIP_CHECK(hipMemsetAsync(m->gP, 0, (size_t)m->n_p * 4, st));
     for (int i = 0; i < m->d.n_layer; ++i)
@@ -505,7 +512,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     RC(wgrad(m, x.d4, 4 * d, a.hn, d, o.w1, 4 * d, d, Mq, st));
     RC(dgrad(m, x.d4, 4 * d, o.w1, x.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st));
     // dx = dout + LN2'(dh)
-    RC(ln_bwd(m, a.x, x.dh, dout, o.ln2w, o.ln2b, a.mean2, a.rstd2, x.dx, 0, 0, Mq, 0, 0, 0, st));
+    RC(ln_bwd(m, a.x, x.dh, nullptr, o.ln2w, o.ln2b, a.mean2, a.rstd2, x.dx, 0, 0, Mq, 0, 0, 0, st, dout));
     // x = qn + att Wp^T + bp
     RC(launch_colsum(x.dx, Mq, d, d, m->gP + o.bp, dt, st));
     RC(wgrad(m, x.dx, d, a.att, d, o.wp, d, d, Mq, st));

@@ -64,7 +64,8 @@ int launch_ln_fwd(const LnFwdParams& p, int dtype, hipStream_t stream);
 struct LnBwdParams {
     const void* x;                // LN input rows [rows,d] T
     const void* dy;               // grad wrt LN output, rows mapped like LnFwdParams (seg..)
-    const void* dy2;              // optional second grad (contiguous [rows,d]) added to dy
+    const void* dy2;              // optional second grad (contiguous [rows,d]) added to dy BEFORE the LN backward
+    const void* dx_add;           // optional [rows,d] T added to the result AFTER it (residual branch)
     const float* gamma; const float* mean; const float* rstd;   // stats indexed by mapped row
     void* dx; int dx_f32; int dx_accumulate;                     // dx (+)= ...
     float* dgamma; float* dbeta;                                 // fp32, atomically accumulated

@@ -34,8 +34,7 @@ template <bool TOP_P>
 __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sv = reinterpret_cast<float*>(smem);                              // [V] values / probabilities
-    float* sp = reinterpret_cast<float*>(smem + (size_t)SV_MAX * 4);         // TOP_P: sorted probabilities
-    unsigned short* si = reinterpret_cast<unsigned short*>(smem + (size_t)SV_MAX * 8);   // TOP_P: sorted ids
+    unsigned short* si = reinterpret_cast<unsigned short*>(smem + (size_t)SV_MAX * 4);   // TOP_P: ids sorted by probability
     __shared__ float sh[4];
     __shared__ unsigned int hist[256];
     __shared__ unsigned int sel_prefix, sel_k;
@@ -89,7 +88,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
         // bitonic sort (descending) of (prob, id) pairs, n padded to a power of two
         int n = 1;
         while (n < V) n <<= 1;
-        for (int e = tid; e < n; e += 256) { sp[e] = e < V ? sv[e] : -1.0f; si[e] = (unsigned short)(e < V ? e : 0); }
+        // (ids only: the probabilities are looked up through the id, which keeps the row in place)
+        auto pr = [&](int i) -> float { const unsigned id = si[i]; return id < (unsigned)V ? sv[id] : -1.0f; };
+        for (int e = tid; e < n; e += 256) si[e] = (unsigned short)(e < V ? e : 0xFFFF);
         __syncthreads();
         for (int k = 2; k <= n; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -97,12 +98,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
                     const int l = i ^ j;
                     if (l > i) {
                         const bool desc = (i & k) == 0;
-                        const float a = sp[i], b = sp[l];
+                        const float a = pr(i), b = pr(l);
                         const bool before = (a > b) || (a == b && si[i] < si[l]);   // ties: lower id first
-                        if (desc ? !before : before) {
-                            sp[i] = b; sp[l] = a;
-                            const unsigned short t = si[i]; si[i] = si[l]; si[l] = t;
-                        }
+                        if (desc ? !before : before) { const unsigned short t = si[i]; si[i] = si[l]; si[l] = t; }
                     }
                 }
                 __syncthreads();
@@ -112,7 +110,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
             int J = V;
             for (int j = 0; j < V; ++j) {
                 if (j > 0 && c >= p.top_p) { J = j; break; }
-                c += sp[j];
+                c += sv[si[j]];
             }
             sJ = J;
         }
@@ -215,7 +213,7 @@ int launch_sample(const SampleParams& p, hipStream_t stream) {
     if (p.rows <= 0) return MEBT_OK;
     if (p.V > SV_MAX || p.V <= 0) { mebt_set_error("sample: vocabulary must be in [1, 16384]"); return MEBT_ESHAPE; }
     const bool tp = p.top_p > 0.f;
-    const size_t lds = tp ? (size_t)SV_MAX * 10 : (size_t)SV_MAX * 4;
+    const size_t lds = tp ? (size_t)SV_MAX * 6 : (size_t)SV_MAX * 4;
     if (tp) {
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(sample_kernel<true>, dim3(p.rows), dim3(256), lds, stream, p);

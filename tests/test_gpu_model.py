@@ -33,7 +33,7 @@ def test_forward_logits_and_loss_vs_golden(name, dtype):
     for c, (mode, t) in enumerate(zip(g["case_mode"], g["case_t"])):
         training = mode == "train"
         ci, ti, seq_len = orc.divide_indices(idx, float(t), cfg, training)
-        logits = nm.forward(x.reshape(B, -1).to(DEV), ci.to(DEV), ti.to(DEV), training=True)
+        logits = nm.forward(x.reshape(B, -1).to(DEV), ci.to(DEV), ti.to(DEV), training=True)   # engine keeps refs
         st = nm.loss_stats(logits).cpu()
         lg = logits.cpu()
         np.testing.assert_allclose(lg[..., g["cols"]].numpy(), g[f"c{c}_cols"], atol=tol, rtol=0)
@@ -81,15 +81,16 @@ def test_gradients_vs_oracle_autograd(name, dtype):
         nm.backward(lg, scale)
         torch.cuda.synchronize()
         gv = nm.views(orc.param_shapes(cfg), grads=True)
-        worst = 0.0
+        lim = 2e-3 if dtype == "f32" else 8e-2
+        bad = []
         for k, p in P.items():
             ref = p.grad if p.grad is not None else torch.zeros_like(p)
             got = gv[k].cpu()
-            denom = ref.abs().max().item() + 1e-8
+            denom = ref.abs().max().item() + 1e-6      # attn.key.bias has an exactly-zero gradient (softmax shift invariance)
             err = (got - ref).abs().max().item() / denom
-            worst = max(worst, err)
-            lim = 2e-3 if dtype == "f32" else 8e-2
-            assert err < lim, (name, dtype, t, k, err, denom)
+            if not err < lim:
+                bad.append((k, round(err, 5), denom))
+        assert not bad, (name, dtype, t, len(bad), bad[:40])
 
 
 @pytest.mark.parametrize("name", ["micro", "micro_budget"])
