@@ -66,11 +66,15 @@ int64_t mebt_workspace_bytes(const mebt_model* m, int32_t B, int32_t NC, int32_t
 
 /* embed + GPT.forward: replaces reference transformer.py:255-283 / :298-322 + gpt.py:234-253.
  * x_ids [B,N] i64 token grid, ci [B,NC] / ti [B,NT] i64 position sets, logits [B,NT,V] fp32 out.
- * training != 0 keeps the activations in `ws` for mebt_backward_*; dropout_seed keys the
- * counter-based dropout masks (ignored when all p_drop are 0 or training == 0). */
+ * training: bit 0 keeps the activations in `ws` for mebt_loss / mebt_backward_*, bit 1 enables
+ * dropout (masks keyed by dropout_seed; ignored when all p_drop are 0). */
 int mebt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
                  const int64_t* x_ids, const int64_t* ci, const int64_t* ti, float* logits,
                  int32_t training, uint64_t dropout_seed, mebt_stream_t stream);
+/* GPT.forward on caller-embedded inputs (reference gpt.py:234-253): sos [B,NS,d], contexts [B,NC,d],
+ * targets [B,NT,d] fp32 -> logits [B,NT,V].  Inference only (no activations kept). */
+int mebt_gpt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t NC, int32_t NT, const float* sos,
+                     const float* contexts, const float* targets, float* logits, mebt_stream_t stream);
 /* Masked-token loss + top-1/top-5 of the last mebt_forward: replaces F.cross_entropy(sum,
  * label_smoothing) and utils.accuracy (transformer.py:726-731, utils.py:80-94).
  * out4 (device, 4 doubles) = { CE sum, #top-1 hits, #top-5 hits, #rows }. */
@@ -79,6 +83,8 @@ int mebt_loss(mebt_model* m, void* ws, const float* logits, double* out4, mebt_s
  * caller can overlap the data-parallel all-reduce of finished gradient buckets with the rest
  * (reference: DDP reducer, train_transformer.py:39-41).  Order: head, layers hi..lo descending, embed. */
 int mebt_backward_head(mebt_model* m, void* ws, const float* logits, const float* upstream, float loss_scale, mebt_stream_t stream);
+/* Same, from an explicit upstream gradient dL/dlogits [B,NT,V] fp32 (caller-computed loss). */
+int mebt_backward_head_dlogits(mebt_model* m, void* ws, const float* dlogits, mebt_stream_t stream);
 int mebt_backward_layers(mebt_model* m, void* ws, int32_t layer_hi, int32_t layer_lo, mebt_stream_t stream);
 int mebt_backward_embed(mebt_model* m, void* ws, mebt_stream_t stream);
 /* Fused AdamW over both flat buffers + refresh of the bf16 mirror: replaces torch.optim.AdamW with

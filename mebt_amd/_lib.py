@@ -35,8 +35,10 @@ PROTOTYPES = {
     "mebt_model_sync_lowp": (c_i32, [c_vp, c_vp]),
     "mebt_workspace_bytes": (c_i64, [c_vp, c_i32, c_i32, c_i32, c_i32]),
     "mebt_forward": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.c_uint64, c_vp]),
+    "mebt_gpt_forward": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mebt_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mebt_backward_head": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
+    "mebt_backward_head_dlogits": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
     "mebt_backward_layers": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "mebt_backward_embed": (c_i32, [c_vp, c_vp, c_vp]),
     "mebt_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp]),

@@ -202,8 +202,8 @@ extern "C" int mebt_model_param_counts(const mebt_model* m, int64_t* n_w, int64_
 extern "C" int mebt_model_bind(mebt_model* m, float* W, void* W_lp, float* gW, float* P, float* gP) {
     if (!m || !W || !P) { mebt_set_error("model_bind: W and P are required"); return MEBT_EINVAL; }
     if (m->d.dtype == MEBT_BF16 && !W_lp) { mebt_set_error("model_bind: bf16 mode needs the bf16 weight mirror"); return MEBT_EINVAL; }
+    if (m->W != W || m->Wlp != W_lp || m->P != P) m->ctx.valid = false;   // attaching gradient buffers keeps a live forward
     m->W = W; m->Wlp = W_lp; m->gW = gW; m->P = P; m->gP = gP;
-    m->ctx.valid = false;
     return MEBT_OK;
 }
 
@@ -332,15 +332,18 @@ static int ln_fwd(const mebt_model* m, const void* x, void* y, int64_t gw, int64
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
-extern "C" int mebt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
-                            const int64_t* x_ids, const int64_t* ci, const int64_t* ti, float* logits,
-                            int32_t training, uint64_t dropout_seed, mebt_stream_t stream) {
+static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
+                        const int64_t* x_ids, const int64_t* ci, const int64_t* ti, const float* const* embedded,
+                        float* logits, int32_t training, uint64_t dropout_seed, mebt_stream_t stream) {
     (void)dropout_seed;
     if (!m || !m->W) { mebt_set_error("forward: model not bound"); return MEBT_EINVAL; }
     if (B <= 0 || N <= 0 || NC < 0 || NT <= 0) { mebt_set_error("forward: need B > 0, N > 0, NC >= 0, NT > 0"); return MEBT_ESHAPE; }
     if (N > m->d.block_size) { mebt_set_error("forward: sequence longer than block_size (pos_emb rows)"); return MEBT_ESHAPE; }
-    if (!ws || !x_ids || !ti || (NC > 0 && !ci) || !logits) { mebt_set_error("forward: null pointer"); return MEBT_EINVAL; }
-    if (training && (m->d.embd_pdrop > 0.f || m->d.resid_pdrop > 0.f || m->d.attn_pdrop > 0.f)) {
+    if (!ws || !logits) { mebt_set_error("forward: null pointer"); return MEBT_EINVAL; }
+    if (!embedded && (!x_ids || !ti || (NC > 0 && !ci))) { mebt_set_error("forward: null pointer"); return MEBT_EINVAL; }
+    const bool want_dropout = (training & 2) != 0;
+    training = training & 1;
+    if (want_dropout && (m->d.embd_pdrop > 0.f || m->d.resid_pdrop > 0.f || m->d.attn_pdrop > 0.f)) {
         mebt_set_error("forward: dropout > 0 in training mode is not built yet (set *_pdrop = 0)");
         return MEBT_EINVAL;
     }
@@ -353,12 +356,23 @@ extern "C" int mebt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B
     const int d = m->d.n_embd, NS = m->d.n_latent, H = m->d.n_head, V = m->d.vocab, dt = m->d.dtype;
     x.ws = ws; x.B = B; x.N = N; x.NC = NC; x.NT = NT; x.x_ids = x_ids; x.ci = ci; x.ti = ti;
 
-    EmbedParams ep;
-    ep.x_ids = x_ids; ep.ci = ci; ep.ti = ti;
-    ep.tok_emb = m->P + m->tok_emb; ep.pos_emb = m->P + m->pos_emb; ep.mask_emb = m->P + m->mask_emb; ep.sos_emb = m->P + m->sos_emb;
-    ep.sos = x.sos0; ep.ctx = x.ctx; ep.tgt = x.tgt0;
-    ep.B = B; ep.N = N; ep.NC = NC; ep.NT = NT; ep.NS = NS; ep.d = d; ep.vocab = V; ep.block_size = m->d.block_size;
-    RC(launch_embed_fwd(ep, dt, st));
+    if (embedded) {   // GPT.forward boundary (gpt.py:234): the caller hands over fp32 embeddings
+        void* dst[3] = {x.sos0, x.ctx, x.tgt0};
+        const size_t cnt[3] = {(size_t)B * NS * d, (size_t)B * NC * d, (size_t)B * NT * d};
+        for (int k = 0; k < 3; ++k) {
+            if (!cnt[k]) continue;
+            if (!embedded[k]) { mebt_set_error("forward: null embedded input"); return MEBT_EINVAL; }
+            if (dt == MEBT_BF16) RC(launch_cast_f32_to_bf16(embedded[k], dst[k], cnt[k], st));
+            else MEBT_HIP_CHECK(hipMemcpyAsync(dst[k], embedded[k], cnt[k] * 4, hipMemcpyDeviceToDevice, st));
+        }
+    } else {
+        EmbedParams ep;
+        ep.x_ids = x_ids; ep.ci = ci; ep.ti = ti;
+        ep.tok_emb = m->P + m->tok_emb; ep.pos_emb = m->P + m->pos_emb; ep.mask_emb = m->P + m->mask_emb; ep.sos_emb = m->P + m->sos_emb;
+        ep.sos = x.sos0; ep.ctx = x.ctx; ep.tgt = x.tgt0;
+        ep.B = B; ep.N = N; ep.NC = NC; ep.NT = NT; ep.NS = NS; ep.d = d; ep.vocab = V; ep.block_size = m->d.block_size;
+        RC(launch_embed_fwd(ep, dt, st));
+    }
 
     const void* Sv = x.sos0;
     const void* Tv = x.tgt0;
@@ -436,6 +450,18 @@ extern "C" int mebt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B
     return MEBT_OK;
 }
 
+extern "C" int mebt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
+                            const int64_t* x_ids, const int64_t* ci, const int64_t* ti, float* logits,
+                            int32_t training, uint64_t dropout_seed, mebt_stream_t stream) {
+    return forward_impl(m, ws, ws_bytes, B, N, NC, NT, x_ids, ci, ti, nullptr, logits, training, dropout_seed, stream);
+}
+
+extern "C" int mebt_gpt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t NC, int32_t NT,
+                                const float* sos, const float* contexts, const float* targets, float* logits, mebt_stream_t stream) {
+    const float* e[3] = {sos, contexts, targets};
+    return forward_impl(m, ws, ws_bytes, B, 1, NC, NT, nullptr, nullptr, nullptr, e, logits, 0, 0, stream);
+}
+
 extern "C" int mebt_loss(mebt_model* m, void* ws, const float* logits, double* out4, mebt_stream_t stream) {
     if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("loss: no training-mode forward on this workspace"); return MEBT_EINVAL; }
     FwdCtx& x = m->ctx;
@@ -473,26 +499,52 @@ static int dgrad(const mebt_model* m, const void* dY, int ld_dy, int64_t w_off, 
     return gemm(m, p, st);
 }
 
-extern "C" int mebt_backward_head(mebt_model* m, void* ws, const float* logits, const float* upstream, float loss_scale, mebt_stream_t stream) {
-    if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("backward: no training-mode forward on this workspace"); return MEBT_EINVAL; }
-    if (!m->gW || !m->gP) { mebt_set_error("backward: gradient buffers not bound"); return MEBT_EINVAL; }
+// shared tail of the head backward: dlogits (already in x.dlogits) -> dW_head, d ln_f, g_T
+static int head_backward_common(mebt_model* m, hipStream_t st) {
     FwdCtx& x = m->ctx;
-    hipStream_t st = S(stream);
-    const int d = m->d.n_embd, V = m->d.vocab, dt = m->d.dtype, R = x.B * x.NT;
-    if (!x.loss_done) RC(mebt_loss(m, ws, logits, nullptr, stream));   // the CE backward needs the per-row logsumexp
-    // P-side gradients are accumulated with atomics (LN affine, biases, embeddings): zero them first
-    MEBT_HIP_CHECK(hipMemsetAsync(m->gP, 0, (size_t)m->n_p * 4, st));
-    for (int i = 0; i < m->d.n_layer; ++i)
-        if (!m->live[i]) MEBT_HIP_CHECK(hipMemsetAsync(m->gW + m->lo[i].wq, 0, (size_t)12 * d * d * 4, st));
-    CeBwdParams cp;
-    cp.logits = logits; cp.x_ids = x.x_ids; cp.ti = x.ti; cp.row_lse = x.row_lse; cp.dlogits = x.dlogits; cp.upstream = upstream;
-    cp.scale = loss_scale; cp.label_smoothing = m->d.label_smoothing; cp.rows = R; cp.V = V; cp.B = x.B; cp.N = x.N; cp.NT = x.NT;
-    RC(launch_ce_bwd(cp, dt, st));
+    const int d = m->d.n_embd, V = m->d.vocab, R = x.B * x.NT;
     RC(wgrad(m, x.dlogits, V, x.hf, d, m->head_w, V, d, R, st));
     RC(dgrad(m, x.dlogits, V, m->head_w, x.dhf, R, V, d, EPI_NONE, nullptr, 0, st));
     RC(ln_bwd(m, x.T_final, x.dhf, nullptr, m->lnf_w, m->lnf_b, x.meanf, x.rstdf, x.g_T, 0, 0, R, 0, 0, 0, st));
     x.gT_defined = true; x.gS_defined = false; x.gC_defined = false;
     return MEBT_OK;
+}
+
+static int backward_prologue(mebt_model* m, void* ws, hipStream_t st) {
+    if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("backward: no training-mode forward on this workspace"); return MEBT_EINVAL; }
+    if (!m->gW || !m->gP) { mebt_set_error("backward: gradient buffers not bound"); return MEBT_EINVAL; }
+    const int d = m->d.n_embd;
+    // P-side gradients are accumulated with atomics (LN affine, biases, embeddings): zero them first
+    MEBT_HIP_CHECK(hipMemsetAsync(m->gP, 0, (size_t)m->n_p * 4, st));
+    for (int i = 0; i < m->d.n_layer; ++i)
+        if (!m->live[i]) MEBT_HIP_CHECK(hipMemsetAsync(m->gW + m->lo[i].wq, 0, (size_t)12 * d * d * 4, st));
+    return MEBT_OK;
+}
+
+extern "C" int mebt_backward_head(mebt_model* m, void* ws, const float* logits, const float* upstream, float loss_scale, mebt_stream_t stream) {
+    hipStream_t st = S(stream);
+    RC(backward_prologue(m, ws, st));
+    FwdCtx& x = m->ctx;
+    const int V = m->d.vocab, dt = m->d.dtype, R = x.B * x.NT;
+    if (!x.loss_done) RC(mebt_loss(m, ws, logits, nullptr, stream));   // the CE backward needs the per-row logsumexp
+    CeBwdParams cp;
+    cp.logits = logits; cp.x_ids = x.x_ids; cp.ti = x.ti; cp.row_lse = x.row_lse; cp.dlogits = x.dlogits; cp.upstream = upstream;
+    cp.scale = loss_scale; cp.label_smoothing = m->d.label_smoothing; cp.rows = R; cp.V = V; cp.B = x.B; cp.N = x.N; cp.NT = x.NT;
+    RC(launch_ce_bwd(cp, dt, st));
+    return head_backward_common(m, st);
+}
+
+// Backward from an arbitrary upstream gradient on the logits (a caller that computes its own loss
+// on the returned logits, as the reference's shared_step does with F.cross_entropy).
+extern "C" int mebt_backward_head_dlogits(mebt_model* m, void* ws, const float* dlogits, mebt_stream_t stream) {
+    hipStream_t st = S(stream);
+    RC(backward_prologue(m, ws, st));
+    FwdCtx& x = m->ctx;
+    if (!dlogits) { mebt_set_error("backward: null dlogits"); return MEBT_EINVAL; }
+    const size_t n = (size_t)x.B * x.NT * m->d.vocab;
+    if (m->d.dtype == MEBT_BF16) RC(launch_cast_f32_to_bf16(dlogits, x.dlogits, n, st));
+    else MEBT_HIP_CHECK(hipMemcpyAsync(x.dlogits, dlogits, n * 4, hipMemcpyDeviceToDevice, st));
+    return head_backward_common(m, st);
 }
 
 static int backward_layer(mebt_model* m, int i, hipStream_t st) {

@@ -121,8 +121,9 @@ class NativeModel:
         return self.ws
 
     # ---- compute -----------------------------------------------------------------------------------
-    def forward(self, x_ids, ci, ti, training=False, logits=None, dropout_seed=0):
-        """x_ids [B,N] i64, ci [B,NC], ti [B,NT] -> logits [B,NT,V] fp32."""
+    def forward(self, x_ids, ci, ti, training=False, logits=None, dropout_seed=0, dropout=True):
+        """x_ids [B,N] i64, ci [B,NC], ti [B,NT] -> logits [B,NT,V] fp32.  training keeps the
+        activations for backward / the fused loss; dropout (only with training) enables the masks."""
         assert x_ids.dtype == torch.long and ti.dtype == torch.long
         x_ids, ti = x_ids.contiguous(), ti.contiguous()
         ci = ci.contiguous() if ci is not None else None
@@ -134,9 +135,21 @@ class NativeModel:
         if logits is None:
             logits = torch.empty(B, NT, self.vocab, device=self.device, dtype=torch.float32)
         check(self.lib.mebt_forward(self.h, ptr(ws), ws.numel(), B, N, NC, NT, ptr(x_ids),
-                                    ptr(ci) if NC > 0 else None, ptr(ti), ptr(logits), int(training),
+                                    ptr(ci) if NC > 0 else None, ptr(ti), ptr(logits),
+                                    (1 | (2 if dropout else 0)) if training else 0,
                                     int(dropout_seed), cur_stream()))
         self._keep = (x_ids, ci, ti, logits)   # the native context holds raw pointers to these
+        return logits
+
+    def gpt_forward(self, sos, contexts, targets):
+        """GPT.forward boundary: fp32 embeddings in, logits out (inference)."""
+        sos, contexts, targets = (t.to(self.device, torch.float32).contiguous() for t in (sos, contexts, targets))
+        B, NC, NT = sos.shape[0], contexts.shape[1], targets.shape[1]
+        self.sync_lowp()
+        ws = self.workspace(B, NC, NT, False)
+        logits = torch.empty(B, NT, self.vocab, device=self.device, dtype=torch.float32)
+        check(self.lib.mebt_gpt_forward(self.h, ptr(ws), ws.numel(), B, NC, NT, ptr(sos), ptr(contexts) if NC > 0 else None,
+                                        ptr(targets), ptr(logits), cur_stream()))
         return logits
 
     def loss_stats(self, logits):
@@ -155,10 +168,16 @@ class NativeModel:
     def backward_embed(self):
         check(self.lib.mebt_backward_embed(self.h, ptr(self.ws), cur_stream()))
 
-    def backward(self, logits, loss_scale, upstream=None, between=None):
+    def backward(self, logits, loss_scale, upstream=None, between=None, dlogits=None):
         """Full backward.  `between(stage, hi, lo)` is called after each finished gradient bucket
-        ('head', 'layers', 'embed') so a data-parallel reducer can launch its all-reduce."""
-        self.backward_head(logits, loss_scale, upstream)
+        ('head', 'layers', 'embed') so a data-parallel reducer can launch its all-reduce.
+        `dlogits` (fp32 [B,NT,V]) replaces the fused cross-entropy backward by an explicit upstream."""
+        if dlogits is not None:
+            self.ensure_grads()
+            dlogits = dlogits.contiguous()
+            check(self.lib.mebt_backward_head_dlogits(self.h, ptr(self.ws), ptr(dlogits), cur_stream()))
+        else:
+            self.backward_head(logits, loss_scale, upstream)
         if between:
             between("head", None, None)
         step = 4

@@ -1,0 +1,635 @@
+"""Net2NetTransformer — host-side mirror of reference mebt/transformer.py:60-824 on top of the HIP
+engine.  Same constructor, attributes (`transformer`, `mask_sampler`, `tok_emb`, `mask_emb`,
+`sos_emb`, `pos_emb`, `first_stage_model`, `config`, `learning_rate` ...), state-dict names and
+method signatures, so `train_transformer.py` / `draft_and_revise_videos.py` style callers work
+unchanged.  Written from scratch: every tensor op of the reference is replaced by calls into
+libmebt_hip.so (mebt_amd/_lib.py); PyTorch only owns memory and streams.
+
+Precision: `compute_dtype` = "bf16" (MFMA bf16, fp32 accumulate — what bench.py measures) or
+"f32" (exact-fp32 MFMA — the 1e-3 parity mode).  Set it before the first forward, or through the
+MEBT_COMPUTE_DTYPE environment variable.
+"""
+import copy
+import math
+import os
+import random
+import weakref
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import instantiate_from_config
+from .engine import NativeModel
+from .lightning_shim import LightningModuleShim
+from .modules.gpt import GPT
+from .modules.encoders import SOSProvider
+
+
+# ---- video-length priors (reference transformer.py:25-49; resolved there with eval(name)) ----------
+def uniform(vid_lengths, t):
+    return np.ones_like(vid_lengths, dtype=float)
+
+
+def _gauss(vid_lengths, t, b, c):
+    return np.exp((-(t - (vid_lengths - 1) * b) ** 2) / (2 * (b * c) ** 2))
+
+
+def gaussian(vid_lengths, t, b, c):
+    return _gauss(vid_lengths, t, b, c)
+
+
+def gaussian100000_2(vid_lengths, t):
+    return _gauss(vid_lengths, t, 100000, 2)
+
+
+def gaussian2(vid_lengths, t):
+    return _gauss(vid_lengths, t, 30000, 2)
+
+
+def longest(vid_lengths, t):
+    x = np.zeros_like(vid_lengths, dtype=float)
+    x[-1] = 1.
+    return x
+
+
+T_PRIORS = {"uniform": uniform, "gaussian100000_2": gaussian100000_2, "gaussian2": gaussian2, "longest": longest}
+
+
+# ---- context-temperature schedules (reference transformer.py:51-58) -----------------------------------
+def linear(t):
+    return 1. - t
+
+
+def constant(t):
+    return 1.
+
+
+def cosine(t):
+    return np.cos(t * np.pi / 2.)
+
+
+CTEMP_SCHEDULES = {"linear": linear, "constant": constant, "cosine": cosine}
+
+
+def disabled_train(self, mode=True):
+    return self
+
+
+def _cfg_has(cfg, key):
+    return hasattr(cfg, key) if not isinstance(cfg, dict) else key in cfg
+
+
+# ---- autograd bridges ----------------------------------------------------------------------------------
+class _LogitsFn(torch.autograd.Function):
+    """logits = engine.forward(...); backward feeds dL/dlogits to the HIP backward, which writes the
+    parameter gradients straight into the flat gradient buffers (`param.grad` are views of them)."""
+
+    @staticmethod
+    def forward(ctx, trigger, model, x_ids, ci, ti):
+        ctx.model = model
+        return model._native.forward(x_ids, ci, ti, training=True, dropout_seed=model._next_seed())
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        m = ctx.model
+        m._native.backward(None, 0.0, between=m._bucket_hook, dlogits=dlogits)
+        m._attach_grads()
+        return torch.zeros((), device=dlogits.device), None, None, None, None
+
+
+class _LossFn(torch.autograd.Function):
+    """Fused masked-token loss (+top-1/top-5) on the logits of the last training forward; the
+    backward runs the fused CE-backward kernel and the whole network backward."""
+
+    @staticmethod
+    def forward(ctx, trigger, model, logits, scale):
+        ctx.model, ctx.logits, ctx.scale = model, logits, scale
+        stats = model._native.loss_stats(logits)
+        ctx.mark_non_differentiable(stats)
+        return (stats[0] * scale).to(torch.float32), stats
+
+    @staticmethod
+    def backward(ctx, gloss, _gstats):
+        m = ctx.model
+        up = gloss.to(torch.float32).contiguous()
+        m._native.backward(ctx.logits, ctx.scale, upstream=up, between=m._bucket_hook)
+        m._attach_grads()
+        return torch.zeros((), device=gloss.device), None, None, None
+
+
+class MebtAdamW(torch.optim.Optimizer):
+    """torch.optim.Optimizer façade over the fused AdamW kernel: keeps the 4 param_groups of
+    reference transformer.py:790-797 (so `optimizer_step`'s per-group LR writes work) but updates
+    the two flat buffers with one kernel family (mebt_adamw_step)."""
+
+    def __init__(self, model, groups, lr, betas=(0.9, 0.95), eps=1e-8):
+        super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0))
+        self._model = weakref.ref(model)
+        self._steps = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        m = self._model()
+        m._ensure_native()
+        lrs = {g["lr"] for g in self.param_groups}
+        if len(lrs) != 1:
+            raise NotImplementedError("per-group learning rates differ; the reference sets one LR for all groups")
+        self._steps += 1
+        g0 = self.param_groups[0]
+        red = m._reducer
+        m._native.adamw_step(g0["lr"], g0["weight_decay"], self._steps, betas=g0["betas"], eps=g0["eps"],
+                             grad_scale=(red.grad_scale if red is not None else 1.0))
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        pass        # every backward overwrites the gradient buffers
+
+
+class Net2NetTransformer(LightningModuleShim):
+    def __init__(self, transformer_config, first_stage_config, mask_config, ckpt_path=None, ignore_keys=[],
+                 first_stage_key="video", cond_stage_key="label", pkeep=1.0, sos_token=0):
+        super().__init__()
+        cfg = self.config = transformer_config
+        self.class_cond_dim = cfg.class_cond_dim if _cfg_has(cfg, "class_cond_dim") else None
+        self.be_unconditional = cfg.unconditional
+        self.sos_token = sos_token
+        self.first_stage_key = first_stage_key
+        self.first_stage_vocab_size = cfg.vocab_size
+        self.cond_stage_key = cond_stage_key
+        self.vtokens = cfg.vtokens
+        self.n_embd = cfg.n_embd
+        self.vis_epoch = cfg.vis_epoch if _cfg_has(cfg, "vis_epoch") else 100
+        # optional keys get in-place defaults, like reference :83-100
+        cfg.avg_loss = float(cfg.avg_loss) if _cfg_has(cfg, "avg_loss") else 0.0
+        for k in ("embd_pdrop", "resid_pdrop", "attn_pdrop"):
+            if not _cfg_has(cfg, k):
+                setattr(cfg, k, 0.0)
+        self.sample_every_n_latent_frames = cfg.sample_every_n_latent_frames if _cfg_has(cfg, "sample_every_n_latent_frames") else 0
+        self.label_smoothing = cfg.label_smoothing if _cfg_has(cfg, "label_smoothing") else 0.0
+
+        self.init_first_stage_from_ckpt(first_stage_config)
+        self.init_cond_stage_from_ckpt(cfg)
+        gpt_vocab = self.first_stage_vocab_size + self.cond_stage_vocab_size
+        self.transformer = GPT(gpt_vocab, cfg.block_size, n_layer=cfg.n_layer, n_head=cfg.n_head, n_embd=cfg.n_embd,
+                               vtokens_pos=cfg.vtokens_pos if _cfg_has(cfg, "vtokens_pos") else False,
+                               n_unmasked=cfg.n_unmasked if _cfg_has(cfg, "n_unmasked") else 0,
+                               attn_pdrop=cfg.attn_pdrop, embd_pdrop=cfg.embd_pdrop, resid_pdrop=cfg.resid_pdrop,
+                               mode=cfg.mode)
+        self.transformer._owner = weakref.ref(self)
+        self.mask_sampler = instantiate_from_config(config=mask_config)
+
+        if not _cfg_has(cfg, "beta_params"):                                      # reference :113-119
+            mp = mask_config.params if _cfg_has(mask_config, "params") else {}
+            self.range = mp.t_range if _cfg_has(mp, "t_range") else [0., 1.]
+            self.beta = False
+        else:
+            self.beta_params = cfg.beta_params
+            self.beta_iter = float(cfg.beta_iter)
+            self.beta = True
+        self.t_lengths = np.array(list(range(self.mask_sampler.shape[0]))) + 1
+        if not _cfg_has(cfg, "t_prior"):
+            cfg.t_prior = "longest"
+        if cfg.t_prior not in T_PRIORS:
+            raise ValueError(f"unknown t_prior {cfg.t_prior!r} (known: {sorted(T_PRIORS)})")
+        self.t_prior = T_PRIORS[cfg.t_prior]                                       # reference :125 uses eval()
+
+        self.tok_emb = nn.Embedding(gpt_vocab, cfg.n_embd)
+        self.tok_emb.weight.data.normal_(mean=0.0, std=0.02)
+        self.mask_emb = nn.Parameter(torch.zeros(1, 1, cfg.n_embd))
+        self.mask_emb.data.normal_(mean=0.0, std=0.02)
+        if not _cfg_has(cfg, "sos_emb"):
+            cfg.sos_emb = 1
+        if cfg.sos_emb > 0:
+            self.sos_emb = nn.Parameter(torch.zeros(1, cfg.sos_emb, cfg.n_embd))
+            self.sos_emb.data.normal_(mean=0.0, std=0.02)
+        self.num_pos = np.prod(self.mask_sampler.shape[1:])
+        self.pos_emb = nn.Parameter(torch.zeros(1, cfg.block_size, cfg.n_embd))
+        self.pos_emb.data.normal_(mean=0.0, std=0.02)
+        self.n_head = cfg.n_head
+        self.first_mode = cfg.mode[0]
+        # training hyper-parameters the launcher sets post-hoc (train_transformer.py:54-66)
+        self.learning_rate, self.warmup_steps, self.weight_decay, self.cosine_lr = 4.5e-6, 0, 0.01, False
+        # engine state
+        self.compute_dtype = os.environ.get("MEBT_COMPUTE_DTYPE", "bf16")
+        self._native = None
+        self._reducer = None            # mebt_amd.parallel.GradReducer when data-parallel
+        self._seed_ctr = 0
+        self.noise_hook = None          # tests inject Exp(1) noise: fn(kind, shape) -> tensor
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
+        self.pkeep = pkeep
+        self.save_hyperparameters(transformer_config=transformer_config, first_stage_config=first_stage_config,
+                                  mask_config=mask_config, first_stage_key=first_stage_key,
+                                  cond_stage_key=cond_stage_key, pkeep=pkeep, sos_token=sos_token)
+
+    # ---- construction helpers -----------------------------------------------------------------------
+    def init_from_ckpt(self, path, ignore_keys=list()):
+        """reference :170-178: load `state_dict`, dropping keys by prefix, strict=False"""
+        sd = torch.load(path, map_location="cpu", weights_only=False)["state_dict"]
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                print("Deleting key {} from state_dict.".format(k))
+                del sd[k]
+        self.load_state_dict(sd, strict=False)
+        print(f"Restored from {path}")
+
+    def init_first_stage_from_ckpt(self, config):
+        """reference :180-192.  The 3D-VQGAN first stage is outside this hot path:
+        with `vtokens: True` the batch carries token grids and no first stage exists; with `vtokens:
+        False` the model is still constructible (so the shipped YAMLs load unchanged) but only accepts
+        int64 token grids — pixel videos raise in encode_to_z."""
+        self.first_stage_model = None
+        if self.vtokens:
+            self.first_stage_vocab_size = 16384                                    # reference :192
+        else:
+            self.first_stage_vocab_size = self.config.first_stage_vocab_size if _cfg_has(self.config, "first_stage_vocab_size") else self.config.vocab_size
+
+    def init_cond_stage_from_ckpt(self, args):
+        """reference :204-214 (unconditional only)"""
+        if self.be_unconditional:
+            self.cond_stage_key = self.first_stage_key
+            self.cond_stage_model = SOSProvider(self.sos_token)
+            self.cond_stage_vocab_size = 0
+        else:
+            raise ValueError('conditional model %s is not implementated' % self.cond_stage_key)
+
+    # ---- engine plumbing ------------------------------------------------------------------------------
+    def _param_dict(self):
+        return dict(self.named_parameters())
+
+    def _ensure_native(self):
+        dev = self.tok_emb.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("mebt_amd runs on MI355X only: move the model to the GPU (`model.cuda()`); "
+                               "there is no CPU path in the product")
+        nm = self._native
+        if nm is not None and nm.device == dev and self.tok_emb.weight.data_ptr() == self._tok_ptr:
+            return nm
+        cfg = self.config
+        modes = [b.mode for b in self.transformer.blocks]
+        nm = NativeModel(cfg.n_layer, cfg.n_head, cfg.n_embd, self.transformer.head.weight.shape[0], cfg.sos_emb,
+                         cfg.block_size, modes, dtype=self.compute_dtype, label_smoothing=self.label_smoothing,
+                         embd_pdrop=cfg.embd_pdrop, resid_pdrop=cfg.resid_pdrop, attn_pdrop=cfg.attn_pdrop)
+        nm.allocate(dev, with_grads=False)
+        params = self._param_dict()
+        views = nm.views({k: tuple(v.shape) for k, v in params.items()})
+        with torch.no_grad():
+            for k, p in params.items():
+                views[k].copy_(p.data)
+                p.data = views[k]           # the Parameter object survives; its storage is now the flat buffer
+        nm.sync_lowp(force=True)
+        self._native, self._tok_ptr = nm, self.tok_emb.weight.data_ptr()
+        return nm
+
+    def _attach_grads(self):
+        nm = self._native
+        if getattr(self, "_grads_attached", None) is nm.gW:
+            return
+        gv = nm.views({k: tuple(v.shape) for k, v in self._param_dict().items()}, grads=True)
+        for k, p in self._param_dict().items():
+            p.grad = gv[k]
+        self._grads_attached = nm.gW
+
+    def _next_seed(self):
+        self._seed_ctr += 1
+        return (self.global_step << 20) ^ self._seed_ctr
+
+    def _bucket_hook(self, stage, hi, lo):
+        if self._reducer is not None:
+            self._reducer.bucket_ready(self._native, stage, hi, lo)
+
+    def _trigger(self, dev):
+        return torch.zeros((), device=dev, requires_grad=True)
+
+    def _gpt_forward_embedded(self, sos_emb, contexts, targets):
+        return self._ensure_native().gpt_forward(sos_emb, contexts, targets)
+
+    # ---- forward ----------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_to_z(self, x):
+        """reference :683-694; only the token-grid branch exists here"""
+        if x.dtype != torch.long:
+            raise NotImplementedError("pixel-space input needs the 3D-VQGAN first stage, which is outside this "
+                                      "hot path; pass int64 token grids [B,T,H,W] (config vtokens: True)")
+        return x, x.reshape(x.shape[0], -1)
+
+    def _draw_t(self, debug):
+        """reference :225-241: ONE scalar t per step from the python RNG (or the beta schedule)"""
+        if self.beta and (self.training or debug):
+            if self.global_step > self.beta_iter:
+                alpha, beta = 1., 1.
+            else:
+                a_, b_ = self.beta_params
+                alpha = a_ - (a_ - 1.) * (self.global_step / self.beta_iter)
+                beta = b_ - (b_ - 1.) * (self.global_step / self.beta_iter)
+            return float(torch.distributions.beta.Beta(alpha, beta).sample())
+        t = random.random()
+        if self.training or debug:
+            t = self.range[0] + t * (self.range[1] - self.range[0])
+        return t
+
+    def forward(self, x, c, t=None, indices=None, vid_t=None, debug=False):
+        """one step to produce the logits (reference :216-286) -> (logits, z_targets, NT_weight, seq_len)"""
+        assert indices is not None
+        _, x_ids = self.encode_to_z(x)
+        nm = self._ensure_native()
+        if t is None:
+            t = self._draw_t(debug)
+        if vid_t is None:
+            prior_t = self.t_prior(self.t_lengths, self.global_step)
+            vid_t = self.t_lengths
+        else:
+            assert len(vid_t) == 1
+            prior_t = np.ones_like(vid_t, dtype=float)
+        ci, ti, seq_len = self.mask_sampler.divide_indices(indices, torch.tensor(float(t)), vid_t, prior_t, debug)
+        ci, ti = ci.contiguous(), ti.contiguous()
+        z_targets = torch.gather(x_ids, 1, ti)
+        NT_weight = float(seq_len - ci.shape[1])
+        if torch.is_grad_enabled() and self.training:
+            logits = _LogitsFn.apply(self._trigger(x_ids.device), self, x_ids, ci, ti)
+        else:   # no autograd: optionally keep the activations so the fused loss kernel can run
+            logits = nm.forward(x_ids, ci, ti, training=getattr(self, "_keep_for_loss", False), dropout=False)
+        return logits, z_targets, NT_weight, seq_len
+
+    def reconstruct_mask(self, x_indices, context_indices, target_indices, debug=False):
+        """inference forward on caller-supplied index sets (reference :288-324) -> (logits, None)"""
+        B = x_indices.shape[0]
+        x_ids = x_indices.reshape(B, -1)
+        nm = self._ensure_native()
+        return nm.forward(x_ids, context_indices, target_indices, training=False), None
+
+    def top_k_logits(self, logits, k):
+        return top_k_logits(logits, k)
+
+    # ---- loss / training hooks -------------------------------------------------------------------------
+    def get_input(self, key, batch):
+        return batch[key]
+
+    def get_xc(self, batch, N=None):
+        x = self.get_input(self.first_stage_key, batch)
+        c = self.get_input(self.cond_stage_key, batch)
+        if N is not None:
+            x, c = x[:N], c[:N]
+        return x, c
+
+    def shared_step(self, batch, batch_idx):
+        """reference :717-732 with the loss + top-1/top-5 fused into one pass over the logits
+        (mebt_loss) and its backward fused with the CE gradient (mebt_backward_head)."""
+        x, c = self.get_xc(batch)
+        indices = self.get_input('indices', batch)
+        self._keep_for_loss = True
+        try:
+            logits, target, NT_weight, seq_len = self(x, c, indices=indices)
+        finally:
+            self._keep_for_loss = False
+        ratio = NT_weight / float(seq_len)
+        B = logits.shape[0]
+        scale = 1.0 / (B * seq_len * ratio ** self.config.avg_loss)
+        if logits.requires_grad:
+            loss, stats = _LossFn.apply(self._trigger(logits.device), self, logits.detach(), scale)
+        else:
+            stats = self._native.loss_stats(logits)
+            loss = (stats[0] * scale).to(torch.float32)
+        n = stats[3]
+        acc1 = (stats[1] * (100.0 / n)).to(torch.float32)
+        acc5 = (stats[2] * (100.0 / n)).to(torch.float32)
+        return acc1, acc5, loss, ratio
+
+    def training_step(self, batch, batch_idx):
+        acc1, acc5, loss, ratio = self.shared_step(batch, batch_idx)
+        self.log("train/loss", loss, prog_bar=True, logger=True, on_step=True, on_epoch=True, sync_dist=True)
+        self.log('train/acc1', acc1, prog_bar=True, logger=True, on_step=True, on_epoch=True, sync_dist=True)
+        self.log('train/acc5', acc5, prog_bar=True, logger=True, on_step=True, on_epoch=True, sync_dist=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        with torch.no_grad():
+            acc1, acc5, loss, ratio = self.shared_step(batch, batch_idx)
+        self.log("val/loss", loss, prog_bar=True, logger=True, on_step=True, on_epoch=True, sync_dist=True)
+        self.log('val/acc1', acc1, prog_bar=True, logger=True, on_step=True, on_epoch=True, sync_dist=True)
+        self.log('val/acc5', acc5, prog_bar=True, logger=True, on_step=True, on_epoch=True, sync_dist=True)
+        return loss
+
+    def configure_optimizers(self):
+        """The 4 AdamW groups of reference :749-798: Linear weights of `transformer` (decayed),
+        tok/mask/sos embeddings, biases + LayerNorm, pos_emb (all undecayed); betas (0.9, 0.95)."""
+        decay, no_decay = set(), set()
+        for mn, m in self.transformer.named_modules():
+            for pn, _ in m.named_parameters(recurse=False):
+                fpn = f"{mn}.{pn}" if mn else pn
+                if pn.endswith("bias") or isinstance(m, (nn.LayerNorm, nn.Embedding)):
+                    no_decay.add(fpn)
+                elif isinstance(m, nn.Linear):
+                    decay.add(fpn)
+        pd = dict(self.transformer.named_parameters())
+        assert not (decay & no_decay) and not (pd.keys() - (decay | no_decay))
+        emb = [p for n, p in self.named_parameters() if "_emb" in n and n != "pos_emb"]
+        pos = [p for n, p in self.named_parameters() if "pos_emb" in n]
+        groups = [
+            {"params": [pd[n] for n in sorted(decay)], "weight_decay": self.weight_decay},
+            {"params": emb, "weight_decay": 0.0},
+            {"params": [pd[n] for n in sorted(no_decay)], "weight_decay": 0.0},
+            {"params": pos, "weight_decay": 0.0},
+        ]
+        return MebtAdamW(self, groups, lr=self.learning_rate, betas=(0.9, 0.95))
+
+    def lr_scale(self):
+        """manual warm-up / cosine of reference :665-678"""
+        step = self.trainer.global_step
+        if step < self.warmup_steps:
+            return min(1., float(step + 1) / self.warmup_steps)
+        if self.cosine_lr:
+            rad = float(step - self.warmup_steps) / float(self.trainer.max_steps - self.warmup_steps)
+            assert rad >= 0
+            return 0.5 * (1 + np.cos(rad * np.pi))
+        return 1.
+
+    def optimizer_step(self, epoch_nb=0, batch_nb=0, optimizer=None, optimizer_i=0, opt_closure=None, on_tpu=False,
+                       using_native_amp=False, using_lbfgs=False):
+        scale = self.lr_scale()
+        if self.trainer.global_step < self.warmup_steps or self.cosine_lr:
+            for pg in optimizer.param_groups:
+                pg['lr'] = self.learning_rate * scale
+        self.log("learning_rate", self.learning_rate * scale, logger=True, on_step=True, sync_dist=True)
+        optimizer.step(closure=opt_closure)
+
+    # ---- sampling -----------------------------------------------------------------------------------------
+    def _noise(self, kind, shape, device):
+        if self.noise_hook is not None:
+            return self.noise_hook(kind, tuple(shape)).to(device, torch.float32)
+        return torch.empty(shape, device=device, dtype=torch.float32).exponential_()
+
+    def _sample_tokens(self, logits, temperature, top_k, top_p, want_probs=False):
+        """sample_from_logits (:843-889) + score gather (:409) in one kernel -> (ids, scores, probs?)"""
+        B, NT, V = logits.shape
+        noise = self._noise("exp", (B, NT, V), logits.device)
+        return sample_from_logits_scored(logits, temperature, top_k, top_p, noise, want_probs)
+
+    @staticmethod
+    def _scatter(partial, target_indices, ids):
+        """x[b, ti[b,j]] = ids[b,j]  — replaces the two sparse_coo -> dense -> where of :413-439"""
+        B, N = partial.shape
+        out = partial.clone()
+        ti = target_indices.contiguous()
+        ids = ids.contiguous()
+        _lib.check(_lib.load().mebt_op_scatter_ids(_lib.ptr(out), _lib.ptr(ti), _lib.ptr(ids), B, N, ti.shape[1],
+                                                   _lib.cur_stream()))
+        return out
+
+    @torch.no_grad()
+    def sample(self, x, c, temperature=1.0, top_k=None, top_p=None, n_steps=8, context_indices=None,
+               target_indices=None, strategy='maskgit', context_temperature=4.5, phase_history=None, refine_steps=1,
+               forget_pivot=False, skips=[False, False, False], debug=False, ctemp_schedule='linear', edit=False):
+        """MaskGIT-style iterative decoding (reference :353-447)."""
+        B = x.shape[0]
+        N = int(np.prod(x.shape[1:]))
+        edit_N = target_indices.shape[1] if edit else N
+        x = x.reshape(B, N)
+        assert not self.transformer.training
+        if strategy not in ('maskgit', 'random', 'mlm', 'bootstrap'):
+            return None
+        if ctemp_schedule not in CTEMP_SCHEDULES:
+            raise ValueError(ctemp_schedule)
+        self.mask_sampler.noise_hook = self.noise_hook
+        dev = x.device
+        if context_indices is None:
+            context_indices = torch.empty(B, 0, dtype=torch.long, device=dev)
+            target_indices = torch.arange(N, device=dev).repeat(B, 1)
+        else:
+            context_indices, target_indices = context_indices.clone(), target_indices.clone()
+        partial = x
+        history, context_history = [], []
+        if debug:
+            history.append(partial.clone())
+            V = self.transformer.head.weight.shape[0]
+            partial_probs = -torch.ones(B, N, V, device=dev)
+        for t_next in np.linspace(0, 1, n_steps + 1)[1:]:
+            tt = torch.full((B,), fill_value=t_next)                        # float32, like reference :398
+            n_masked = torch.ceil(self.mask_sampler.schedule_fn(tt) * edit_N)
+            if int((n_masked > target_indices.shape[-1]).sum()) == B:       # :401-402
+                continue
+            logits, _ = self.reconstruct_mask(partial, context_indices, target_indices, debug)
+            ids, scores, probs = self._sample_tokens(logits, temperature, top_k, top_p, want_probs=debug)
+            target_indices = target_indices.view(B, -1)
+            if debug:
+                partial_probs.scatter_(1, target_indices.unsqueeze(-1).expand(-1, -1, probs.shape[-1]), probs)
+            partial = self._scatter(partial, target_indices, ids)
+            ctemp = context_temperature * CTEMP_SCHEDULES[ctemp_schedule](t_next)   # :440
+            if debug:
+                history.append(partial.clone())
+                context_history.append(context_indices)
+            context_indices, target_indices = self.mask_sampler.generate_next_mask(
+                context_indices, target_indices, scores, t_next, strategy=strategy, context_temperature=ctemp,
+                n_masked_toks=n_masked)
+        if debug:
+            return partial.view(B, -1), context_indices, target_indices, history, context_history, partial_probs
+        return partial.view(B, -1), context_indices, target_indices
+
+    def _gibbs_pass(self, x, masks, temperature, top_k, top_p, debug):
+        partial = x
+        for ctx, tgt in zip(*masks):
+            logits, _ = self.reconstruct_mask(partial, ctx.contiguous(), tgt.contiguous(), debug)
+            ids, _, _ = self._sample_tokens(logits, temperature, top_k, top_p)
+            partial = self._scatter(partial, tgt.reshape(x.shape[0], -1), ids)
+        return partial
+
+    def _full_sets(self, B, N, device, context_indices, target_indices):
+        if context_indices is None:
+            context_indices = torch.empty(B, 0, dtype=torch.long, device=device)
+            target_indices = torch.arange(N, device=device).repeat(B, 1)
+        return context_indices, target_indices
+
+    @torch.no_grad()
+    def draft(self, x, c, temperature=1.0, top_k=None, top_p=None, n_steps=8, debug=False, context_indices=None,
+              target_indices=None):
+        """reference :544-586"""
+        B, N = x.shape[0], int(np.prod(x.shape[1:]))
+        x = x.reshape(B, N)
+        self.mask_sampler.noise_hook = self.noise_hook
+        ci, ti = self._full_sets(B, N, x.device, context_indices, target_indices)
+        masks = self.mask_sampler.create_gibbs_draft_mask(ci, ti, n_steps, x.device)
+        assert not self.transformer.training
+        return self._gibbs_pass(x, masks, temperature, top_k, top_p, debug).view(B, -1)
+
+    @torch.no_grad()
+    def revise(self, x, c, temperature=1.0, top_k=None, top_p=None, n_steps=8, debug=False, context_indices=None,
+               target_indices=None):
+        """reference :588-630"""
+        B, N = x.shape[0], int(np.prod(x.shape[1:]))
+        x = x.reshape(B, N)
+        self.mask_sampler.noise_hook = self.noise_hook
+        ci, ti = self._full_sets(B, N, x.device, context_indices, target_indices)
+        masks = self.mask_sampler.create_gibbs_revise_mask(ci, ti, n_steps, x.device)
+        assert not self.transformer.training
+        return self._gibbs_pass(x, masks, temperature, top_k, top_p, debug).view(B, -1)
+
+    @torch.no_grad()
+    def draft_and_revise(self, x, c, n_draft=8, draft_t=1.0, draft_k=None, draft_p=None, n_revise=8, revise_t=1.0,
+                         revise_k=None, revise_p=None, M=2, skip_draft=False, debug=False, context_indices=None,
+                         target_indices=None, edit=False):
+        """reference :632-663"""
+        B, N = x.shape[0], int(np.prod(x.shape[1:]))
+        x = x.reshape(B, N)
+        assert not self.transformer.training
+        if not skip_draft:
+            x = self.draft(x, c, draft_t, draft_k, draft_p, n_draft, debug, context_indices, target_indices)
+        if edit:
+            context_indices = target_indices = None
+        for _ in range(M):
+            x = self.revise(x, c, revise_t, revise_k, revise_p, n_revise, debug, context_indices, target_indices)
+        return x.view(B, -1)
+
+
+# ---- module-level sampler helpers (reference :826-910) -----------------------------------------------------
+def sample_from_logits_scored(logits, temperature, top_k, top_p, noise, want_probs=False):
+    """ids = argmax(p/noise), scores = p[ids] (and optionally p) in ONE kernel; p is the distribution
+    after temperature / top-k / top-p (reference :859-874)."""
+    shape = logits.shape[:-1]
+    V = logits.shape[-1]
+    lg = logits.to(torch.float32).contiguous().view(-1, V)
+    nz = noise.to(torch.float32).contiguous().view(-1, V)
+    R = lg.shape[0]
+    ids = torch.empty(R, dtype=torch.long, device=lg.device)
+    score = torch.empty(R, dtype=torch.float32, device=lg.device)
+    probs = torch.empty(R, V, dtype=torch.float32, device=lg.device) if want_probs else None
+    _lib.check(_lib.load().mebt_op_sample(_lib.ptr(lg), _lib.ptr(nz), float(temperature), int(top_k or 0),
+                                          float(top_p or 0.0), _lib.ptr(ids), _lib.ptr(score), _lib.ptr(probs), R, V,
+                                          _lib.cur_stream()))
+    return ids.view(shape), score.view(shape), (probs.view(*shape, V) if want_probs else None)
+
+
+def sample_from_logits(logits, temperature=1.0, top_k=None, top_p=None, return_probs=False, noise=None):
+    """reference :843-889 (same signature + an optional explicit `noise` tensor of Exp(1) draws)"""
+    if noise is None:
+        noise = torch.empty_like(logits, dtype=torch.float32).exponential_()
+    ids, _, probs = sample_from_logits_scored(logits, temperature, top_k, top_p, noise, want_probs=return_probs)
+    return (ids, probs) if return_probs else ids
+
+
+def gumbel_sort(prob):
+    """reference :826-841 — kept for API completeness (full descending order of p_norm / Exp(1))"""
+    prob = prob / prob.sum(-1, keepdim=True)
+    key = prob / torch.empty_like(prob).exponential_() * (prob > 0).float()
+    return key.sort(dim=-1, descending=True)[1]
+
+
+def top_k_logits(logits, k):
+    """reference :891-895"""
+    v, _ = torch.topk(logits, k)
+    out = logits.clone()
+    out[out < v[..., [-1]]] = -float('Inf')
+    return out
+
+
+def top_p_probs(probs, p):
+    """reference :898-910"""
+    sp, si = torch.sort(probs, dim=-1, descending=True)
+    rem = torch.cumsum(sp, dim=-1) >= p
+    rem[..., 1:] = rem[..., :-1].clone()
+    rem[..., 0] = 0
+    rem = rem.scatter(-1, si, rem)
+    probs = probs.masked_fill(rem, 0.0)
+    return probs / torch.sum(probs, dim=-1, keepdim=True)

@@ -34,3 +34,51 @@ def build_native(cfg, dtype, P=None, device="cuda"):
             views[k].copy_(v.detach())
     nm.sync_lowp(force=True)
     return nm
+
+
+def product_config(name, schedule="linear", vtokens=True):
+    """Config objects for the shipped Net2NetTransformer equal to make_golden.build_reference's."""
+    from mebt_amd.config import AttrDict
+    from tests.golden import make_golden as mg
+    c = mg.CONFIGS[name]
+    tcfg = AttrDict(unconditional=True, vocab_size=16384, first_stage_vocab_size=16384, block_size=c["block_size"],
+                    n_layer=c["n_layer"], n_head=c["n_head"], n_embd=c["n_embd"], n_unmasked=0, embd_pdrop=0.0,
+                    resid_pdrop=0.0, attn_pdrop=0.0, sample_every_n_latent_frames=0, first_stage_key="video",
+                    cond_stage_key="label", vtokens=vtokens, vtokens_pos=False, vis_epoch=100, sos_emb=c["sos_emb"],
+                    avg_loss=True, mode=list(c["mode"]), class_cond_dim=None)
+    if "label_smoothing" in c:
+        tcfg["label_smoothing"] = c["label_smoothing"]
+    mcfg = AttrDict(target="mebt.mask_sampler.MaskGen",
+                    params=AttrDict(iid=False, schedule=schedule, max_token=c["block_size"], method="mlm",
+                                    shape=c["shape"], t_range=[0.0, 1.0], budget=c["budget"]))
+    return tcfg, AttrDict(params=AttrDict(ckpt_path=None)), mcfg
+
+
+def build_product(name, dtype, schedule="linear", device="cuda"):
+    """The shipped module (mebt.transformer.Net2NetTransformer) with the closed-form weights."""
+    from mebt.transformer import Net2NetTransformer
+    from oracle import closed_form as cf
+    from tests.golden import make_golden as mg
+    tcfg, vcfg, mcfg = product_config(name, schedule)
+    model = Net2NetTransformer(tcfg, vcfg, mcfg, cond_stage_key="label")
+    model.compute_dtype = dtype
+    sd = {k: torch.from_numpy(v) for k, v in cf.state_dict_numpy(orc.param_shapes(mg.oracle_cfg(name, schedule))).items()}
+    model.load_state_dict(sd, strict=True)
+    return model.to(device)
+
+
+def closed_form_hook():
+    """noise hook replaying the numbered closed-form streams of make_golden.ClosedFormRNG"""
+    from oracle import closed_form as cf
+    state = {"k": 0}
+
+    def hook(kind, shape):
+        k = state["k"]
+        state["k"] += 1
+        if kind == "randn":
+            return torch.from_numpy(cf.pseudo_normal("noise", tuple(shape), std=1.0, stream=k))
+        if kind == "perm":
+            return torch.from_numpy(cf.permutation("noise", int(shape[0]), stream=k))
+        return torch.from_numpy(cf.exp1_noise("noise", tuple(shape), stream=k))
+
+    return hook, state

@@ -1,0 +1,147 @@
+"""The shipped Python surface (mebt.transformer.Net2NetTransformer & friends, backed by
+libmebt_hip.so) against the golden vectors of the reference: forward, loss/accuracy, the sampling
+loops (bit-exact token ids for identical noise) and three optimiser steps.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import closed_form as cf
+from oracle import mebt_oracle as orc
+from tests.golden import make_golden as mg
+from tests.helpers import load_golden, build_product, closed_form_hook
+
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("name", ["c1", "micro_budget"])
+def test_module_forward_and_shared_step(name):
+    g = load_golden("forward_" + name)
+    model = build_product(name, "f32")
+    x, idx = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["indices"]).to(DEV)
+    for c, (mode, t) in enumerate(zip(g["case_mode"], g["case_t"])):
+        model.train(mode == "train")
+        with torch.no_grad():
+            logits, z_t, ntw, seq_len = model(x, None, t=float(t), indices=idx)
+        meta = g[f"c{c}_meta"]
+        assert (z_t.cpu().numpy() == g[f"c{c}_z_targets"]).all()
+        assert ntw == meta[0] and seq_len == meta[1]
+        np.testing.assert_allclose(logits.cpu()[..., g["cols"]].numpy(), g[f"c{c}_cols"], atol=1e-4, rtol=0)
+        # shared_step (fused loss + top-1/top-5) with the python RNG draw forced to t
+        import random
+        orig = random.random
+        random.random = lambda: float(t)
+        try:
+            with torch.no_grad():
+                a1, a5, loss, ratio = model.shared_step({"video": x, "indices": idx}, 0)
+        finally:
+            random.random = orig
+        assert abs(float(loss) - meta[2]) < 2e-5 * abs(meta[2])
+        assert abs(float(a1) - meta[3]) < 1e-3 and abs(float(a5) - meta[4]) < 1e-3
+
+
+def test_state_dict_roundtrip_and_names():
+    model = build_product("micro", "f32")
+    sd = model.state_dict()
+    shapes = orc.param_shapes(mg.oracle_cfg("micro"))
+    assert set(sd.keys()) == set(shapes.keys())                      # SURVEY.md §A.2 schema
+    ref = cf.state_dict_numpy(shapes)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]) and np.array_equal(v.cpu().numpy(), ref[k]), k
+
+
+def test_sample_loops_bit_exact():
+    g = load_golden("sample_loops")
+    for i, (strategy, sched, run) in enumerate(zip(g["run_strategy"], g["run_schedule"], g["runs"])):
+        n_steps, temp, k, p, ctemp = run
+        model = build_product("micro", "f32", schedule=str(sched)).eval()
+        hook, state = closed_form_hook()
+        model.noise_hook = hook
+        x = torch.zeros(2, 2, 4, 4, dtype=torch.long, device=DEV)
+        xs, ci, ti = model.sample(x, None, float(temp), None if k < 0 else int(k), None if p < 0 else float(p), int(n_steps),
+                                  None, None, strategy=str(strategy), context_temperature=float(ctemp), skips=False)
+        assert state["k"] == int(g[f"r{i}_ndraws"]), (i, state["k"])
+        assert (xs.cpu().numpy() == g[f"r{i}_x"]).all(), i
+        assert (ci.cpu().numpy() == g[f"r{i}_ci"]).all() and (ti.cpu().numpy() == g[f"r{i}_ti"]).all(), i
+    # continuation from given index sets
+    model = build_product("micro", "f32", schedule="cosine").eval()
+    hook, _ = closed_form_hook()
+    model.noise_hook = hook
+    idx = torch.from_numpy(g["cont_idx"]).to(DEV)
+    xs, ci, ti = model.sample(torch.from_numpy(g["cont_x0"]).to(DEV), None, 1.0, None, None, 4, idx[:, :10], idx[:, 10:],
+                              context_temperature=3.0, skips=False)
+    assert (xs.cpu().numpy() == g["cont_x"]).all() and (ci.cpu().numpy() == g["cont_ci"]).all() and (ti.cpu().numpy() == g["cont_ti"]).all()
+
+
+def test_draft_and_revise_bit_exact():
+    g = load_golden("sample_loops")
+    opt = lambda v, f: None if v < 0 else f(v)
+    for i, r in enumerate(g["dnr"]):
+        model = build_product("micro", "f32").eval()
+        hook, state = closed_form_hook()
+        model.noise_hook = hook
+        xs = model.draft_and_revise(torch.from_numpy(g[f"d{i}_x0"]).to(DEV), None, int(r[0]), float(r[1]), opt(r[2], int),
+                                    opt(r[3], float), int(r[4]), float(r[5]), opt(r[6], int), opt(r[7], float), int(r[8]), bool(r[9]))
+        assert state["k"] == int(g[f"d{i}_ndraws"])
+        assert (xs.cpu().numpy() == g[f"d{i}_x"]).all(), i
+
+
+def test_sample_debug_tuple_and_gpt_forward_boundary():
+    model = build_product("micro", "f32", schedule="cosine").eval()
+    hook, _ = closed_form_hook()
+    model.noise_hook = hook
+    x = torch.zeros(2, 2, 4, 4, dtype=torch.long, device=DEV)
+    out = model.sample(x, None, 1.0, None, None, 4, None, None, context_temperature=2.0, skips=False, debug=True)
+    assert len(out) == 6 and out[5].shape == (2, 32, 16384) and len(out[3]) == len(out[4]) + 1
+    # GPT.forward on embedded inputs == oracle
+    cfg = mg.oracle_cfg("micro")
+    P = orc.closed_form_params(cfg)
+    xx, idx = mg.inputs("micro", 2, "gptfwd")
+    ci, ti = idx[:, :9], idx[:, 9:]
+    sos, ctx, tgt = orc.embed(P, cfg, xx.reshape(2, -1), ci, ti)
+    ref = orc.gpt_forward(P, cfg, sos, ctx, tgt)
+    got, _ = model.transformer(sos.to(DEV), ctx.to(DEV), tgt.to(DEV), None, 0.)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["micro", "micro_budget"])
+@pytest.mark.parametrize("path", ["fused", "reference_style"])
+def test_lightning_style_training_steps(name, path):
+    """training_step -> loss.backward() -> optimizer_step, as the Lightning loop drives the
+    reference; 'reference_style' computes F.cross_entropy on the returned logits exactly like
+    reference shared_step (transformer.py:722-730) and lets autograd call the HIP backward."""
+    import random
+    import torch.nn.functional as F
+    g = load_golden("train_" + name)
+    model = build_product(name, "f32").train()
+    model.learning_rate, model.weight_decay = float(g["lr"]), float(g["wd"])
+    opt = model.configure_optimizers()
+    assert [len(grp["params"]) for grp in opt.param_groups] == list(g["group_sizes"])
+    assert [grp["weight_decay"] for grp in opt.param_groups] == list(g["group_wd"])
+    names = [str(n) for n in g["names"]]
+    for s, t in enumerate(g["ts"]):
+        x, idx = torch.from_numpy(g[f"s{s}_x"]).to(DEV), torch.from_numpy(g[f"s{s}_indices"]).to(DEV)
+        orig = random.random
+        random.random = lambda: float(t)
+        try:
+            if path == "fused":
+                loss = model.training_step({"video": x, "indices": idx}, 0)
+            else:
+                logits, target, ntw, seq_len = model(x, None, indices=idx)
+                B = logits.shape[0]
+                ce = F.cross_entropy(logits.reshape(-1, logits.size(-1)), target.reshape(-1), reduction='sum',
+                                     label_smoothing=model.label_smoothing)
+                loss = ce / (B * seq_len * (ntw / float(seq_len)) ** model.config.avg_loss)
+        finally:
+            random.random = orig
+        loss.backward()
+        meta = g[f"s{s}_meta"]
+        assert abs(float(loss) - meta[0]) < 5e-5 * abs(meta[0]), (s, float(loss), meta[0])
+        sd = dict(model.named_parameters())
+        gn = np.array([float(sd[n].grad.double().norm()) for n in names])
+        np.testing.assert_allclose(gn, g[f"s{s}_gradnorm"], rtol=2e-3, atol=1e-6)
+        model.optimizer_step(optimizer=opt)
+        model.trainer.global_step += 1
+        pn = np.array([float(sd[n].detach().double().norm()) for n in names])
+        np.testing.assert_allclose(pn, g[f"s{s}_pnorm"], rtol=2e-5)
