@@ -1,0 +1,400 @@
+// MFMA flash attention for gfx950, bf16, head size 64: forward, dQ and dK/dV kernels.
+// Replaces reference mebt/modules/gpt.py:131-137 (q@k^T * 1/sqrt(hd) -> softmax -> @v) and its
+// autograd backward for the four routings (NQ x NK) = (NS,NC), (NS,NS), (NT,NS), (NS,NS+NT).
+//
+// Structure (all three kernels): a workgroup = 4 waves, each wave owns 16 rows (queries in
+// forward/dQ, keys in dK/dV) of one (batch, head); the other side is streamed in 64-row tiles
+// through LDS (register-staged, next tile's global loads issued before the MFMAs of the current
+// one, two LDS stages, one barrier per tile).  The score tile is computed TRANSPOSED with respect
+// to the owned rows so that (i) the softmax statistics of a row live in one lane (+2 shuffles
+// across the 4 lane groups) and (ii) the score accumulators are directly the B operand of the
+// next product (v_mfma_f32_16x16x32_bf16: lane = column, registers = 4 rows), with no LDS round
+// trip.  The operand that must be read column-wise (V in forward, K in dQ, Q/dO in dK/dV) comes
+// from the same row-major LDS image through ds_read_b64_tr_b16.
+//
+// LDS tile image: [64 rows][64 bf16] = 128-byte rows, 16-byte chunk index XOR-swizzled with
+// ((row >> 1) & 3) << 1, which is conflict-free for both the ds_read_b128 row reads and the
+// transposed reads used here.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TILE = 64;                 // rows per streamed tile
+constexpr int TILE_BYTES = TILE * 64 * 2;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 3) << 1; }
+
+// 4 x 16-byte chunks per thread cover half a tile: a [64 x 64] bf16 tile = 512 chunks = 2 per thread
+struct TileLoad {
+    uint32_t goff[2];
+    uint32_t loff[2];
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t step;
+    // base: first row of this (batch) slice at column h*64; rows: valid rows in the slice
+    __device__ __forceinline__ void init(const bf16_t* base, int rows, int ld, int tid) {
+        rsrc = make_rsrc(base, rows > 0 ? ((size_t)(rows - 1) * ld + 64) * 2 : 0);
+        step = (uint32_t)TILE * ld * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, c = id & 7;
+            goff[i] = ((uint32_t)row * ld + 8 * c) * 2;
+            loff[i] = row * 128 + ((c ^ swz(row)) << 4);
+        }
+    }
+    __device__ __forceinline__ void load(u32x4 (&r)[2], int tile) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) r[i] = buf_load16(rsrc, goff[i] + (uint32_t)tile * step);
+    }
+    __device__ __forceinline__ void store(char* lds, const u32x4 (&r)[2]) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(lds + loff[i]) = r[i];
+    }
+};
+
+// row-wise fragment: 16 rows (blk16) x 32 k (ks): lane l holds row l&15, k = 32ks + 8(l>>4) + j
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int blk16, int ks, int lane) {
+    const int row = blk16 * 16 + (lane & 15);
+    const int c = 4 * ks + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((c ^ swz(row)) << 4));
+}
+// column-wise fragment (transposed read): the operand's "row" is tile column 16*cb + (l&15); its
+// k index 8g + j maps to tile row  32*kk + 16*(j>>2) + 4g + (j&3)  — the order in which a pair of
+// 16-row score accumulators presents its rows (see pack_acc).
+__device__ __forceinline__ bf16x8 frag_cols(const char* tile, int cb, int kk, int lane) {
+    const int g = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3;
+    const int ch = 2 * cb + (pp >> 1);
+    const int r0 = 32 * kk + 4 * g + q4, r1 = r0 + 16;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + r0 * 128 + ((ch ^ swz(r0)) << 4) + 8 * (pp & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + r1 * 128 + ((ch ^ swz(r1)) << 4) + 8 * (pp & 1)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// two 16-row accumulators (rows 4g+r of blocks 2kk and 2kk+1) -> B operand of the next product
+__device__ __forceinline__ bf16x8 pack_acc(const f32x4& a, const f32x4& b) {
+    bf16x8 v = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+    return v;
+}
+// fragment straight from global memory: lane l holds row (l&15) of a 16-row block, k = 32ks + 8(l>>4) + j
+__device__ __forceinline__ bf16x8 frag_global(const bf16_t* base, int row, int rows, int ld, int ks, int lane) {
+    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row >= rows) return z;
+    return *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + 32 * ks + 8 * (lane >> 4));
+}
+__device__ __forceinline__ float group_sum(float v) {   // across the 4 lane groups (same l&15)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // 2 stages x (K, V)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (size_t)b * p.NQ * p.ldq + h * 64;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (size_t)b * p.NK * p.ldk + h * 64;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * p.NK * p.ldv + h * 64;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = frag_global(Q, q, p.NQ, p.ldq, ks, lane);
+    TileLoad lk, lv;
+    lk.init(K, p.NK, p.ldk, tid);
+    lv.init(V, p.NK, p.ldv, tid);
+    const int ntiles = (p.NK + TILE - 1) / TILE;
+    const float c = 0.125f * LOG2E;     // 1/sqrt(64) folded with log2(e)
+
+    f32x4 o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f32x4{0, 0, 0, 0};
+    float m = -INFINITY, l = 0.f;
+
+    u32x4 rk[2], rv[2];
+    lk.load(rk, 0);
+    lv.load(rv, 0);
+    lk.store(smem, rk);
+    lv.store(smem + TILE_BYTES, rv);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const char* sK = smem + (t & 1) * 2 * TILE_BYTES;
+        const char* sV = sK + TILE_BYTES;
+        const bool more = t + 1 < ntiles;
+        if (more) { lk.load(rk, t + 1); lv.load(rv, t + 1); }
+        // S^T[key][q] for the 64 keys of the tile
+        f32x4 s[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            s[kb] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) s[kb] = MFMA(frag_rows(sK, kb, ks, lane), qf[ks], s[kb]);
+        }
+        const int k0 = t * TILE;
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + 16 * kb + 4 * g + r;
+                s[kb][r] = key < p.NK ? s[kb][r] * c : -INFINITY;
+                tmax = fmaxf(tmax, s[kb][r]);
+            }
+        tmax = group_max(tmax);
+        const float mn = fmaxf(m, tmax);
+        const float alpha = exp2f(m - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[kb][r] = exp2f(s[kb][r] - mn); ps += s[kb][r]; }
+        ps = group_sum(ps);
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] *= alpha;
+        // O^T[e][q] += V^T[e][key] P^T[key][q]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 pf = pack_acc(s[2 * kk], s[2 * kk + 1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = MFMA(frag_cols(sV, e, kk, lane), pf, o[e]);
+        }
+        if (more) {
+            char* d = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+            lk.store(d, rk);
+            lv.store(d + TILE_BYTES, rv);
+        }
+        __syncthreads();
+    }
+    if (q < p.NQ) {
+        const float inv = 1.0f / l;
+        bf16_t* O = reinterpret_cast<bf16_t*>(p.o) + ((size_t)b * p.NQ + q) * p.ldo + h * 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store4<bf16_t>(O + 16 * e + 4 * g, o[e] * inv);
+        if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * p.NQ + q] = m * 0.6931471805599453f + logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dQ (+ delta = rowsum(dO * O)).  One wave = 16 query rows; K/V tiles streamed.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
+    const bool qv = q < p.NQ;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (size_t)b * p.NQ * p.ldq + h * 64;
+    const bf16_t* G = reinterpret_cast<const bf16_t*>(p.d_o) + (size_t)b * p.NQ * p.lddo + h * 64;
+    const bf16_t* Oo = reinterpret_cast<const bf16_t*>(p.o) + (size_t)b * p.NQ * p.ldo + h * 64;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (size_t)b * p.NK * p.ldk + h * 64;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * p.NK * p.ldv + h * 64;
+    bf16x8 qf[2], gf[2];
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        qf[ks] = frag_global(Q, q, p.NQ, p.ldq, ks, lane);
+        gf[ks] = frag_global(G, q, p.NQ, p.lddo, ks, lane);
+        const bf16x8 of = frag_global(Oo, q, p.NQ, p.ldo, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += (float)gf[ks][j] * (float)of[j];
+    }
+    delta = group_sum(delta);
+    const size_t sidx = ((size_t)b * p.H + h) * p.NQ + q;
+    const float lse2 = qv ? p.lse[sidx] * LOG2E : 0.f;
+    if (qv && g == 0) p.delta[sidx] = delta;
+    TileLoad lk, lv;
+    lk.init(K, p.NK, p.ldk, tid);
+    lv.init(V, p.NK, p.ldv, tid);
+    const int ntiles = (p.NK + TILE - 1) / TILE;
+    const float c = 0.125f * LOG2E;
+
+    f32x4 dq[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dq[e] = f32x4{0, 0, 0, 0};
+    u32x4 rk[2], rv[2];
+    lk.load(rk, 0);
+    lv.load(rv, 0);
+    lk.store(smem, rk);
+    lv.store(smem + TILE_BYTES, rv);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const char* sK = smem + (t & 1) * 2 * TILE_BYTES;
+        const char* sV = sK + TILE_BYTES;
+        const bool more = t + 1 < ntiles;
+        if (more) { lk.load(rk, t + 1); lv.load(rv, t + 1); }
+        const int k0 = t * TILE;
+        f32x4 ds[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s = MFMA(frag_rows(sK, kb, ks, lane), qf[ks], s);      // S^T[key][q]
+                dp = MFMA(frag_rows(sV, kb, ks, lane), gf[ks], dp);    // dP^T[key][q] = V dO^T
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + 16 * kb + 4 * g + r;
+                const float pr = key < p.NK ? exp2f(s[r] * c - lse2) : 0.f;
+                ds[kb][r] = pr * (dp[r] - delta) * 0.125f;
+            }
+        }
+        // dQ^T[e][q] += K^T[e][key] dS^T[key][q]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 df = pack_acc(ds[2 * kk], ds[2 * kk + 1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dq[e] = MFMA(frag_cols(sK, e, kk, lane), df, dq[e]);
+        }
+        if (more) {
+            char* d = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+            lk.store(d, rk);
+            lv.store(d + TILE_BYTES, rv);
+        }
+        __syncthreads();
+    }
+    if (qv) {
+        bf16_t* D = reinterpret_cast<bf16_t*>(p.dq) + ((size_t)b * p.NQ + q) * p.lddq + h * 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store4<bf16_t>(D + 16 * e + 4 * g, dq[e]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dK, dV.  One wave = 16 key rows; Q / dO tiles (+ lse, delta) streamed.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    __shared__ float sL[2][TILE], sD[2][TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int key = blockIdx.x * 64 + wave * 16 + (lane & 15);
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (size_t)b * p.NQ * p.ldq + h * 64;
+    const bf16_t* G = reinterpret_cast<const bf16_t*>(p.d_o) + (size_t)b * p.NQ * p.lddo + h * 64;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (size_t)b * p.NK * p.ldk + h * 64;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * p.NK * p.ldv + h * 64;
+    const float* L = p.lse + ((size_t)b * p.H + h) * p.NQ;
+    const float* Dl = p.delta + ((size_t)b * p.H + h) * p.NQ;
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        kf[ks] = frag_global(K, key, p.NK, p.ldk, ks, lane);
+        vf[ks] = frag_global(V, key, p.NK, p.ldv, ks, lane);
+    }
+    TileLoad lq, lg;
+    lq.init(Q, p.NQ, p.ldq, tid);
+    lg.init(G, p.NQ, p.lddo, tid);
+    const int ntiles = (p.NQ + TILE - 1) / TILE;
+    const float c = 0.125f * LOG2E;
+
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dk[e] = f32x4{0, 0, 0, 0}; dv[e] = f32x4{0, 0, 0, 0}; }
+    u32x4 rq[2], rg[2];
+    float rl = 0.f, rd = 0.f;
+    auto load_stats = [&](int t) {
+        if (tid < TILE) {
+            const int qq = t * TILE + tid;
+            rl = qq < p.NQ ? L[qq] * LOG2E : INFINITY;    // +inf: exp2(s - inf) = 0 masks padded query rows
+            rd = qq < p.NQ ? Dl[qq] : 0.f;
+        }
+    };
+    lq.load(rq, 0);
+    lg.load(rg, 0);
+    load_stats(0);
+    lq.store(smem, rq);
+    lg.store(smem + TILE_BYTES, rg);
+    if (tid < TILE) { sL[0][tid] = rl; sD[0][tid] = rd; }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const char* sQ = smem + (t & 1) * 2 * TILE_BYTES;
+        const char* sG = sQ + TILE_BYTES;
+        const float* cl = sL[t & 1];
+        const float* cd = sD[t & 1];
+        const bool more = t + 1 < ntiles;
+        if (more) { lq.load(rq, t + 1); lg.load(rg, t + 1); load_stats(t + 1); }
+        f32x4 pr[4], ds[4];
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s = MFMA(frag_rows(sQ, qb, ks, lane), kf[ks], s);      // S[q][key]
+                dp = MFMA(frag_rows(sG, qb, ks, lane), vf[ks], dp);    // dP[q][key] = dO V^T
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = 16 * qb + 4 * g + r;
+                pr[qb][r] = exp2f(s[r] * c - cl[qi]);
+                ds[qb][r] = pr[qb][r] * (dp[r] - cd[qi]) * 0.125f;
+            }
+        }
+        // dV^T[e][key] += dO^T[e][q] P[q][key];   dK^T[e][key] += Q^T[e][q] dS[q][key]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 pf = pack_acc(pr[2 * kk], pr[2 * kk + 1]);
+            const bf16x8 df = pack_acc(ds[2 * kk], ds[2 * kk + 1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dv[e] = MFMA(frag_cols(sG, e, kk, lane), pf, dv[e]);
+                dk[e] = MFMA(frag_cols(sQ, e, kk, lane), df, dk[e]);
+            }
+        }
+        if (more) {
+            char* d = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+            lq.store(d, rq);
+            lg.store(d + TILE_BYTES, rg);
+            if (tid < TILE) { sL[(t + 1) & 1][tid] = rl; sD[(t + 1) & 1][tid] = rd; }
+        }
+        __syncthreads();
+    }
+    if (key < p.NK) {
+        bf16_t* DK = reinterpret_cast<bf16_t*>(p.dk) + ((size_t)b * p.NK + key) * p.lddk + h * 64;
+        bf16_t* DV = reinterpret_cast<bf16_t*>(p.dv) + ((size_t)b * p.NK + key) * p.lddv + h * 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            store4<bf16_t>(DK + 16 * e + 4 * g, dk[e]);
+            store4<bf16_t>(DV + 16 * e + 4 * g, dv[e]);
+        }
+    }
+}
+
+}  // namespace
+
+static int check_layout(const AttnParams& p) {
+    if (p.HD != 64) { mebt_set_error("mfma attention: head size must be 64"); return MEBT_ESHAPE; }
+    if ((p.ldq | p.ldk | p.ldv | p.ldo) % 8) { mebt_set_error("mfma attention: row strides must be multiples of 8 elements"); return MEBT_ESHAPE; }
+    return MEBT_OK;
+}
+
+int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
+    if (int rc = check_layout(p)) return rc;
+    const dim3 grid((p.NQ + 63) / 64, p.H, p.B);
+    hipLaunchKernelGGL(attn_fwd_mfma, grid, dim3(256), 0, stream, p);
+    MEBT_HIP_CHECK(hipGetLastError());
+    return MEBT_OK;
+}
+
+int launch_attn_bwd_mfma(const AttnParams& p, hipStream_t stream) {
+    if (int rc = check_layout(p)) return rc;
+    if ((p.lddo | p.lddq | p.lddk | p.lddv) % 8) { mebt_set_error("mfma attention: row strides must be multiples of 8 elements"); return MEBT_ESHAPE; }
+    const dim3 gq((p.NQ + 63) / 64, p.H, p.B);
+    hipLaunchKernelGGL(attn_bwd_dq_mfma, gq, dim3(256), 0, stream, p);
+    const dim3 gk((p.NK + 63) / 64, p.H, p.B);
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma, gk, dim3(256), 0, stream, p);
+    MEBT_HIP_CHECK(hipGetLastError());
+    return MEBT_OK;
+}

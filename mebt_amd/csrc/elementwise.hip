@@ -212,15 +212,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
 // ------------------------------------------------------------------------------------------------
 // column sums: out[n] += sum_m X[m,n]
 // ------------------------------------------------------------------------------------------------
+// Workgroup = 64 columns x `rows_per_block` rows: thread (cg = tid&15, rl = tid>>4) sums rows
+// rl, rl+16, ... of its 4 columns (16 threads x 8/16 B = one 128/256-B segment per row), the 16
+// row-lanes are reduced through LDS and ONE atomic per column leaves the workgroup, so at most
+// M/rows_per_block adders meet on an address (float atomics collapse under contention).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, int ldx, float* out, int rows_per_block) {
-    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (n >= N) return;
+    __shared__ float red[16][64 + 4];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int n = blockIdx.x * 64 + cg * 4;
     const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
     f32x4 acc = {0, 0, 0, 0};
-    for (int m = m0; m < m1; ++m) acc += load4<T>(X + (size_t)m * ldx + n);
+    if (n < N)
+        for (int m = m0 + rl; m < m1; m += 16) acc += load4<T>(X + (size_t)m * ldx + n);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(out + n + j, acc[j]);
+    for (int j = 0; j < 4; ++j) red[rl][cg * 4 + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+        const int col = blockIdx.x * 64 + threadIdx.x;
+        if (col < N) atomicAdd(out + col, t);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -397,7 +411,8 @@ int launch_ln_fwd(const LnFwdParams& p, int dtype, hipStream_t stream) {
 int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream) {
     if (p.rows <= 0) return MEBT_OK;
     if (p.d % 4 || p.d > 256 * LN_MAXC) { mebt_set_error("layernorm: d must be a multiple of 4 and <= 2048"); return MEBT_ESHAPE; }
-    const int blocks = min((p.rows + 3) / 4, 1024);
+    // few workgroups: each ends with 2*d float atomics on the same dgamma/dbeta addresses
+    const int blocks = min((p.rows + 3) / 4, 128);
     if (dtype == MEBT_BF16) {
         if (p.dx_f32) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, stream, p);
@@ -411,9 +426,10 @@ int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream) {
 int launch_colsum(const void* X, int M, int N, int ldx, float* out, int dtype, hipStream_t stream) {
     if (M <= 0 || N <= 0) return MEBT_OK;
     if (N % 4) { mebt_set_error("colsum: N must be a multiple of 4"); return MEBT_ESHAPE; }
-    const int gx = (N / 4 + 255) / 256;
-    int rpb = 32;
-    while ((long)gx * ((M + rpb - 1) / rpb) > 4096) rpb *= 2;
+    const int gx = (N + 63) / 64;
+    int rpb = 256;
+    while ((M + rpb - 1) / rpb > 32) rpb *= 2;          // <= 32 adders per address
+    while (rpb > 64 && (long)gx * ((M + rpb - 1) / rpb) < 256) rpb /= 2;   // but fill the chip
     const dim3 grid(gx, (M + rpb - 1) / rpb);
     if (dtype == MEBT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, stream, reinterpret_cast<const bf16_t*>(X), M, N, ldx, out, rpb);
     else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, reinterpret_cast<const float*>(X), M, N, ldx, out, rpb);

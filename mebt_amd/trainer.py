@@ -1,0 +1,48 @@
+"""The training step as the launcher and bench.py drive it: forward -> fused loss -> backward with
+bucketed all-reduce overlap -> fused AdamW, all on the engine, no host synchronisation inside.
+Counterpart of what Lightning's fit loop does around the reference's training_step / optimizer_step
+(SURVEY.md §3.1)."""
+import random
+
+import numpy as np
+import torch
+
+from .parallel import GradReducer
+
+
+class TrainLoop:
+    def __init__(self, model, reducer=None, max_steps=0):
+        """model: mebt_amd.transformer.Net2NetTransformer on its GPU, with learning_rate /
+        warmup_steps / weight_decay / cosine_lr set (train_transformer.py:54-66)."""
+        self.model = model
+        self.native = model._ensure_native()
+        self.native.ensure_grads()
+        self.reducer = reducer or GradReducer(world_size=1)
+        model._reducer = self.reducer
+        self.step_count = 0
+        model.trainer.max_steps = max_steps
+        self.reducer.broadcast_parameters(self.native)
+
+    def step(self, x, indices, t=None):
+        """x [B,T,H,W] int64 tokens, indices [B,N] permutations.  Returns a device tensor
+        [CE sum, #top1, #top5, #rows, loss] (float64) — read it only when you want to log."""
+        m, nm, red = self.model, self.native, self.reducer
+        B = x.shape[0]
+        x_ids = x.reshape(B, -1)
+        if t is None:
+            t = m._draw_t(False)
+        prior_t = m.t_prior(m.t_lengths, m.global_step)
+        ci, ti, seq_len = m.mask_sampler.divide_indices(indices, torch.tensor(float(t)), m.t_lengths, prior_t)
+        ci, ti = ci.contiguous(), ti.contiguous()
+        ratio = float(seq_len - ci.shape[1]) / float(seq_len)
+        scale = 1.0 / (B * seq_len * ratio ** m.config.avg_loss)
+        logits = nm.forward(x_ids, ci, ti, training=True, dropout_seed=m._next_seed())
+        stats = nm.loss_stats(logits)
+        nm.backward(logits, scale, between=lambda s, hi, lo: red.bucket_ready(nm, s, hi, lo))
+        red.wait()
+        lr = m.learning_rate * m.lr_scale()
+        self.step_count += 1
+        nm.adamw_step(lr, m.weight_decay, self.step_count, grad_scale=red.grad_scale)
+        m.trainer.global_step += 1
+        m.global_step += 1
+        return torch.cat([stats, (stats[0] * scale).reshape(1)])
