@@ -142,6 +142,8 @@ int mebt_op_cast_bf16(const float* src, void* dst, int64_t n, mebt_stream_t stre
  * then read {launches, total ms, total algorithmic flops} of the GEMM family. */
 int mebt_profile_enable(int32_t on);
 int mebt_profile_read(int32_t family, double* launches, double* total_ms, double* total_flops);
+/* Benchmarking / tests only: force the bf16 GEMM block tile (bm, bn in {128, 64}); (0, 0) restores the heuristic. */
+void mebt_debug_gemm_tile(int32_t bm, int32_t bn);
 
 #ifdef __cplusplus
 }

@@ -136,76 +136,84 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdParams p) {
     if (p.mean && lane == 0) { p.mean[orow] = mean; p.rstd[orow] = rstd; }
 }
 
-// dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  dgamma += dy*xhat;  dbeta += dy
+// LayerNorm backward, two kernels:
+//  (1) dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) [+ dx_add] — one wave per row, full grid;
+//  (2) dgamma += sum_rows dy*xhat, dbeta += sum_rows dy — column reduction (64 columns x a chunk of
+//      rows per workgroup, LDS reduce, ONE atomic per column per workgroup: float atomics collapse
+//      when hundreds of workgroups meet on the same 2*d addresses).
 template <typename T, typename TDX>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdParams p) {
-    __shared__ float red[2][4][64 * 4 + 4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 dg[LN_MAXC], db[LN_MAXC];
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const LnBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const long mrow = map_row(row, p.seg, p.seg_stride, p.seg_off);
+    const T* x = reinterpret_cast<const T*>(p.x) + (size_t)row * p.d;
+    const T* dy = reinterpret_cast<const T*>(p.dy) + (size_t)mrow * p.d;
+    const T* dy2 = p.dy2 ? reinterpret_cast<const T*>(p.dy2) + (size_t)row * p.d : nullptr;
+    const float mean = p.mean[mrow], rstd = p.rstd[mrow];
+    f32x4 xh[LN_MAXC], gy[LN_MAXC];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) { dg[c] = f32x4{0, 0, 0, 0}; db[c] = f32x4{0, 0, 0, 0}; }
-    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
-        const long mrow = map_row(row, p.seg, p.seg_stride, p.seg_off);
-        const T* x = reinterpret_cast<const T*>(p.x) + (size_t)row * p.d;
-        const T* dy = reinterpret_cast<const T*>(p.dy) + (size_t)mrow * p.d;
-        const T* dy2 = p.dy2 ? reinterpret_cast<const T*>(p.dy2) + (size_t)row * p.d : nullptr;
-        const float mean = p.mean[mrow], rstd = p.rstd[mrow];
-        f32x4 xh[LN_MAXC], gy[LN_MAXC];
-        float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int e = lane * 4 + 256 * c;
+        if (e < p.d) {
+            const f32x4 xv = load4<T>(x + e);
+            f32x4 d = load4<T>(dy + e);
+            if (dy2) d += load4<T>(dy2 + e);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + e);
 #pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {
-            const int e = lane * 4 + 256 * c;
-            if (e < p.d) {
-                const f32x4 xv = load4<T>(x + e);
-                f32x4 d = load4<T>(dy + e);
-                if (dy2) d += load4<T>(dy2 + e);
-                const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + e);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    xh[c][j] = (xv[j] - mean) * rstd;
-                    gy[c][j] = d[j] * g[j];
-                    s1 += gy[c][j];
-                    s2 += gy[c][j] * xh[c][j];
-                    dg[c][j] += d[j] * xh[c][j];
-                    db[c][j] += d[j];
-                }
-            }
-        }
-        const float m1 = wave_sum(s1) / p.d, m2 = wave_sum(s2) / p.d;
-        TDX* dx = reinterpret_cast<TDX*>(p.dx) + (size_t)row * p.d;
-#pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {
-            const int e = lane * 4 + 256 * c;
-            if (e < p.d) {
-                f32x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = rstd * (gy[c][j] - m1 - xh[c][j] * m2);
-                if (p.dx_add) o += load4<T>(reinterpret_cast<const T*>(p.dx_add) + (size_t)row * p.d + e);
-                if (p.dx_accumulate) o += load4<TDX>(dx + e);
-                store4<TDX>(dx + e, o);
+            for (int j = 0; j < 4; ++j) {
+                xh[c][j] = (xv[j] - mean) * rstd;
+                gy[c][j] = d[j] * g[j];
+                s1 += gy[c][j];
+                s2 += gy[c][j] * xh[c][j];
             }
         }
     }
-    // reduce dgamma / dbeta over the 4 waves, then one atomic per element per workgroup.  The chunk
-    // condition is workgroup-uniform (the barriers must not sit under a lane-dependent branch).
+    const float m1 = wave_sum(s1) / p.d, m2 = wave_sum(s2) / p.d;
+    TDX* dx = reinterpret_cast<TDX*>(p.dx) + (size_t)row * p.d;
 #pragma unroll
     for (int c = 0; c < LN_MAXC; ++c) {
-        if (256 * c < p.d) {
-            const int e = lane * 4 + 256 * c;
-            __syncthreads();
+        const int e = lane * 4 + 256 * c;
+        if (e < p.d) {
+            f32x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { red[0][wave][lane * 4 + j] = dg[c][j]; red[1][wave][lane * 4 + j] = db[c][j]; }
-            __syncthreads();
-            if (wave == 0 && e < p.d) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float g = red[0][0][lane * 4 + j] + red[0][1][lane * 4 + j] + red[0][2][lane * 4 + j] + red[0][3][lane * 4 + j];
-                    const float b = red[1][0][lane * 4 + j] + red[1][1][lane * 4 + j] + red[1][2][lane * 4 + j] + red[1][3][lane * 4 + j];
-                    atomicAdd(p.dgamma + e + j, g);
-                    atomicAdd(p.dbeta + e + j, b);
-                }
-            }
+            for (int j = 0; j < 4; ++j) o[j] = rstd * (gy[c][j] - m1 - xh[c][j] * m2);
+            if (p.dx_add) o += load4<T>(reinterpret_cast<const T*>(p.dx_add) + (size_t)row * p.d + e);
+            if (p.dx_accumulate) o += load4<TDX>(dx + e);
+            store4<TDX>(dx + e, o);
         }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_param_kernel(const LnBwdParams p, int rows_per_block) {
+    __shared__ float red[2][16][64 + 4];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int n = blockIdx.x * 64 + cg * 4;
+    const long m0 = (long)blockIdx.y * rows_per_block;
+    const long m1 = m0 + rows_per_block < p.rows ? m0 + rows_per_block : p.rows;
+    f32x4 ag = {0, 0, 0, 0}, ab = {0, 0, 0, 0};
+    if (n < p.d)
+        for (long m = m0 + rl; m < m1; m += 16) {
+            const long mrow = map_row(m, p.seg, p.seg_stride, p.seg_off);
+            const f32x4 xv = load4<T>(reinterpret_cast<const T*>(p.x) + (size_t)m * p.d + n);
+            f32x4 d = load4<T>(reinterpret_cast<const T*>(p.dy) + (size_t)mrow * p.d + n);
+            if (p.dy2) d += load4<T>(reinterpret_cast<const T*>(p.dy2) + (size_t)m * p.d + n);
+            const float mean = p.mean[mrow], rstd = p.rstd[mrow];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ag[j] += d[j] * ((xv[j] - mean) * rstd); ab[j] += d[j]; }
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][rl][cg * 4 + j] = ag[j]; red[1][rl][cg * 4 + j] = ab[j]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, col = threadIdx.x & 63;
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[which][r][col];
+        const int c = blockIdx.x * 64 + col;
+        if (c < p.d) atomicAdd((which ? p.dbeta : p.dgamma) + c, t);
     }
 }
 
@@ -411,13 +419,19 @@ int launch_ln_fwd(const LnFwdParams& p, int dtype, hipStream_t stream) {
 int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream) {
     if (p.rows <= 0) return MEBT_OK;
     if (p.d % 4 || p.d > 256 * LN_MAXC) { mebt_set_error("layernorm: d must be a multiple of 4 and <= 2048"); return MEBT_ESHAPE; }
-    // few workgroups: each ends with 2*d float atomics on the same dgamma/dbeta addresses
-    const int blocks = min((p.rows + 3) / 4, 128);
+    const dim3 grid((p.rows + 3) / 4);
+    const int gx = (p.d + 63) / 64;
+    int rpb = 256;
+    while ((p.rows + rpb - 1) / rpb > 32) rpb *= 2;
+    while (rpb > 64 && (long)gx * ((p.rows + rpb - 1) / rpb) < 256) rpb /= 2;
+    const dim3 pgrid(gx, (p.rows + rpb - 1) / rpb);
     if (dtype == MEBT_BF16) {
-        if (p.dx_f32) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, stream, p);
+        if (p.dx_f32) hipLaunchKernelGGL((ln_bwd_dx_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((ln_bwd_dx_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(ln_bwd_param_kernel<bf16_t>, pgrid, dim3(256), 0, stream, p, rpb);
     } else {
-        hipLaunchKernelGGL((ln_bwd_kernel<float, float>), dim3(blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((ln_bwd_dx_kernel<float, float>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(ln_bwd_param_kernel<float>, pgrid, dim3(256), 0, stream, p, rpb);
     }
     CHECK_LAUNCH();
     return MEBT_OK;

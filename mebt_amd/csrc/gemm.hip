@@ -27,8 +27,6 @@ namespace {
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-__device__ __forceinline__ int rc_swz(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
-
 // ------------------------------------------------------------------------------------------------
 // epilogue shared by both kernels.  v = 4 consecutive output columns n..n+3 of row m.
 // ------------------------------------------------------------------------------------------------
@@ -68,17 +66,23 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
 }
 
 // ------------------------------------------------------------------------------------------------
-// bf16 kernel
+// bf16 kernel, templated on the block tile (TBM x TBN in {128,64}) so that small outputs still fill
+// 256 CUs: 4 waves as 2x2, each wave (TBM/2) x (TBN/2) = (TBM/32) x (TBN/32) MFMA tiles of 16x16.
 // ------------------------------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
 
-template <bool KC>
+// swizzle of the 16-byte chunk index of an RC image row (k-row `krow`): conflict-free transposed reads
+template <int ROWS> __device__ __forceinline__ int rc_swizzle(int krow);
+template <> __device__ __forceinline__ int rc_swizzle<128>(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }          // 256-B rows
+template <> __device__ __forceinline__ int rc_swizzle<64>(int krow) { return (((krow >> 1) & 1) << 1) | (((krow >> 3) & 1) << 2); }   // 128-B rows
+
+template <bool KC, int ROWS>
 struct TileLoader {
-    // per-thread: 4 x 16-byte chunks of a [128 x 64] (KC) or [64 x 128] (RC) bf16 tile
-    uint32_t goff[4];
-    uint32_t loff[4];
-    bool ok[4];
+    // per-thread 16-byte chunks of a [ROWS x 64] (KC) or [64 x ROWS] (RC) bf16 tile
+    static constexpr int NCH = ROWS / 32;
+    uint32_t goff[NCH];
+    uint32_t loff[NCH];
+    bool ok[NCH];
     uint32_t step;   // byte advance per k-tile
     __amdgpu_buffer_rsrc_t rsrc;
 
@@ -88,37 +92,38 @@ struct TileLoader {
             rsrc = make_rsrc(b + (size_t)r0 * ld, (size_t)(rows - r0) * ld * 2);
             step = BK * 2;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NCH; ++i) {
                 const int id = tid + 256 * i, row = id >> 3, c = id & 7;
                 goff[i] = ((uint32_t)row * ld + 8 * c) * 2;
                 loff[i] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
                 ok[i] = true;
             }
         } else {
+            constexpr int CPR = ROWS / 8;          // chunks per k-row
             rsrc = make_rsrc(b, (size_t)K * ld * 2);
             step = (uint32_t)BK * ld * 2;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int id = tid + 256 * i, krow = id >> 4, c = id & 15;
+            for (int i = 0; i < NCH; ++i) {
+                const int id = tid + 256 * i, krow = id / CPR, c = id % CPR;
                 const int col = r0 + 8 * c;
                 ok[i] = col < rows;
                 goff[i] = ((uint32_t)krow * ld + col) * 2;
-                loff[i] = krow * 256 + ((c ^ rc_swz(krow)) << 4);
+                loff[i] = krow * (ROWS * 2) + ((c ^ rc_swizzle<ROWS>(krow)) << 4);
             }
         }
     }
-    __device__ __forceinline__ void load(u32x4 (&r)[4], int kt) const {
+    __device__ __forceinline__ void load(u32x4 (&r)[NCH], int kt) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = buf_load16(rsrc, ok[i] ? goff[i] + (uint32_t)kt * step : (uint32_t)MEBT_OOB);
+        for (int i = 0; i < NCH; ++i) r[i] = buf_load16(rsrc, ok[i] ? goff[i] + (uint32_t)kt * step : (uint32_t)MEBT_OOB);
     }
-    __device__ __forceinline__ void store(char* lds, const u32x4 (&r)[4]) const {
+    __device__ __forceinline__ void store(char* lds, const u32x4 (&r)[NCH]) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(lds + loff[i]) = r[i];
+        for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(lds + loff[i]) = r[i];
     }
 };
 
 // fragment of 16 rows x 32 k for v_mfma_f32_16x16x32_bf16: lane l holds row (l&15), k = 8*(l>>4)+j
-template <bool KC>
+template <bool KC, int ROWS>
 __device__ __forceinline__ bf16x8 read_frag(const char* tile, int blk16 /*16-row block in tile*/, int ks, int lane) {
     if (KC) {
         const int row = blk16 * 16 + (lane & 15);
@@ -127,24 +132,20 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int blk16 /*16-row
     } else {
         const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
         const int ch = 2 * blk16 + (pp >> 1);
-        s16x4 lo, hi;
-        {
-            const int krow = 32 * ks + 8 * g + q;
-            lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + krow * 256 + ((ch ^ rc_swz(krow)) << 4) + 8 * (pp & 1)));
-        }
-        {
-            const int krow = 32 * ks + 8 * g + 4 + q;
-            hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + krow * 256 + ((ch ^ rc_swz(krow)) << 4) + 8 * (pp & 1)));
-        }
+        const int k0 = 32 * ks + 8 * g + q, k1 = k0 + 4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + k0 * (ROWS * 2) + ((ch ^ rc_swizzle<ROWS>(k0)) << 4) + 8 * (pp & 1)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + k1 * (ROWS * 2) + ((ch ^ rc_swizzle<ROWS>(k1)) << 4) + 8 * (pp & 1)));
         typedef short s16x8 __attribute__((ext_vector_type(8)));
-        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     }
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int TBM, int TBN>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = (TBM + TBN) * BK * 2;
+    constexpr int TM = TBM / 32, TN = TBN / 32;         // MFMA tiles per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
         const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (bid / ntx) * BM, n0 = (bid % ntx) * BN;
+    const int m0 = (bid / ntx) * TBM, n0 = (bid % ntx) * TBN;
 
     const int nkt = (p.K + BK - 1) / BK;
     const int per = (nkt + gridDim.z - 1) / gridDim.z;
@@ -163,28 +164,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     const int kt1 = min(nkt, kt0 + per);
     if (kt0 >= kt1) return;
 
-    TileLoader<A_KC> la;
-    TileLoader<B_KC> lb;
+    TileLoader<A_KC, TBM> la;
+    TileLoader<B_KC, TBN> lb;
     la.init(p.A, p.M, p.K, p.lda, m0, tid);
     lb.init(p.B, p.N, p.K, p.ldb, n0, tid);
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 ra[4], rb[4];
+    u32x4 ra[TBM / 32], rb[TBN / 32];
     la.load(ra, kt0);
     lb.load(rb, kt0);
     la.store(smem, ra);
-    lb.store(smem + BM * BK * 2, rb);
+    lb.store(smem + TBM * BK * 2, rb);
     __syncthreads();
 
     for (int kt = kt0; kt < kt1; ++kt) {
         const int s = (kt - kt0) & 1;
-        const char* sA = smem + s * STAGE_BYTES;
-        const char* sB = sA + BM * BK * 2;
+        const char* sA = smem + s * STAGE;
+        const char* sB = sA + TBM * BK * 2;
         const bool more = kt + 1 < kt1;
         if (more) {
             la.load(ra, kt + 1);
@@ -192,21 +193,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bf[4];
+            bf16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = read_frag<A_KC>(sA, wm * 4 + i, ks, lane);
+            for (int i = 0; i < TM; ++i) af[i] = read_frag<A_KC, TBM>(sA, wm * TM + i, ks, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = read_frag<B_KC>(sB, wn * 4 + j, ks, lane);
+            for (int j = 0; j < TN; ++j) bf[j] = read_frag<B_KC, TBN>(sB, wn * TN + j, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            char* dA = smem + (s ^ 1) * STAGE_BYTES;
+            char* dA = smem + (s ^ 1) * STAGE;
             la.store(dA, ra);
-            lb.store(dA + BM * BK * 2, rb);
+            lb.store(dA + TBM * BK * 2, rb);
         }
         __syncthreads();
     }
@@ -214,11 +215,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     const bool atomic = gridDim.z > 1;
     const bool add_bias = blockIdx.z == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (TBM / 2) + i * 16 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (TBN / 2) + j * 16 + 4 * (lane >> 4);
             if (m < p.M && n < p.N) epilogue_store<bf16_t>(p, m, n, acc[i][j], add_bias, atomic);
         }
     }
@@ -360,7 +361,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 // host launcher
 // ------------------------------------------------------------------------------------------------
 static int g_gemm_force_split = 0;
+static int g_gemm_force_tile = 0;     // (BM << 8) | BN, benchmarking only
 void mebt_gemm_force_split(int s) { g_gemm_force_split = s; }
+extern "C" void mebt_debug_gemm_tile(int bm, int bn) { g_gemm_force_tile = (bm && bn) ? ((bm << 8) | bn) : 0; }
 
 int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     GemmParams p = p_in;
@@ -374,30 +377,43 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     if ((!p.a_kc && (p.M % 8)) || (!p.b_kc && (p.N % 8))) { mebt_set_error("gemm: row extent of an RC operand must be a multiple of 8"); return MEBT_ESHAPE; }
     if (dtype == MEBT_F32) p.c_f32 = 1;
     if (p.K <= 0) { mebt_set_error("gemm: K must be positive (empty reductions are handled by the caller)"); return MEBT_ESHAPE; }
-    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, 1);
-    int split = 1;
-    const bool can_split = p.c_f32 && p.epilogue == EPI_NONE && p.split_k != 1;
-    if (can_split) {
-        const int tiles = grid.x * grid.y;
-        const int nkt = (p.K + kq - 1) / kq;
-        if (p.split_k > 1) split = p.split_k;
-        else if (tiles < 192) split = min(max(1, 384 / tiles), max(1, nkt / 4));
-        if (g_gemm_force_split > 0) split = g_gemm_force_split;
-        split = max(1, min(split, nkt));
+    // tile selection (bf16): the largest tile that still yields ~one workgroup per CU
+    int tbm = 128, tbn = 128;
+    if (dtype == MEBT_BF16) {
+        auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+        if (g_gemm_force_tile) { tbm = g_gemm_force_tile >> 8; tbn = g_gemm_force_tile & 255; }
+        else if (wgs(128, 128) >= 700) { tbm = 128; tbn = 128; }      // measured on MI355X (tools/gemm_bench.py --variants)
+        else if (wgs(128, 128) >= 256) { tbm = 128; tbn = 64; }
+        else { tbm = 64; tbn = 64; }
     }
+    dim3 grid((p.N + tbn - 1) / tbn, (p.M + tbm - 1) / tbm, 1);
+    int split = 1;
+    const bool can_split = p.c_f32 && p.epilogue == EPI_NONE && p.split_k > 1;   // atomics split-K only on request
+    if (can_split) {
+        const int nkt = (p.K + kq - 1) / kq;
+        split = max(1, min(p.split_k, nkt));
+    }
+    if (g_gemm_force_split > 0 && p.c_f32 && p.epilogue == EPI_NONE) split = g_gemm_force_split;
     grid.z = split;
     if (split > 1 && !p.beta) {
         // split-K accumulates with fp32 atomics into a zeroed C
         MEBT_HIP_CHECK(hipMemset2DAsync(p.C, (size_t)p.ldc * 4, 0, (size_t)p.N * 4, p.M, stream));
     }
     if (dtype == MEBT_BF16) {
-        const size_t lds = 2 * STAGE_BYTES;
-#define LAUNCH_BF16(AK, BKC) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC>), grid, dim3(256), lds, stream, p)
+#define LAUNCH_T(AK, BKC, TM_, TN_) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC, TM_, TN_>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p)
+#define LAUNCH_BF16(AK, BKC)                                           \
+        do {                                                           \
+            if (tbm == 128 && tbn == 128) LAUNCH_T(AK, BKC, 128, 128); \
+            else if (tbm == 128 && tbn == 64) LAUNCH_T(AK, BKC, 128, 64); \
+            else if (tbm == 64 && tbn == 128) LAUNCH_T(AK, BKC, 64, 128); \
+            else LAUNCH_T(AK, BKC, 64, 64);                            \
+        } while (0)
         if (p.a_kc && p.b_kc) LAUNCH_BF16(true, true);
         else if (p.a_kc && !p.b_kc) LAUNCH_BF16(true, false);
         else if (!p.a_kc && !p.b_kc) LAUNCH_BF16(false, false);
         else LAUNCH_BF16(false, true);
 #undef LAUNCH_BF16
+#undef LAUNCH_T
     } else if (dtype == MEBT_F32) {
 #define LAUNCH_F32(AK, BKC) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC>), grid, dim3(256), 0, stream, p)
         if (p.a_kc && p.b_kc) LAUNCH_F32(true, true);
@@ -414,12 +430,14 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
 }
 
 int gemm_init_attributes() {
-    // the bf16 kernel uses 64 KiB of dynamic LDS
-#define SET_ATTR(AK, BKC) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AK, BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES))
+    // dynamic LDS up to 64 KiB
+#define SET_T(AK, BKC, TM_, TN_) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AK, BKC, TM_, TN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2))
+#define SET_ATTR(AK, BKC) do { SET_T(AK, BKC, 128, 128); SET_T(AK, BKC, 128, 64); SET_T(AK, BKC, 64, 128); SET_T(AK, BKC, 64, 64); } while (0)
     SET_ATTR(true, true);
     SET_ATTR(true, false);
     SET_ATTR(false, false);
     SET_ATTR(false, true);
 #undef SET_ATTR
+#undef SET_T
     return MEBT_OK;
 }

@@ -66,6 +66,23 @@ def test_gemm_layouts_exact_integers(dtype, a_kc, b_kc, M, N, K):
     assert torch.equal(out.double(), ref), (out.double() - ref).abs().max()
 
 
+@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 128), (64, 64)])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0), (0, 1)])
+def test_gemm_every_tile_variant(tile, a_kc, b_kc):
+    """each block-tile instantiation of the bf16 kernel, forced, on ragged integer operands"""
+    M, N, K = 328, 200, 192
+    Am, Bm = rnd(M, K, seed=11, ints=True), rnd(N, K, seed=12, ints=True)
+    ref = Am.double() @ Bm.double().t()
+    A = Am if a_kc else Am.t().contiguous()
+    B = Bm if b_kc else Bm.t().contiguous()
+    lib().mebt_debug_gemm_tile(*tile)
+    try:
+        out, _ = run_gemm(_lib.BF16, A, B, M, N, K, a_kc, b_kc, c_f32=1)
+    finally:
+        lib().mebt_debug_gemm_tile(0, 0)
+    assert torch.equal(out.double(), ref), (out.double() - ref).abs().max()
+
+
 @pytest.mark.parametrize("dtype", [_lib.BF16, _lib.F32])
 def test_gemm_ragged_reduction_and_splitk(dtype):
     """wgrad shape: reduction over an arbitrary token count (not a tile multiple), split-K atomics."""
