@@ -128,13 +128,16 @@ def main():
     ms = 1e3 * elapsed / args.steps
     value = world * n_targets * args.steps / elapsed
 
+    # dominant kernel family: MFMA GEMMs — time every launch of 2 more steps with HIP events on the
+    # launch stream (rank 0 records; every rank runs the steps because they contain collectives)
+    lib = _lib.load()
     if rank == 0:
-        # dominant kernel family: MFMA GEMMs — time every launch of 2 more steps with HIP events on the launch stream
-        lib = _lib.load()
         lib.mebt_profile_enable(1)
-        for _ in range(2):
-            loop.step(x, idx, t=args.t)
-        torch.cuda.synchronize()
+    for _ in range(2):
+        loop.step(x, idx, t=args.t)
+    sync()
+    roof = None
+    if rank == 0:
         import ctypes as C
         n, tms, fl = C.c_double(), C.c_double(), C.c_double()
         _lib.check(lib.mebt_profile_read(0, C.byref(n), C.byref(tms), C.byref(fl)))
@@ -143,11 +146,9 @@ def main():
         achieved = fl.value / (tms.value * 1e-3) / 1e12 if tms.value > 0 else 0.0
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None,
-                "kernel": "gemm_bf16_kernel (all layouts)" if args.dtype == "bf16" else "gemm_f32_kernel",
+                "kernel": "gemm_bf16_kernel (all layouts/tiles)" if args.dtype == "bf16" else "gemm_f32_kernel",
                 "launches_per_step": n.value / 2, "gemm_ms_per_step": round(tms.value / 2, 3),
                 "gemm_gflop_per_step": round(fl.value / 2 / 1e9, 1)}
-    if world > 1:
-        dist.barrier()
 
     if rank == 0:
         out = {"metric": "masked video tokens/sec/GPU (train step, 24L d=1024, 1024+256 tok)",
@@ -161,7 +162,7 @@ def main():
                           "global_batch": args.batch * world, "parallelism": f"dp{world}", "dropout": 0.0,
                           "loss": round(float(stats[4]), 4)},
                "roofline": roof}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             sd = {k: v.detach() for k, v in model.state_dict().items()}
             out["cpu_baseline"] = cpu_baseline(sd, cfg, args.t)
         print(json.dumps(out), flush=True)

@@ -1,0 +1,186 @@
+"""CPU tier: host logic of the product (config loading, MaskGen bookkeeping, module/param schema,
+optimizer groups, LR schedule), the C-ABI library's symbol table, and the data-parallel reducer over
+gloo with world_size 2.  No compute call into the HIP library happens here (no GPU)."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mebt_oracle as orc
+from tests.golden import make_golden as mg
+from tests.helpers import load_golden, product_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from mebt_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mebt_hip.h")).read()
+    declared = set(re.findall(r"\b(mebt_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    assert os.path.exists(_lib.LIB_PATH), "build the library first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(_lib.PROTOTYPES) == declared, set(_lib.PROTOTYPES) ^ declared      # the binding covers the whole header
+    bound = _lib.load()
+    assert bound.mebt_abi_version() == 1
+
+
+def test_product_fails_loudly_without_gpu():
+    """no CPU fallback: a forward on a CPU-resident model must raise, not silently compute"""
+    from tests.helpers import build_product
+    if torch.cuda.is_available():
+        pytest.skip("GPU visible")
+    model = build_product("micro", "f32", device="cpu")
+    x, idx = mg.inputs("micro", 2, "cpu")
+    with pytest.raises(RuntimeError):
+        model(x, None, t=0.5, indices=idx)
+
+
+def test_config_loader_and_instantiate(tmp_path):
+    from mebt_amd.config import load_config, AttrDict, instantiate_from_config
+    y = tmp_path / "c.yaml"
+    y.write_text("model:\n  target: mebt.transformer.Net2NetTransformer\n  params:\n    n_layer: 24\n    mode: [latent_enc, latent_self]\n"
+                 "  mask:\n    target: tats.mask_sampler.MaskGen\n    params: {schedule: linear, shape: [4, 16, 16], budget: 1024}\nexp:\n  exact_lr: 1.08e-5\n")
+    cfg = load_config([str(y)], ["model.params.n_layer=4", "exp.warmup_steps=10", "--data.batch_size=6"])
+    assert cfg.model.params.n_layer == 4 and cfg["exp"]["warmup_steps"] == 10 and cfg.data.batch_size == 6
+    assert "cosine_lr" not in cfg.exp and not hasattr(cfg.exp, "cosine_lr") and cfg.exp.get("x", 3) == 3
+    assert abs(cfg.exp.exact_lr - 1.08e-5) < 1e-12
+    ms = instantiate_from_config(cfg.model.mask)           # legacy 'tats.' prefix is rewritten (reference utils.py:6)
+    assert type(ms).__name__ == "MaskGen" and ms.schedule == "linear" and ms.budget == 1024
+    import utils as top_level_utils                       # the import path the reference's scripts use
+    assert top_level_utils.instantiate_from_config is instantiate_from_config
+
+
+def test_maskgen_divide_indices_matches_reference_golden():
+    from mebt.mask_sampler import MaskGen
+    g = load_golden("divide_indices")
+    idx = torch.from_numpy(g["indices"])
+    for k, (sched, num) in enumerate(zip(g["case_sched"], g["case_num"])):
+        t, T, start, training, budget, seq_len = num
+        ms = MaskGen(schedule=str(sched), shape=(4, 2, 2), budget=int(budget))
+        ms.train(bool(training))
+        oc, orr = np.random.choice, np.random.randint
+        np.random.choice = lambda a, p=None, _T=int(T): _T
+        np.random.randint = lambda lo, hi=None, _s=int(start): _s
+        try:
+            c, tg, sl = ms.divide_indices(idx, torch.tensor(float(t)), np.arange(4) + 1, np.ones(4))
+        finally:
+            np.random.choice, np.random.randint = oc, orr
+        assert sl == int(seq_len)
+        assert c.shape == g[f"k{k}_ctx"].shape and (c.numpy() == g[f"k{k}_ctx"]).all(), (k, sched, num)
+        assert tg.shape == g[f"k{k}_tgt"].shape and (tg.numpy() == g[f"k{k}_tgt"]).all(), (k, sched, num)
+    with pytest.raises(ValueError):
+        MaskGen(schedule="nope")
+
+
+def test_module_schema_optimizer_groups_and_lr_schedule():
+    from mebt.transformer import Net2NetTransformer
+    tcfg, vcfg, mcfg = product_config("micro")
+    model = Net2NetTransformer(tcfg, vcfg, mcfg, cond_stage_key="label")
+    shapes = orc.param_shapes(mg.oracle_cfg("micro"))
+    sd = model.state_dict()
+    assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
+    g = load_golden("train_micro")
+    model.learning_rate, model.weight_decay = 1e-3, 0.05
+    opt = model.configure_optimizers()
+    assert [len(grp["params"]) for grp in opt.param_groups] == list(g["group_sizes"])
+    assert [grp["weight_decay"] for grp in opt.param_groups] == list(g["group_wd"])
+    decay, emb, no_decay, pos = orc.decay_split({k: None for k in shapes})
+    named = {id(p): n for n, p in model.named_parameters()}
+    assert sorted(named[id(p)] for p in opt.param_groups[0]["params"]) == sorted("transformer." + n for n in decay)
+    # warm-up / cosine (reference transformer.py:665-678)
+    model.warmup_steps, model.cosine_lr, model.trainer.max_steps = 10, True, 110
+    for step in (0, 5, 9, 10, 60, 110):
+        model.trainer.global_step = step
+        assert abs(model.learning_rate * model.lr_scale() - orc.lr_at(step, 1e-3, 10, True, 110)) < 1e-12
+    # constructible from the shipped-style config with vtokens False (token grids only)
+    tcfg2, vcfg2, mcfg2 = product_config("micro", vtokens=False)
+    m2 = Net2NetTransformer(tcfg2, vcfg2, mcfg2)
+    with pytest.raises(NotImplementedError):
+        m2.encode_to_z(torch.zeros(1, 3, 4, 8, 8))
+    # unsupported routing fails loudly
+    tcfg3, vcfg3, mcfg3 = product_config("micro_maskgit")
+    m3 = Net2NetTransformer(tcfg3, vcfg3, mcfg3)
+    assert [b.mode for b in m3.transformer.blocks] == ["latent_enc", "latent_dec", "maskgit"]   # padding rule gpt.py:208-209
+
+
+def _dp_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mebt_amd.parallel import GradReducer
+        from mebt_amd.engine import flat_layout
+        torch.set_num_threads(1)
+        cfg = mg.oracle_cfg("micro")
+        P = orc.closed_form_params(cfg)
+        shapes = orc.param_shapes(cfg)
+        x, idx = mg.inputs("micro", 4, "dp")
+        per = 4 // world
+        xs, ids = x[rank * per:(rank + 1) * per], idx[rank * per:(rank + 1) * per]
+
+        class FakeNative:            # the reducer only touches the flat gradient buffers and the bucket ranges
+            n_layer, n_embd = cfg.n_layer, cfg.n_embd
+            def layer_w_range(self, hi, lo):
+                per_l = 12 * self.n_embd * self.n_embd
+                return lo * per_l, (hi + 1) * per_l
+            def head_w_range(self):
+                return self.n_layer * 12 * self.n_embd * self.n_embd, self.gW.numel()
+        nat = FakeNative()
+        Wn, Pn = flat_layout(cfg.n_layer)
+        st = orc.TrainState(P, lr=1e-3, weight_decay=0.05)
+        red = GradReducer(world_size=world)
+
+        def hook(grads):             # flatten exactly like the engine lays the buffers out, reduce bucket by bucket
+            nat.gW = torch.cat([grads["transformer." + n if not n.startswith("transformer.") else n].reshape(-1) for n in Wn])
+            nat.gP = torch.cat([grads[n].reshape(-1) for n in Pn])
+            red.bucket_ready(nat, "head", None, None)
+            hi = cfg.n_layer - 1
+            while hi >= 0:
+                lo = max(0, hi - 1)
+                red.bucket_ready(nat, "layers", hi, lo)
+                hi = lo - 1
+            red.bucket_ready(nat, "embed", None, None)
+            red.wait()
+            for flat, names in ((nat.gW, Wn), (nat.gP, Pn)):
+                off = 0
+                for n in names:
+                    k = int(np.prod(shapes[n]))
+                    grads[n] = (flat[off:off + k] * red.grad_scale).view(shapes[n]).clone()
+                    off += k
+        r = orc.train_step(st, cfg, xs, ids, 0.4, grad_hook=hook)
+        t = red.mean_scalars(torch.tensor([r["loss"]], dtype=torch.float64))
+        if rank == 0:
+            ret.put(({k: v.detach().numpy().copy() for k, v in st.P.items()}, float(t)))   # numpy: pickled by value
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_reducer_gloo_world2():
+    """2 ranks x half batch with bucketed all-reduce == 1 process x full batch (the DDP contract,
+    reference train_transformer.py:39-41): parameters after one AdamW step and the mean loss."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    P2, loss2 = ret.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = mg.oracle_cfg("micro")
+    x, idx = mg.inputs("micro", 4, "dp")
+    st = orc.TrainState(orc.closed_form_params(cfg), lr=1e-3, weight_decay=0.05)
+    r = orc.train_step(st, cfg, x, idx, 0.4)
+    assert abs(r["loss"] - loss2) < 1e-5 * abs(r["loss"])        # mean of per-rank mean losses == full-batch loss (equal shards)
+    for k, v in st.P.items():
+        assert np.allclose(v.detach().numpy(), P2[k], rtol=2e-4, atol=2e-6), k
