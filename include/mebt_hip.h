@@ -142,6 +142,10 @@ int mebt_op_cast_bf16(const float* src, void* dst, int64_t n, mebt_stream_t stre
  * then read {launches, total ms, total algorithmic flops} of the GEMM family. */
 int mebt_profile_enable(int32_t on);
 int mebt_profile_read(int32_t family, double* launches, double* total_ms, double* total_flops);
+/* Tests only: multiplies out[0..n) (fp32, n % 4 == 0) in place by the dropout keep-scales (0 or 1/(1-p))
+ * of site `site` under `seed` — fill `out` with ones to read the mask the kernels use.  Site ids: 16*layer
+ * + {0 attention probabilities, 1 proj output, 2 MLP output}; 0xFFFF0/1/2 = embedded sos/contexts/targets. */
+int mebt_debug_dropout_mask(uint64_t seed, uint32_t site, float p, int64_t n, float* out, mebt_stream_t stream);
 /* Benchmarking / tests only: force the bf16 GEMM block tile (bm, bn in {128, 64}); (0, 0) restores the heuristic. */
 void mebt_debug_gemm_tile(int32_t bm, int32_t bn);
 

@@ -71,10 +71,12 @@ __global__ __launch_bounds__(64) void attn_fwd_generic(const AttnParams p) {
         l *= alpha;
 #pragma unroll
         for (int e = 0; e < HD; ++e) o[e] *= alpha;
+        const uint64_t dbase = (((uint64_t)b * p.H + h) * p.NQ + qi) * p.NK + k0;
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
-            const float pj = __expf(s[j] - mn);   // exp(-inf) = 0 for padded keys
+            float pj = __expf(s[j] - mn);   // exp(-inf) = 0 for padded keys
             l += pj;
+            if (p.drop.thresh) pj *= drop_keep(p.drop, dbase + j);   // attn_drop acts on the normalised probabilities (gpt.py:135)
 #pragma unroll
             for (int e = 0; e < HD; ++e) o[e] += pj * sV[j][e];
         }
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_generic(const AttnParams p) {
 #pragma unroll
             for (int e = 0; e < HD; ++e) { s += q[e] * sK[j][e]; dp += go[e] * sV[j][e]; }
             const float pj = __expf(s * scale - lse);
+            if (p.drop.thresh) dp *= drop_keep(p.drop, (((uint64_t)b * p.H + h) * p.NQ + qi) * p.NK + k0 + j);
             const float ds = pj * (dp - delta) * scale;
 #pragma unroll
             for (int e = 0; e < HD; ++e) dq[e] += ds * sK[j][e];
@@ -165,9 +168,11 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_generic(const AttnParams p) {
 #pragma unroll
             for (int e = 0; e < HD; ++e) { s += sQ[i][e] * k[e]; dp += sG[i][e] * v[e]; }
             const float pi = __expf(s * scale - sL[i]);
-            const float ds = pi * (dp - sD[i]) * scale;
+            const float keep = p.drop.thresh ? drop_keep(p.drop, (((uint64_t)b * p.H + h) * p.NQ + q0 + i) * p.NK + ki) : 1.0f;
+            const float ds = pi * (dp * keep - sD[i]) * scale;
+            const float pd = pi * keep;
 #pragma unroll
-            for (int e = 0; e < HD; ++e) { dv[e] += pi * sG[i][e]; dk[e] += ds * sQ[i][e]; }
+            for (int e = 0; e < HD; ++e) { dv[e] += pd * sG[i][e]; dk[e] += ds * sQ[i][e]; }
         }
     }
     if (valid) {

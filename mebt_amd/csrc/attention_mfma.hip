@@ -162,6 +162,13 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnParams p) {
         ps = group_sum(ps);
         l = l * alpha + ps;
         m = mn;
+        if (p.drop.thresh) {   // attn_drop on the probabilities (gpt.py:135); the row sum above stays undropped
+            const uint64_t dbase = (((uint64_t)b * p.H + h) * p.NQ + q) * p.NK + k0;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kb][r] *= drop_keep(p.drop, dbase + 16 * kb + 4 * g + r);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] *= alpha;
         // O^T[e][q] += V^T[e][key] P^T[key][q]
@@ -249,7 +256,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const AttnParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + 16 * kb + 4 * g + r;
                 const float pr = key < p.NK ? exp2f(s[r] * c - lse2) : 0.f;
-                ds[kb][r] = pr * (dp[r] - delta) * 0.125f;
+                const float keep = p.drop.thresh ? drop_keep(p.drop, (((uint64_t)b * p.H + h) * p.NQ + q) * p.NK + key) : 1.0f;
+                ds[kb][r] = pr * (dp[r] * keep - delta) * 0.125f;
             }
         }
         // dQ^T[e][q] += K^T[e][key] dS^T[key][q]
@@ -338,8 +346,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = 16 * qb + 4 * g + r;
-                pr[qb][r] = exp2f(s[r] * c - cl[qi]);
-                ds[qb][r] = pr[qb][r] * (dp[r] - cd[qi]) * 0.125f;
+                const float pv = exp2f(s[r] * c - cl[qi]);
+                const float keep = p.drop.thresh ? drop_keep(p.drop, (((uint64_t)b * p.H + h) * p.NQ + t * TILE + qi) * p.NK + key) : 1.0f;
+                ds[qb][r] = pv * (dp[r] * keep - cd[qi]) * 0.125f;
+                pr[qb][r] = pv * keep;
             }
         }
         // dV^T[e][key] += dO^T[e][q] P[q][key];   dK^T[e][key] += Q^T[e][q] dS[q][key]

@@ -95,6 +95,7 @@ extern "C" int mebt_op_embed_fwd(int32_t dtype, const int64_t* x_ids, const int6
     EmbedParams p;
     p.x_ids = x_ids; p.ci = ci; p.ti = ti; p.tok_emb = tok_emb; p.pos_emb = pos_emb; p.mask_emb = mask_emb; p.sos_emb = sos_emb;
     p.sos = sos; p.ctx = ctx; p.tgt = tgt; p.B = B; p.N = N; p.NC = NC; p.NT = NT; p.NS = NS; p.d = d; p.vocab = vocab; p.block_size = block_size;
+    p.drop = make_drop(0, 0, 0.f);
     return launch_embed_fwd(p, dtype, S(stream));
 }
 

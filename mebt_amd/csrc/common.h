@@ -101,7 +101,14 @@ __device__ __forceinline__ uint32_t mix_hash(uint64_t seed, uint32_t site, uint6
     x ^= x >> 31;
     return (uint32_t)(x >> 32);
 }
-// keep-scale for dropout probability p: returns 0 (dropped) or 1/(1-p)
-__device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thresh, float inv_keep) {
-    return mix_hash(seed, site, idx) >= thresh ? inv_keep : 0.0f;
+// Dropout descriptor: element `idx` of site `site` is kept iff hash >= thresh (thresh = p * 2^32);
+// kept values are scaled by inv_keep = 1/(1-p).  thresh == 0 disables the site.
+struct DropCfg {
+    uint64_t seed;
+    uint32_t site;
+    uint32_t thresh;
+    float inv_keep;
+};
+__device__ __forceinline__ float drop_keep(const DropCfg& d, uint64_t idx) {
+    return mix_hash(d.seed, d.site, idx) >= d.thresh ? d.inv_keep : 0.0f;
 }

@@ -24,9 +24,12 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedParams p) {
     const float* src0;
     const float* src1 = nullptr;
     T* dst;
+    DropCfg dc = p.drop;
+    uint64_t ebase;
     if (r < p.NS) {
         src0 = p.sos_emb + (size_t)r * p.d;
         dst = reinterpret_cast<T*>(p.sos) + ((size_t)b * p.NS + r) * p.d;
+        dc.site = SITE_EMB_SOS; ebase = ((uint64_t)b * p.NS + r) * p.d;
     } else if (r < p.NS + p.NC) {
         const int i = r - p.NS;
         long pos = p.ci[(size_t)b * p.NC + i];
@@ -36,6 +39,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedParams p) {
         src0 = p.tok_emb + (size_t)tok * p.d;
         src1 = p.pos_emb + (size_t)pos * p.d;
         dst = reinterpret_cast<T*>(p.ctx) + ((size_t)b * p.NC + i) * p.d;
+        dc.site = SITE_EMB_CTX; ebase = ((uint64_t)b * p.NC + i) * p.d;
     } else {
         const int j = r - p.NS - p.NC;
         long pos = p.ti[(size_t)b * p.NT + j];
@@ -43,10 +47,15 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedParams p) {
         src0 = p.mask_emb;
         src1 = p.pos_emb + (size_t)pos * p.d;
         dst = reinterpret_cast<T*>(p.tgt) + ((size_t)b * p.NT + j) * p.d;
+        dc.site = SITE_EMB_TGT; ebase = ((uint64_t)b * p.NT + j) * p.d;
     }
     for (int e = lane * 4; e < p.d; e += 256) {
         f32x4 v = *reinterpret_cast<const f32x4*>(src0 + e);
         if (src1) v += *reinterpret_cast<const f32x4*>(src1 + e);
+        if (dc.thresh) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= drop_keep(dc, ebase + e + j);
+        }
         store4<T>(dst + e, v);
     }
 }
@@ -369,6 +378,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
     }
 }
 
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void apply_dropout_kernel(const TS* src, TD* dst, size_t n, DropCfg d) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        f32x4 v = load4<TS>(src + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= drop_keep(d, i + j);
+        store4<TD>(dst + i, v);
+    }
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16_t* dst, size_t n) {
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024)
         store4<bf16_t>(dst + i, *reinterpret_cast<const f32x4*>(src + i));
@@ -475,6 +494,18 @@ int launch_adamw(const AdamWParams& p, hipStream_t stream) {
     if (p.n % 4) { mebt_set_error("adamw: flat buffer length must be a multiple of 4"); return MEBT_ESHAPE; }
     const size_t blocks = (p.n / 4 + 255) / 256;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, p);
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+
+int launch_apply_dropout(const void* src, void* dst, size_t n, int src_f32, int dst_f32, const DropCfg& d, hipStream_t stream) {
+    if (n == 0) return MEBT_OK;
+    if (n % 4) { mebt_set_error("dropout: length must be a multiple of 4"); return MEBT_ESHAPE; }
+    const size_t blocks = (n / 4 + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 4096 ? blocks : 4096));
+    if (src_f32 && dst_f32) hipLaunchKernelGGL((apply_dropout_kernel<float, float>), grid, dim3(256), 0, stream, (const float*)src, (float*)dst, n, d);
+    else if (!src_f32 && !dst_f32) hipLaunchKernelGGL((apply_dropout_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, n, d);
+    else { mebt_set_error("dropout: mixed element types are not supported"); return MEBT_EDTYPE; }
     CHECK_LAUNCH();
     return MEBT_OK;
 }

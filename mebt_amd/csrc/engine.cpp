@@ -56,7 +56,9 @@ struct FwdCtx {
     void *dlogits = nullptr, *dhf = nullptr, *d4 = nullptr, *dh = nullptr, *dx = nullptr, *datt = nullptr, *dqkv_q = nullptr,
          *dqkv_k = nullptr, *dqn = nullptr, *dkn = nullptr;
     float* delta = nullptr;
+    void *dout_m = nullptr, *dx_m = nullptr;     // dropout-masked copies of dout / dx (backward operands)
     bool gS_defined = false, gT_defined = false, gC_defined = false;
+    bool drop_on = false; uint64_t drop_seed = 0;
 };
 
 }  // namespace
@@ -151,8 +153,9 @@ extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) 
             mebt_set_error("model_create: unsupported block mode (only latent_enc/latent_self/latent_dec/lt2l; 'maskgit' full attention is not built)");
             return MEBT_EINVAL;
         }
-    if (d.embd_pdrop != 0.f || d.resid_pdrop != 0.f || d.attn_pdrop != 0.f) {
-        // dropout is applied only when mebt_forward(training=1); kernels for it are not built yet
+    if (d.embd_pdrop < 0.f || d.embd_pdrop >= 1.f || d.resid_pdrop < 0.f || d.resid_pdrop >= 1.f || d.attn_pdrop < 0.f || d.attn_pdrop >= 1.f) {
+        mebt_set_error("model_create: dropout probabilities must be in [0, 1)");
+        return MEBT_EINVAL;
     }
     mebt_model* m = new mebt_model();
     m->d = d;
@@ -300,6 +303,7 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
         x.dqn = c.take(Mmax * d * e);
         x.dkn = c.take(Mmax * d * e);
         x.delta = (float*)c.take((int64_t)B * H * (NS + NT) * 4);
+        if (m->d.resid_pdrop > 0.f) { x.dout_m = c.take(Mmax * d * e); x.dx_m = c.take(Mmax * d * e); }
     }
 }
 
@@ -335,18 +339,14 @@ static int ln_fwd(const mebt_model* m, const void* x, void* y, int64_t gw, int64
 static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
                         const int64_t* x_ids, const int64_t* ci, const int64_t* ti, const float* const* embedded,
                         float* logits, int32_t training, uint64_t dropout_seed, mebt_stream_t stream) {
-    (void)dropout_seed;
     if (!m || !m->W) { mebt_set_error("forward: model not bound"); return MEBT_EINVAL; }
     if (B <= 0 || N <= 0 || NC < 0 || NT <= 0) { mebt_set_error("forward: need B > 0, N > 0, NC >= 0, NT > 0"); return MEBT_ESHAPE; }
     if (N > m->d.block_size) { mebt_set_error("forward: sequence longer than block_size (pos_emb rows)"); return MEBT_ESHAPE; }
     if (!ws || !logits) { mebt_set_error("forward: null pointer"); return MEBT_EINVAL; }
     if (!embedded && (!x_ids || !ti || (NC > 0 && !ci))) { mebt_set_error("forward: null pointer"); return MEBT_EINVAL; }
-    const bool want_dropout = (training & 2) != 0;
+    const bool drop_on = (training & 2) != 0 && (m->d.embd_pdrop > 0.f || m->d.resid_pdrop > 0.f || m->d.attn_pdrop > 0.f);
     training = training & 1;
-    if (want_dropout && (m->d.embd_pdrop > 0.f || m->d.resid_pdrop > 0.f || m->d.attn_pdrop > 0.f)) {
-        mebt_set_error("forward: dropout > 0 in training mode is not built yet (set *_pdrop = 0)");
-        return MEBT_EINVAL;
-    }
+    if (drop_on && embedded) { mebt_set_error("forward: dropout with caller-embedded inputs is not supported"); return MEBT_EINVAL; }
     FwdCtx& x = m->ctx;
     x.valid = false;
     Carve c{(char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), 0};
@@ -355,6 +355,8 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
     hipStream_t st = S(stream);
     const int d = m->d.n_embd, NS = m->d.n_latent, H = m->d.n_head, V = m->d.vocab, dt = m->d.dtype;
     x.ws = ws; x.B = B; x.N = N; x.NC = NC; x.NT = NT; x.x_ids = x_ids; x.ci = ci; x.ti = ti;
+    x.drop_on = drop_on; x.drop_seed = dropout_seed;
+    const float p_emb = drop_on ? m->d.embd_pdrop : 0.f, p_res = drop_on ? m->d.resid_pdrop : 0.f, p_att = drop_on ? m->d.attn_pdrop : 0.f;
 
     if (embedded) {   // GPT.forward boundary (gpt.py:234): the caller hands over fp32 embeddings
         void* dst[3] = {x.sos0, x.ctx, x.tgt0};
@@ -371,6 +373,7 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         ep.tok_emb = m->P + m->tok_emb; ep.pos_emb = m->P + m->pos_emb; ep.mask_emb = m->P + m->mask_emb; ep.sos_emb = m->P + m->sos_emb;
         ep.sos = x.sos0; ep.ctx = x.ctx; ep.tgt = x.tgt0;
         ep.B = B; ep.N = N; ep.NC = NC; ep.NT = NT; ep.NS = NS; ep.d = d; ep.vocab = V; ep.block_size = m->d.block_size;
+        ep.drop = make_drop(dropout_seed, 0, p_emb);       // gpt.py:238-240
         RC(launch_embed_fwd(ep, dt, st));
     }
 
@@ -416,11 +419,13 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         ap.q = a.q; ap.k = a.k; ap.v = a.v; ap.o = a.att; ap.lse = a.lse;
         ap.B = B; ap.H = H; ap.NQ = a.NQ; ap.NK = a.NK; ap.HD = d / H;
         ap.ldq = a.ldqkv_q; ap.ldk = a.ldqkv_k; ap.ldv = a.ldqkv_k; ap.ldo = d;
+        ap.drop = make_drop(dropout_seed, 16 * i + SITE_ATTN, p_att);   // gpt.py:135
         RC(launch_attn_fwd(ap, dt, st));
         // x = LN1(query) + proj(att)   — residual on the NORMALISED query (gpt.py:180,184)
         {
             GemmParams p = gp(a.att, m->Wop(o.wp), a.x, Mq, d, d, d, d, d, 1, 1);
             p.bias = m->P + o.bp; p.epilogue = EPI_RESID; p.aux = a.qn; p.ld_aux = d;
+            p.drop = make_drop(dropout_seed, 16 * i + SITE_PROJ, p_res);    // gpt.py:140
             RC(gemm(m, p, st));
         }
         // x = x + mlp(LN2(x))  (gpt.py:185, 150-155)
@@ -433,6 +438,7 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         {
             GemmParams p = gp(a.u, m->Wop(o.w2), a.out, Mq, d, 4 * d, 4 * d, 4 * d, d, 1, 1);
             p.bias = m->P + o.b2; p.epilogue = EPI_RESID; p.aux = a.x; p.ld_aux = d;
+            p.drop = make_drop(dropout_seed, 16 * i + SITE_MLP, p_res);     // gpt.py:154
             RC(gemm(m, p, st));
         }
         if (mode == MEBT_MODE_LATENT_DEC) Tv = a.out; else Sv = a.out;   // gpt.py:187-190
@@ -556,25 +562,38 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     const bool isdec = mode == MEBT_MODE_LATENT_DEC;
     if (isdec ? !x.gT_defined : !x.gS_defined) return MEBT_OK;   // the loss does not depend on this block
     const void* dout = isdec ? x.g_T : x.g_S;
-    // out = x + u W2^T + b2
-    RC(launch_colsum(dout, Mq, d, d, m->gP + o.b2, dt, st));
-    RC(wgrad(m, dout, d, a.u, 4 * d, o.w2, d, 4 * d, Mq, st));
-    RC(dgrad(m, dout, d, o.w2, x.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, st));   // d(pre) = (dout W2) * gelu'(pre)
+    const float p_res = x.drop_on ? m->d.resid_pdrop : 0.f, p_att = x.drop_on ? m->d.attn_pdrop : 0.f;
+    const int f32 = dt == MEBT_F32;
+    // out = x + dropout(u W2^T + b2): the branch gradient is dout * mask (the mask is recomputed, never stored)
+    const void* dmlp = dout;
+    if (p_res > 0.f) {
+        RC(launch_apply_dropout(dout, x.dout_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_MLP, p_res), st));
+        dmlp = x.dout_m;
+    }
+    RC(launch_colsum(dmlp, Mq, d, d, m->gP + o.b2, dt, st));
+    RC(wgrad(m, dmlp, d, a.u, 4 * d, o.w2, d, 4 * d, Mq, st));
+    RC(dgrad(m, dmlp, d, o.w2, x.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, st));   // d(pre) = (dmlp W2) * gelu'(pre)
     RC(launch_colsum(x.d4, Mq, 4 * d, 4 * d, m->gP + o.b1, dt, st));
     RC(wgrad(m, x.d4, 4 * d, a.hn, d, o.w1, 4 * d, d, Mq, st));
     RC(dgrad(m, x.d4, 4 * d, o.w1, x.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st));
     // dx = dout + LN2'(dh)
     RC(ln_bwd(m, a.x, x.dh, nullptr, o.ln2w, o.ln2b, a.mean2, a.rstd2, x.dx, 0, 0, Mq, 0, 0, 0, st, dout));
-    // x = qn + att Wp^T + bp
-    RC(launch_colsum(x.dx, Mq, d, d, m->gP + o.bp, dt, st));
-    RC(wgrad(m, x.dx, d, a.att, d, o.wp, d, d, Mq, st));
-    RC(dgrad(m, x.dx, d, o.wp, x.datt, Mq, d, d, EPI_NONE, nullptr, 0, st));
+    // x = qn + dropout(att Wp^T + bp)
+    const void* dproj = x.dx;
+    if (p_res > 0.f) {
+        RC(launch_apply_dropout(x.dx, x.dx_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_PROJ, p_res), st));
+        dproj = x.dx_m;
+    }
+    RC(launch_colsum(dproj, Mq, d, d, m->gP + o.bp, dt, st));
+    RC(wgrad(m, dproj, d, a.att, d, o.wp, d, d, Mq, st));
+    RC(dgrad(m, dproj, d, o.wp, x.datt, Mq, d, d, EPI_NONE, nullptr, 0, st));
     // attention backward
     AttnParams ap;
     memset(&ap, 0, sizeof(ap));
     ap.q = a.q; ap.k = a.k; ap.v = a.v; ap.o = a.att; ap.lse = a.lse; ap.B = B; ap.H = H; ap.NQ = a.NQ; ap.NK = a.NK; ap.HD = d / H;
     ap.ldq = a.ldqkv_q; ap.ldk = a.ldqkv_k; ap.ldv = a.ldqkv_k; ap.ldo = d;
     ap.d_o = x.datt; ap.lddo = d; ap.delta = x.delta;
+    ap.drop = make_drop(x.drop_seed, 16 * i + SITE_ATTN, p_att);
     const int esz = m->esz();
     if (mode == MEBT_MODE_LATENT_SELF) {
         ap.dq = x.dqkv_q; ap.dk = (char*)x.dqkv_q + (size_t)d * esz; ap.dv = (char*)x.dqkv_q + (size_t)2 * d * esz;
@@ -625,6 +644,14 @@ extern "C" int mebt_backward_layers(mebt_model* m, void* ws, int32_t layer_hi, i
 extern "C" int mebt_backward_embed(mebt_model* m, void* ws, mebt_stream_t stream) {
     if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("backward: no training-mode forward on this workspace"); return MEBT_EINVAL; }
     FwdCtx& x = m->ctx;
+    if (x.drop_on && m->d.embd_pdrop > 0.f) {   // embd dropout (gpt.py:238-240): gradients pass through the same masks
+        const int f32 = m->d.dtype == MEBT_F32;
+        const size_t dd = m->d.n_embd;
+        const float pe = m->d.embd_pdrop;
+        if (x.gS_defined) RC(launch_apply_dropout(x.g_S, x.g_S, (size_t)x.B * m->d.n_latent * dd, f32, f32, make_drop(x.drop_seed, SITE_EMB_SOS, pe), S(stream)));
+        if (x.gT_defined) RC(launch_apply_dropout(x.g_T, x.g_T, (size_t)x.B * x.NT * dd, f32, f32, make_drop(x.drop_seed, SITE_EMB_TGT, pe), S(stream)));
+        if (x.gC_defined) RC(launch_apply_dropout(x.g_C, x.g_C, (size_t)x.B * x.NC * dd, 1, 1, make_drop(x.drop_seed, SITE_EMB_CTX, pe), S(stream)));
+    }
     EmbedBwdParams p;
     p.x_ids = x.x_ids; p.ci = x.ci; p.ti = x.ti;
     p.g_ctx = x.g_C; p.g_tgt = x.g_T; p.g_sos = x.g_S;
@@ -669,4 +696,10 @@ extern "C" int mebt_adamw_step(mebt_model* m, float* mW, float* vW, float* mP, f
     const int64_t tail_n = (m->tok_live ? m->n_p : m->tok_emb) - m->lnf_w;
     RC(run(m->P, m->gP, mP, vP, nullptr, m->lnf_w, tail_n, 0.f));
     return MEBT_OK;
+}
+
+// Test hook: the keep-scale (0 or 1/(1-p)) of elements 0..n-1 of a dropout site, as the kernels compute it.
+extern "C" int mebt_debug_dropout_mask(uint64_t seed, uint32_t site, float p, int64_t n, float* out, mebt_stream_t stream) {
+    if (!out || n < 0 || (n % 4)) { mebt_set_error("dropout_mask: bad arguments (n must be a multiple of 4)"); return MEBT_EINVAL; }
+    return launch_apply_dropout(out, out, (size_t)n, 1, 1, make_drop(seed, site, p), S(stream));
 }

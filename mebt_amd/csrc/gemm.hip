@@ -49,6 +49,11 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
         for (int j = 0; j < 4; ++j) g[j] = gelu_f(v[j]);
         store4<TA>(reinterpret_cast<TA*>(p.C2) + ci, g);
     } else if (p.epilogue == EPI_RESID) {
+        if (p.drop.thresh) {
+            const uint64_t e0 = (uint64_t)m * p.N + n;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= drop_keep(p.drop, e0 + j);
+        }
         v += load4<TA>(reinterpret_cast<const TA*>(p.aux) + (size_t)m * p.ld_aux + n);
     } else if (p.epilogue == EPI_GELU_BWD) {
         const f32x4 x = load4<TA>(reinterpret_cast<const TA*>(p.aux) + (size_t)m * p.ld_aux + n);

@@ -2,8 +2,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "common.h"
 
 enum { MEBT_F32 = 0, MEBT_BF16 = 1 };
+// dropout site ids (per layer: 16*layer + k)
+enum { SITE_ATTN = 0, SITE_PROJ = 1, SITE_MLP = 2, SITE_EMB_SOS = 0xFFFF0, SITE_EMB_CTX = 0xFFFF1, SITE_EMB_TGT = 0xFFFF2 };
+static inline DropCfg make_drop(uint64_t seed, uint32_t site, float p) {
+    DropCfg d;
+    d.seed = seed; d.site = site;
+    d.thresh = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
+    d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    return d;
+}
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_GELU_BWD = 3 };
 
 // C[M,N] = sum_k A(m,k) B(n,k) (+bias) (+epilogue).  *_kc = 1: operand stored [rows][K];
@@ -22,6 +32,7 @@ struct GemmParams {
     int c_f32;           // bf16 kernel: write fp32 C (weight gradients, logits)
     int beta;            // fp32 C only: C += result
     int split_k;         // 0 = heuristic, 1 = never, >1 = forced (fp32 C, EPI_NONE only)
+    DropCfg drop;        // EPI_RESID: C = dropout(acc + bias) + aux   (resid_pdrop, reference gpt.py:140,154)
 };
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 int gemm_init_attributes();
@@ -40,6 +51,7 @@ struct EmbedParams {
     void* ctx;              // [B,NC,d] T
     void* tgt;              // [B,NT,d] T
     int B, N, NC, NT, NS, d, vocab, block_size;
+    DropCfg drop;           // embd_pdrop on sos / contexts / targets (reference gpt.py:238-240); site = SITE_EMB_*
 };
 int launch_embed_fwd(const EmbedParams& p, int dtype, hipStream_t stream);
 struct EmbedBwdParams {
@@ -72,6 +84,9 @@ struct LnBwdParams {
     int rows, d; int seg, seg_stride, seg_off;
 };
 int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream);
+
+// dst[i] = src[i] * keep(site, i)  (dropout mask re-applied in backward); TS/TD chosen by flags
+int launch_apply_dropout(const void* src, void* dst, size_t n, int src_f32, int dst_f32, const DropCfg& d, hipStream_t stream);
 
 // out[n] += sum_m X[m,n]   (bias gradients, mask_emb / sos_emb gradients)
 int launch_colsum(const void* X, int M, int N, int ldx, float* out, int dtype, hipStream_t stream);
@@ -115,6 +130,7 @@ struct AttnParams {
     int B, H, NQ, NK, HD; int ldq, ldk, ldv, ldo;
     // backward
     const void* d_o; void* dq; void* dk; void* dv; float* delta; int lddo, lddq, lddk, lddv;
+    DropCfg drop;        // attn_pdrop on the probabilities (reference gpt.py:135); element = ((b*H+h)*NQ+q)*NK+key
 };
 int launch_attn_fwd(const AttnParams& p, int dtype, hipStream_t stream);
 int launch_attn_bwd(const AttnParams& p, int dtype, hipStream_t stream);

@@ -15,8 +15,12 @@ Conventions
 * `P` is a dict {state-dict name -> fp32 tensor} using the reference's parameter names
   (SURVEY.md §A.2), e.g. `transformer.blocks.3.attn.query.weight`.
 * All randomness is injected: `t`, permutations and Exp(1)/Normal noise are explicit arguments.
-* Dropout sites (gpt.py:113-114,135,140,154,211,238-241) are the identity here: the oracle states
-  the p=0 / eval-mode function, which is what every parity test compares.
+* Dropout sites (gpt.py:113-114,135,140,154,211,238-241) are the identity by default: the oracle
+  states the p=0 / eval-mode function, which is what every parity test compares.  To check that the
+  HIP kernels put their (counter-based) masks at the reference's sites, the network functions take
+  an optional `drop(kind, layer, tensor)` hook that multiplies explicit keep-scale masks in at
+  exactly those sites: kind in {"emb_sos","emb_ctx","emb_tgt"} (gpt.py:238-240), "attn" (:135),
+  "proj" (:140), "mlp" (:154).
 
 Every function cites the reference lines it restates (paths relative to /root/reference).
 """
@@ -163,7 +167,11 @@ def layer_norm(x, w, b):
     return F.layer_norm(x, (x.shape[-1],), w, b, LN_EPS)
 
 
-def cross_attention(P, pre, n_head, query, key):
+def _nodrop(kind, layer, t):
+    return t
+
+
+def cross_attention(P, pre, n_head, query, key, drop=_nodrop, layer=0):
     """mebt/modules/gpt.py:119-141 (attn_bias == 0.0 at every call site, transformer.py:281,321)."""
     B, NQ, C = query.shape
     NK = key.shape[1]
@@ -174,11 +182,12 @@ def cross_attention(P, pre, n_head, query, key):
     v = lin("value", key).view(B, NK, n_head, hd).transpose(1, 2)        # :128
     att = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(hd))              # :131 scale after the product
     att = F.softmax(att, dim=-1)                                         # :134
+    att = drop("attn", layer, att)                                       # :135 attn_drop
     y = (att @ v).transpose(1, 2).contiguous().view(B, NQ, C)            # :136-137
-    return lin("proj", y)                                                # :140
+    return drop("proj", layer, lin("proj", y))                           # :140 resid_drop(proj(y))
 
 
-def block(P, i, mode, n_head, sos, ctx, tgt):
+def block(P, i, mode, n_head, sos, ctx, tgt, drop=_nodrop):
     """mebt/modules/gpt.py:159-195.  Quirks kept: the residual is taken on the
     *normalised* query (:180,:184) and ln1 is shared by query and key (:180-181)."""
     pre = f"transformer.blocks.{i}."
@@ -198,11 +207,11 @@ def block(P, i, mode, n_head, sos, ctx, tgt):
         raise AssertionError(mode)
     qn = layer_norm(query, P[pre + "ln1.weight"], P[pre + "ln1.bias"])   # :180
     kn = layer_norm(key, P[pre + "ln1.weight"], P[pre + "ln1.bias"])     # :181
-    x = qn + cross_attention(P, pre, n_head, qn, kn)                     # :182,:184
+    x = qn + cross_attention(P, pre, n_head, qn, kn, drop, i)            # :182,:184
     h = layer_norm(x, P[pre + "ln2.weight"], P[pre + "ln2.bias"])
     h = F.linear(h, P[pre + "mlp.0.weight"], P[pre + "mlp.0.bias"])
     h = F.gelu(h)                                                        # exact erf GELU, :152
-    x = x + F.linear(h, P[pre + "mlp.2.weight"], P[pre + "mlp.2.bias"])  # :185
+    x = x + drop("mlp", i, F.linear(h, P[pre + "mlp.2.weight"], P[pre + "mlp.2.bias"]))  # :185, :154
     if mode in ("latent_enc", "latent_self", "lt2l"):
         sos = x                                                          # :187-188
     elif mode == "latent_dec":
@@ -212,11 +221,12 @@ def block(P, i, mode, n_head, sos, ctx, tgt):
     return sos, ctx, tgt
 
 
-def gpt_forward(P, cfg, sos, ctx, tgt, return_hidden=False):
-    """mebt/modules/gpt.py:234-253 (dropouts are identity; head has no bias :217)."""
+def gpt_forward(P, cfg, sos, ctx, tgt, return_hidden=False, drop=_nodrop):
+    """mebt/modules/gpt.py:234-253 (dropouts are identity unless `drop` is given; head has no bias :217)."""
     hidden = []
+    sos, ctx, tgt = drop("emb_sos", 0, sos), drop("emb_ctx", 0, ctx), drop("emb_tgt", 0, tgt)   # :238-240
     for i, mode in enumerate(cfg.mode):
-        sos, ctx, tgt = block(P, i, mode, cfg.n_head, sos, ctx, tgt)
+        sos, ctx, tgt = block(P, i, mode, cfg.n_head, sos, ctx, tgt, drop)
         if return_hidden:
             hidden.append((sos, tgt))
     x = layer_norm(tgt, P["transformer.ln_f.weight"], P["transformer.ln_f.bias"])   # :247
@@ -224,15 +234,15 @@ def gpt_forward(P, cfg, sos, ctx, tgt, return_hidden=False):
     return (logits, hidden) if return_hidden else logits
 
 
-def reconstruct_mask(P, cfg, x_ids, ci, ti):
+def reconstruct_mask(P, cfg, x_ids, ci, ti, drop=_nodrop):
     """mebt/transformer.py:288-324: logits [B,NT,V] for caller-supplied index sets."""
     B = x_ids.shape[0]
     x_ids = x_ids.reshape(B, -1)
     sos, ctx, tgt = embed(P, cfg, x_ids, ci, ti)
-    return gpt_forward(P, cfg, sos, ctx, tgt)
+    return gpt_forward(P, cfg, sos, ctx, tgt, drop=drop)
 
 
-def forward(P, cfg, x, indices, t, training=True, window=None):
+def forward(P, cfg, x, indices, t, training=True, window=None, drop=_nodrop):
     """mebt/transformer.py:216-286 with the RNG draw `t` (:228) explicit.
     Returns (logits, z_targets, NT_weight, seq_len)."""
     B = x.shape[0]
@@ -240,7 +250,7 @@ def forward(P, cfg, x, indices, t, training=True, window=None):
     ci, ti, seq_len = divide_indices(indices, t, cfg, training, window)   # :251
     z_tgt = torch.gather(x_ids, 1, ti)                                    # :256
     NT_weight = float(seq_len - ci.shape[1])                              # :258-259 (before budget cut)
-    logits = reconstruct_mask(P, cfg, x_ids, ci, ti)
+    logits = reconstruct_mask(P, cfg, x_ids, ci, ti, drop)
     return logits, z_tgt, NT_weight, seq_len
 
 

@@ -1,0 +1,82 @@
+"""Dropout (embd / attn / resid, reference gpt.py:135,140,154,238-240) in the HIP engine.
+The masks are counter-based and recomputed in backward; the test reads the exact masks the kernels
+use (mebt_debug_dropout_mask), injects them into the oracle at the reference's dropout sites and
+compares logits and every parameter gradient.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mebt_amd import _lib
+from mebt_amd.engine import NativeModel
+from oracle import mebt_oracle as orc
+from tests.golden import make_golden as mg
+
+DEV = "cuda"
+SITE = {"attn": 0, "proj": 1, "mlp": 2, "emb_sos": 0xFFFF0, "emb_ctx": 0xFFFF1, "emb_tgt": 0xFFFF2}
+
+
+def kernel_mask(seed, site, p, shape):
+    n = int(np.prod(shape))
+    pad = (-n) % 4
+    out = torch.ones(n + pad, device=DEV)
+    _lib.check(_lib.load().mebt_debug_dropout_mask(seed, site, p, n + pad, _lib.ptr(out), _lib.cur_stream()))
+    torch.cuda.synchronize()
+    return out[:n].cpu().view(*shape)
+
+
+@pytest.mark.parametrize("name,dtype", [("micro", "f32"), ("c1", "f32"), ("c1", "bf16")])
+def test_dropout_sites_forward_backward(name, dtype):
+    cfg = mg.oracle_cfg(name)
+    p_emb, p_res, p_att = 0.1, 0.2, 0.15
+    nm = NativeModel(cfg.n_layer, cfg.n_head, cfg.n_embd, cfg.vocab_size, cfg.sos_emb, cfg.block_size, cfg.mode,
+                     dtype=dtype, embd_pdrop=p_emb, resid_pdrop=p_res, attn_pdrop=p_att)
+    nm.allocate(DEV)
+    P = orc.closed_form_params(cfg)
+    views = nm.views(orc.param_shapes(cfg))
+    with torch.no_grad():
+        for k, v in P.items():
+            views[k].copy_(v)
+    nm.sync_lowp(force=True)
+    B, seed, t = 2, 0x1234ABCD5, 0.45
+    x, idx = mg.inputs(name, B, "drop")
+    ci, ti, seq_len = orc.divide_indices(idx, t, cfg, True)
+    pk = {"attn": p_att, "proj": p_res, "mlp": p_res, "emb_sos": p_emb, "emb_ctx": p_emb, "emb_tgt": p_emb}
+    seen = []
+
+    def drop(kind, layer, tensor):
+        site = SITE[kind] if kind.startswith("emb") else 16 * layer + SITE[kind]
+        m = kernel_mask(seed, site, pk[kind], tuple(tensor.shape))
+        seen.append((kind, layer, float((m > 0).float().mean())))
+        return tensor * m
+
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    logits, z_t, ntw, _ = orc.forward(Pg, cfg, x, idx, t, training=True, drop=drop)
+    _, _, loss = orc.loss_and_acc(logits, z_t, ntw, seq_len, cfg)
+    loss.backward()
+    # keep rates are what p says
+    for kind, layer, keep in seen:
+        assert abs(keep - (1 - pk[kind])) < 0.06, (kind, layer, keep)
+
+    lg = nm.forward(x.reshape(B, -1).to(DEV), ci.to(DEV), ti.to(DEV), training=True, dropout_seed=seed)
+    tol = 1e-4 if dtype == "f32" else 8e-2
+    assert (lg.cpu() - logits.detach()).abs().max().item() < tol
+    scale = 1.0 / (B * seq_len * (ntw / seq_len))
+    nm.backward(lg, scale)
+    torch.cuda.synchronize()
+    gv = nm.views(orc.param_shapes(cfg), grads=True)
+    lim = 2e-3 if dtype == "f32" else 1e-1
+    bad = []
+    for k, pr in Pg.items():
+        ref = pr.grad if pr.grad is not None else torch.zeros_like(pr)
+        err = (gv[k].cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-5)   # key.bias: exactly-zero gradient
+        if not err < lim:
+            bad.append((k, round(err, 5)))
+    assert not bad, bad[:20]
+    # a different seed gives a different network function; eval mode ignores dropout entirely
+    lg2 = nm.forward(x.reshape(B, -1).to(DEV), ci.to(DEV), ti.to(DEV), training=True, dropout_seed=seed + 1)
+    assert (lg2 - lg).abs().max().item() > 1e-3
+    lg3 = nm.forward(x.reshape(B, -1).to(DEV), ci.to(DEV), ti.to(DEV), training=False)
+    ref_eval = orc.reconstruct_mask(P, cfg, x, ci, ti)
+    assert (lg3.cpu() - ref_eval).abs().max().item() < tol
