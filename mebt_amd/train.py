@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Training launcher — counterpart of reference train_transformer.py for the token-grid path.
+
+  python -m mebt_amd.train --base cfg.yaml [more.yaml] [key.sub=value ...] --max_steps 1000
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m mebt_amd.train --base cfg.yaml
+
+Same config handling as the reference (YAML list + dot-list overrides, train_transformer.py:25-27;
+exp.{exact_lr,warmup_steps,weight_decay,cosine_lr}, :45-66), seed 42 on every rank (:11) so all ranks
+draw the same `t`; one process per GPU with RCCL all-reduce (DDP, :39-41).  Data: token grids from a
+`.npy` file ([num,T,H,W] int64, `--tokens`) or synthetic grids; every item carries
+`indices = randperm(T*H*W)` like the reference datasets (mebt/data.py:85,233,413,471).
+Checkpoints use the Lightning layout {'state_dict','hyper_parameters','global_step'}.
+"""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--base", nargs="*", default=[], metavar="base_config.yaml")
+    ap.add_argument("--preset", default=None, help="sky_16f | ucf_128f | tiny (instead of --base)")
+    ap.add_argument("--tokens", default=None, help=".npy with [num,T,H,W] int64 token grids")
+    ap.add_argument("--max_steps", type=int, default=100)
+    ap.add_argument("--log_every", type=int, default=10)
+    ap.add_argument("--ckpt_every", type=int, default=0)
+    ap.add_argument("--default_root_dir", default="runs")
+    ap.add_argument("--ckpt_path", default=None)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    args, unknown = ap.parse_known_args()
+
+    import torch.distributed as dist
+    from . import presets
+    from .config import load_config
+    from .parallel import GradReducer
+    from .trainer import TrainLoop
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    random.seed(42); np.random.seed(42); torch.manual_seed(42)          # pl.seed_everything(42)
+
+    cfg = getattr(presets, args.preset)() if args.preset else load_config(args.base, unknown)
+    cfg.model.params.class_cond_dim = None
+    model = presets.build_model(cfg, compute_dtype=args.dtype)
+    if args.ckpt_path:
+        sd = torch.load(args.ckpt_path, map_location="cpu", weights_only=False)
+        model.load_state_dict(sd["state_dict"], strict=False)
+    model = model.to(dev).train()
+    loop = TrainLoop(model, GradReducer(world_size=world), max_steps=args.max_steps)
+
+    shape = list(cfg.model.mask.params.shape)
+    N = int(np.prod(shape))
+    B = cfg.data.batch_size
+    g = torch.Generator().manual_seed(1234 + rank)
+    data = torch.from_numpy(np.load(args.tokens)).long() if args.tokens else None
+    t0 = time.perf_counter()
+    for step in range(args.max_steps):
+        if data is not None:
+            sel = torch.randint(0, data.shape[0], (B,), generator=g)
+            x = data[sel]
+        else:
+            x = torch.randint(0, 16384, (B, *shape), generator=g)
+        idx = torch.stack([torch.randperm(N, generator=g) for _ in range(B)])
+        stats = loop.step(x.to(dev, non_blocking=True), idx.to(dev, non_blocking=True))
+        if (step + 1) % args.log_every == 0:
+            s = loop.reducer.mean_scalars(torch.stack([stats[4], 100 * stats[1] / stats[3], 100 * stats[2] / stats[3]])).cpu()
+            if rank == 0:
+                dt = time.perf_counter() - t0
+                print(f"step {step + 1}: train/loss {s[0]:.4f} acc1 {s[1]:.2f} acc5 {s[2]:.2f} "
+                      f"lr {model.learning_rate * model.lr_scale():.3e}  {dt / (step + 1) * 1e3:.1f} ms/step", flush=True)
+        if args.ckpt_every and rank == 0 and (step + 1) % args.ckpt_every == 0:
+            os.makedirs(args.default_root_dir, exist_ok=True)
+            torch.save({"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                        "hyper_parameters": model.hparams, "global_step": step + 1},
+                       os.path.join(args.default_root_dir, f"step={step + 1}.ckpt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
