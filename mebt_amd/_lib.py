@@ -53,7 +53,9 @@ PROTOTYPES = {
     "mebt_op_next_mask": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "mebt_op_cast_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "mebt_debug_dropout_mask": (c_i32, [C.c_uint64, C.c_uint32, c_f32, c_i64, c_vp, c_vp]),
+    "mebt_debug_side_stream": (None, [c_vp, c_i32]),
     "mebt_debug_gemm_tile": (None, [c_i32, c_i32]),
+    "mebt_debug_gemm_variant": (None, [c_i32]),
     "mebt_profile_enable": (c_i32, [c_i32]),
     "mebt_profile_read": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

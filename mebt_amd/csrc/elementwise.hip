@@ -435,7 +435,8 @@ int launch_ln_fwd(const LnFwdParams& p, int dtype, hipStream_t stream) {
     return MEBT_OK;
 }
 
-int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream) {
+int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream, hipStream_t param_stream, bool use_param_stream) {
+    hipStream_t ps = use_param_stream ? param_stream : stream;
     if (p.rows <= 0) return MEBT_OK;
     if (p.d % 4 || p.d > 256 * LN_MAXC) { mebt_set_error("layernorm: d must be a multiple of 4 and <= 2048"); return MEBT_ESHAPE; }
     const dim3 grid((p.rows + 3) / 4);
@@ -447,10 +448,10 @@ int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream) {
     if (dtype == MEBT_BF16) {
         if (p.dx_f32) hipLaunchKernelGGL((ln_bwd_dx_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((ln_bwd_dx_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(ln_bwd_param_kernel<bf16_t>, pgrid, dim3(256), 0, stream, p, rpb);
+        hipLaunchKernelGGL(ln_bwd_param_kernel<bf16_t>, pgrid, dim3(256), 0, ps, p, rpb);
     } else {
         hipLaunchKernelGGL((ln_bwd_dx_kernel<float, float>), grid, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(ln_bwd_param_kernel<float>, pgrid, dim3(256), 0, stream, p, rpb);
+        hipLaunchKernelGGL(ln_bwd_param_kernel<float>, pgrid, dim3(256), 0, ps, p, rpb);
     }
     CHECK_LAUNCH();
     return MEBT_OK;

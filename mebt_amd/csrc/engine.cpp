@@ -53,10 +53,11 @@ struct FwdCtx {
     bool loss_done = false;
     // backward scratch
     void *g_S = nullptr, *g_T = nullptr; float* g_C = nullptr;
-    void *dlogits = nullptr, *dhf = nullptr, *d4 = nullptr, *dh = nullptr, *dx = nullptr, *datt = nullptr, *dqkv_q = nullptr,
-         *dqkv_k = nullptr, *dqn = nullptr, *dkn = nullptr;
+    void *dlogits = nullptr, *dhf = nullptr, *datt = nullptr;
+    // per-layer backward scratch, two sets (layer parity): the side stream may still read layer i's
+    // operands while the main stream already produces layer i-1's
+    struct Scratch { void *d4, *dh, *dx, *dqkv_q, *dqkv_k, *dqn, *dkn, *dout_m, *dx_m; } sc[2];
     float* delta = nullptr;
-    void *dout_m = nullptr, *dx_m = nullptr;     // dropout-masked copies of dout / dx (backward operands)
     bool gS_defined = false, gT_defined = false, gC_defined = false;
     bool drop_on = false; uint64_t drop_seed = 0;
 };
@@ -73,6 +74,12 @@ struct mebt_model {
     std::vector<char> live;   // per layer: does the loss depend on this block?
     bool tok_live = false;
     FwdCtx ctx;
+    // side stream for work that nothing on the critical path waits for (weight / bias / LN-affine
+    // gradients, the key-side projection in forward): the per-layer kernels at batch 6 are too small
+    // to fill 256 CUs one at a time.  Fork/join with events only (graph-capturable).
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_e1 = nullptr, ev_layer[2] = {nullptr, nullptr}, ev_join = nullptr;
+    bool use_side = true;
     int esz() const { return d.dtype == MEBT_BF16 ? 2 : 4; }
     // weight operand for GEMMs (bf16 mirror in bf16 mode)
     const void* Wop(int64_t off) const {
@@ -81,6 +88,8 @@ struct mebt_model {
 };
 
 static hipStream_t S(mebt_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static int fork_side(mebt_model* m, hipStream_t st);
+static int join_side(mebt_model* m, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------------
 // profiling of the GEMM family with HIP events on the launch stream
@@ -190,11 +199,26 @@ extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) 
     }
     int rc = gemm_init_attributes();
     if (rc) { delete m; return rc; }
+    if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) { m->side = nullptr; m->use_side = false; (void)hipGetLastError(); }
+    if (m->side) {
+        hipEvent_t* evs[] = {&m->ev_fork, &m->ev_e1, &m->ev_layer[0], &m->ev_layer[1], &m->ev_join};
+        for (hipEvent_t* e : evs) MEBT_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
     *out = m;
     return MEBT_OK;
 }
 
-extern "C" void mebt_model_destroy(mebt_model* m) { delete m; }
+extern "C" void mebt_model_destroy(mebt_model* m) {
+    if (!m) return;
+    if (m->side) {
+        (void)hipStreamSynchronize(m->side);
+        hipEvent_t evs[] = {m->ev_fork, m->ev_e1, m->ev_layer[0], m->ev_layer[1], m->ev_join};
+        for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(m->side);
+    }
+    delete m;
+}
+extern "C" void mebt_debug_side_stream(mebt_model* m, int32_t on) { if (m) m->use_side = on != 0 && m->side != nullptr; }
 
 extern "C" int mebt_model_param_counts(const mebt_model* m, int64_t* n_w, int64_t* n_p) {
     if (!m) { mebt_set_error("null model"); return MEBT_EINVAL; }
@@ -294,16 +318,20 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
         x.g_C = (float*)c.take((int64_t)B * NC * d * 4);
         x.dlogits = c.take(R * V * e);
         x.dhf = c.take(R * d * e);
-        x.d4 = c.take(Mmax * 4 * d * e);
-        x.dh = c.take(Mmax * d * e);
-        x.dx = c.take(Mmax * d * e);
         x.datt = c.take(Mmax * d * e);
-        x.dqkv_q = c.take(Mmax * 3 * d * e);
-        x.dqkv_k = c.take(Mmax * 2 * d * e);
-        x.dqn = c.take(Mmax * d * e);
-        x.dkn = c.take(Mmax * d * e);
+        for (int k = 0; k < 2; ++k) {
+            FwdCtx::Scratch& s = x.sc[k];
+            s.d4 = c.take(Mmax * 4 * d * e);
+            s.dh = c.take(Mmax * d * e);
+            s.dx = c.take(Mmax * d * e);
+            s.dqkv_q = c.take(Mmax * 3 * d * e);
+            s.dqkv_k = c.take(Mmax * 2 * d * e);
+            s.dqn = c.take(Mmax * d * e);
+            s.dkn = c.take(Mmax * d * e);
+            s.dout_m = s.dx_m = nullptr;
+            if (m->d.resid_pdrop > 0.f) { s.dout_m = c.take(Mmax * d * e); s.dx_m = c.take(Mmax * d * e); }
+        }
         x.delta = (float*)c.take((int64_t)B * H * (NS + NT) * 4);
-        if (m->d.resid_pdrop > 0.f) { x.dout_m = c.take(Mmax * d * e); x.dx_m = c.take(Mmax * d * e); }
     }
 }
 
@@ -385,34 +413,39 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         const int mode = m->d.modes[i];
         const int Mq = B * a.NQ, Mk = B * a.NK;
         a.q_in = (mode == MEBT_MODE_LATENT_DEC) ? Tv : Sv;
-        // LN1 on query and key with the SAME parameters (gpt.py:180-181)
+        // LN1 on query and key with the SAME parameters (gpt.py:180-181), then the projections
+        // (gpt.py:126-128); the three [d,d] weights are adjacent in W so QKV / KV fuse.  The key side
+        // (LN + KV projection) is independent of the query side: it runs on the side stream.
+        const bool side = m->use_side && mode != MEBT_MODE_LATENT_SELF && Mk > 0;
+        hipStream_t sk = side ? m->side : st;
+        if (side) RC(fork_side(m, st));
         RC(ln_fwd(m, a.q_in, a.qn, o.ln1w, o.ln1b, a.mean1q, a.rstd1q, Mq, 0, 0, 0, st));
         if (mode == MEBT_MODE_LATENT_ENC) {
             a.k_in = x.ctx;
-            RC(ln_fwd(m, x.ctx, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, Mk, 0, 0, 0, st));
+            RC(ln_fwd(m, x.ctx, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, Mk, 0, 0, 0, sk));
         } else if (mode == MEBT_MODE_LATENT_DEC) {
             a.k_in = Sv;
-            RC(ln_fwd(m, Sv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, Mk, 0, 0, 0, st));
+            RC(ln_fwd(m, Sv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, Mk, 0, 0, 0, sk));
         } else if (mode == MEBT_MODE_LT2L) {   // key = LN1(cat[sos, targets]) (gpt.py:175,181)
             a.k_in = Tv;
-            RC(ln_fwd(m, Sv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, B * NS, NS, NS + NT, 0, st));
-            RC(ln_fwd(m, Tv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, B * NT, NT, NS + NT, NS, st));
+            RC(ln_fwd(m, Sv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, B * NS, NS, NS + NT, 0, sk));
+            RC(ln_fwd(m, Tv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, B * NT, NT, NS + NT, NS, sk));
         } else {
             a.k_in = nullptr;
         }
-        // projections (gpt.py:126-128); the three [d,d] weights are adjacent in W so QKV / KV fuse
         if (mode == MEBT_MODE_LATENT_SELF) {
             GemmParams p = gp(a.qn, m->Wop(o.wq), a.q, Mq, 3 * d, d, d, d, 3 * d, 1, 1);
             p.bias = m->P + o.bq;
             RC(gemm(m, p, st));
         } else {
+            GemmParams pk = gp(a.kn, m->Wop(o.wk), a.k, Mk, 2 * d, d, d, d, 2 * d, 1, 1);
+            pk.bias = m->P + o.bk;
+            RC(gemm(m, pk, sk));
             GemmParams p = gp(a.qn, m->Wop(o.wq), a.q, Mq, d, d, d, d, d, 1, 1);
             p.bias = m->P + o.bq;
             RC(gemm(m, p, st));
-            GemmParams pk = gp(a.kn, m->Wop(o.wk), a.k, Mk, 2 * d, d, d, d, 2 * d, 1, 1);
-            pk.bias = m->P + o.bk;
-            RC(gemm(m, pk, st));
         }
+        if (side) { MEBT_HIP_CHECK(hipEventRecord(m->ev_join, m->side)); MEBT_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0)); }
         // softmax(q k^T / sqrt(hd)) v  (gpt.py:131-137)
         AttnParams ap;
         memset(&ap, 0, sizeof(ap));
@@ -509,11 +542,19 @@ static int dgrad(const mebt_model* m, const void* dY, int ld_dy, int64_t w_off, 
 static int head_backward_common(mebt_model* m, hipStream_t st) {
     FwdCtx& x = m->ctx;
     const int d = m->d.n_embd, V = m->d.vocab, R = x.B * x.NT;
-    RC(wgrad(m, x.dlogits, V, x.hf, d, m->head_w, V, d, R, st));
+    hipStream_t sd = st;
+    if (m->use_side) {
+        RC(fork_side(m, st));
+        sd = m->side;
+        // a fresh backward: mark both scratch sets free
+        MEBT_HIP_CHECK(hipEventRecord(m->ev_layer[0], sd));
+        MEBT_HIP_CHECK(hipEventRecord(m->ev_layer[1], sd));
+    }
+    RC(wgrad(m, x.dlogits, V, x.hf, d, m->head_w, V, d, R, sd));
     RC(dgrad(m, x.dlogits, V, m->head_w, x.dhf, R, V, d, EPI_NONE, nullptr, 0, st));
     RC(ln_bwd(m, x.T_final, x.dhf, nullptr, m->lnf_w, m->lnf_b, x.meanf, x.rstdf, x.g_T, 0, 0, R, 0, 0, 0, st));
     x.gT_defined = true; x.gS_defined = false; x.gC_defined = false;
-    return MEBT_OK;
+    return join_side(m, st);
 }
 
 static int backward_prologue(mebt_model* m, void* ws, hipStream_t st) {
@@ -553,6 +594,20 @@ extern "C" int mebt_backward_head_dlogits(mebt_model* m, void* ws, const float* 
     return head_backward_common(m, st);
 }
 
+// fork: the side stream continues after everything enqueued on `st` so far
+static int fork_side(mebt_model* m, hipStream_t st) {
+    MEBT_HIP_CHECK(hipEventRecord(m->ev_fork, st));
+    MEBT_HIP_CHECK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    return MEBT_OK;
+}
+// join: `st` continues after everything enqueued on the side stream so far
+static int join_side(mebt_model* m, hipStream_t st) {
+    if (!m->use_side) return MEBT_OK;
+    MEBT_HIP_CHECK(hipEventRecord(m->ev_join, m->side));
+    MEBT_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0));
+    return MEBT_OK;
+}
+
 static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     FwdCtx& x = m->ctx;
     LayerAct& a = x.L[i];
@@ -561,31 +616,47 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     const int Mq = B * a.NQ, Mk = B * a.NK;
     const bool isdec = mode == MEBT_MODE_LATENT_DEC;
     if (isdec ? !x.gT_defined : !x.gS_defined) return MEBT_OK;   // the loss does not depend on this block
+    const bool side = m->use_side;
+    hipStream_t sd = side ? m->side : st;          // leaves (dW, db, dLN-affine) go here
+    FwdCtx::Scratch& sc = x.sc[i & 1];
+    if (side) MEBT_HIP_CHECK(hipStreamWaitEvent(st, m->ev_layer[i & 1], 0));   // side readers of this scratch set (layer i+2) are done
     const void* dout = isdec ? x.g_T : x.g_S;
     const float p_res = x.drop_on ? m->d.resid_pdrop : 0.f, p_att = x.drop_on ? m->d.attn_pdrop : 0.f;
     const int f32 = dt == MEBT_F32;
     // out = x + dropout(u W2^T + b2): the branch gradient is dout * mask (the mask is recomputed, never stored)
     const void* dmlp = dout;
     if (p_res > 0.f) {
-        RC(launch_apply_dropout(dout, x.dout_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_MLP, p_res), st));
-        dmlp = x.dout_m;
+        RC(launch_apply_dropout(dout, sc.dout_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_MLP, p_res), st));
+        dmlp = sc.dout_m;
     }
-    RC(launch_colsum(dmlp, Mq, d, d, m->gP + o.b2, dt, st));
-    RC(wgrad(m, dmlp, d, a.u, 4 * d, o.w2, d, 4 * d, Mq, st));
-    RC(dgrad(m, dmlp, d, o.w2, x.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, st));   // d(pre) = (dmlp W2) * gelu'(pre)
-    RC(launch_colsum(x.d4, Mq, 4 * d, 4 * d, m->gP + o.b1, dt, st));
-    RC(wgrad(m, x.d4, 4 * d, a.hn, d, o.w1, 4 * d, d, Mq, st));
-    RC(dgrad(m, x.d4, 4 * d, o.w1, x.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st));
-    // dx = dout + LN2'(dh)
-    RC(ln_bwd(m, a.x, x.dh, nullptr, o.ln2w, o.ln2b, a.mean2, a.rstd2, x.dx, 0, 0, Mq, 0, 0, 0, st, dout));
+    if (side) RC(fork_side(m, st));
+    RC(launch_colsum(dmlp, Mq, d, d, m->gP + o.b2, dt, sd));
+    RC(wgrad(m, dmlp, d, a.u, 4 * d, o.w2, d, 4 * d, Mq, sd));
+    if (side) MEBT_HIP_CHECK(hipEventRecord(m->ev_e1, sd));       // last side readers of `dout` itself
+    RC(dgrad(m, dmlp, d, o.w2, sc.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, st));   // d(pre) = (dmlp W2) * gelu'(pre)
+    if (side) RC(fork_side(m, st));
+    RC(launch_colsum(sc.d4, Mq, 4 * d, 4 * d, m->gP + o.b1, dt, sd));
+    RC(wgrad(m, sc.d4, 4 * d, a.hn, d, o.w1, 4 * d, d, Mq, sd));
+    RC(dgrad(m, sc.d4, 4 * d, o.w1, sc.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st));
+    // dx = dout + LN2'(dh)   (dgamma/dbeta reduction on the side stream)
+    if (side) RC(fork_side(m, st));
+    {
+        LnBwdParams p;
+        p.x = a.x; p.dy = sc.dh; p.dy2 = nullptr; p.dx_add = dout; p.gamma = m->P + o.ln2w; p.mean = a.mean2; p.rstd = a.rstd2;
+        p.dx = sc.dx; p.dx_f32 = 0; p.dx_accumulate = 0; p.dgamma = m->gP + o.ln2w; p.dbeta = m->gP + o.ln2b;
+        p.rows = Mq; p.d = d; p.seg = 0; p.seg_stride = 0; p.seg_off = 0;
+        if (dt == MEBT_F32) p.dx_f32 = 1;
+        RC(launch_ln_bwd(p, dt, st, sd, true));
+    }
     // x = qn + dropout(att Wp^T + bp)
-    const void* dproj = x.dx;
+    const void* dproj = sc.dx;
     if (p_res > 0.f) {
-        RC(launch_apply_dropout(x.dx, x.dx_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_PROJ, p_res), st));
-        dproj = x.dx_m;
+        RC(launch_apply_dropout(sc.dx, sc.dx_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_PROJ, p_res), st));
+        dproj = sc.dx_m;
     }
-    RC(launch_colsum(dproj, Mq, d, d, m->gP + o.bp, dt, st));
-    RC(wgrad(m, dproj, d, a.att, d, o.wp, d, d, Mq, st));
+    if (side) RC(fork_side(m, st));
+    RC(launch_colsum(dproj, Mq, d, d, m->gP + o.bp, dt, sd));
+    RC(wgrad(m, dproj, d, a.att, d, o.wp, d, d, Mq, sd));
     RC(dgrad(m, dproj, d, o.wp, x.datt, Mq, d, d, EPI_NONE, nullptr, 0, st));
     // attention backward
     AttnParams ap;
@@ -596,41 +667,54 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     ap.drop = make_drop(x.drop_seed, 16 * i + SITE_ATTN, p_att);
     const int esz = m->esz();
     if (mode == MEBT_MODE_LATENT_SELF) {
-        ap.dq = x.dqkv_q; ap.dk = (char*)x.dqkv_q + (size_t)d * esz; ap.dv = (char*)x.dqkv_q + (size_t)2 * d * esz;
+        ap.dq = sc.dqkv_q; ap.dk = (char*)sc.dqkv_q + (size_t)d * esz; ap.dv = (char*)sc.dqkv_q + (size_t)2 * d * esz;
         ap.lddq = ap.lddk = ap.lddv = 3 * d;
     } else {
-        ap.dq = x.dqkv_q; ap.lddq = d;
-        ap.dk = x.dqkv_k; ap.dv = (char*)x.dqkv_k + (size_t)d * esz; ap.lddk = ap.lddv = 2 * d;
+        ap.dq = sc.dqkv_q; ap.lddq = d;
+        ap.dk = sc.dqkv_k; ap.dv = (char*)sc.dqkv_k + (size_t)d * esz; ap.lddk = ap.lddv = 2 * d;
     }
     RC(launch_attn_bwd(ap, dt, st));
+    if (side) RC(fork_side(m, st));
+    // LN1 backward helper: dx on the main stream (after the side readers of `dout` when it overwrites it), affine grads on the side stream
+    auto ln1 = [&](const void* xin, const void* dy, const void* dy2, const float* mean, const float* rstd, void* dxp, int dx_f32, int acc,
+                   int rows, int seg, int seg_stride, int seg_off) -> int {
+        LnBwdParams p;
+        p.x = xin; p.dy = dy; p.dy2 = dy2; p.dx_add = nullptr; p.gamma = m->P + o.ln1w; p.mean = mean; p.rstd = rstd;
+        p.dx = dxp; p.dx_f32 = dx_f32 || dt == MEBT_F32; p.dx_accumulate = acc; p.dgamma = m->gP + o.ln1w; p.dbeta = m->gP + o.ln1b;
+        p.rows = rows; p.d = d; p.seg = seg; p.seg_stride = seg_stride; p.seg_off = seg_off;
+        return launch_ln_bwd(p, dt, st, sd, true);
+    };
     if (mode == MEBT_MODE_LATENT_SELF) {
-        RC(launch_colsum(x.dqkv_q, Mq, 3 * d, 3 * d, m->gP + o.bq, dt, st));
-        RC(wgrad(m, x.dqkv_q, 3 * d, a.qn, d, o.wq, 3 * d, d, Mq, st));
-        RC(dgrad(m, x.dqkv_q, 3 * d, o.wq, x.dqn, Mq, 3 * d, d, EPI_RESID, x.dx, d, st));   // + dx (residual on qn)
-        RC(ln_bwd(m, a.q_in, x.dqn, nullptr, o.ln1w, o.ln1b, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0, st));
-        return MEBT_OK;
-    }
-    RC(launch_colsum(x.dqkv_q, Mq, d, d, m->gP + o.bq, dt, st));
-    RC(wgrad(m, x.dqkv_q, d, a.qn, d, o.wq, d, d, Mq, st));
-    RC(dgrad(m, x.dqkv_q, d, o.wq, x.dqn, Mq, d, d, EPI_RESID, x.dx, d, st));
-    RC(launch_colsum(x.dqkv_k, Mk, 2 * d, 2 * d, m->gP + o.bk, dt, st));
-    RC(wgrad(m, x.dqkv_k, 2 * d, a.kn, d, o.wk, 2 * d, d, Mk, st));
-    if (Mk > 0) RC(dgrad(m, x.dqkv_k, 2 * d, o.wk, x.dkn, Mk, 2 * d, d, EPI_NONE, nullptr, 0, st));
-    if (mode == MEBT_MODE_LATENT_ENC) {
-        RC(ln_bwd(m, a.q_in, x.dqn, nullptr, o.ln1w, o.ln1b, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0, st));
-        if (Mk > 0) {   // contexts feed every latent_enc block: accumulate in fp32
-            RC(ln_bwd(m, x.ctx, x.dkn, nullptr, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, x.g_C, 1, x.gC_defined ? 1 : 0, Mk, 0, 0, 0, st));
-            x.gC_defined = true;
+        RC(launch_colsum(sc.dqkv_q, Mq, 3 * d, 3 * d, m->gP + o.bq, dt, sd));
+        RC(wgrad(m, sc.dqkv_q, 3 * d, a.qn, d, o.wq, 3 * d, d, Mq, sd));
+        RC(dgrad(m, sc.dqkv_q, 3 * d, o.wq, sc.dqn, Mq, 3 * d, d, EPI_RESID, sc.dx, d, st));   // + dx (residual on qn)
+        if (side) { RC(fork_side(m, st)); MEBT_HIP_CHECK(hipStreamWaitEvent(st, m->ev_e1, 0)); }
+        RC(ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0));
+    } else {
+        RC(launch_colsum(sc.dqkv_q, Mq, d, d, m->gP + o.bq, dt, sd));
+        RC(wgrad(m, sc.dqkv_q, d, a.qn, d, o.wq, d, d, Mq, sd));
+        RC(launch_colsum(sc.dqkv_k, Mk, 2 * d, 2 * d, m->gP + o.bk, dt, sd));
+        RC(wgrad(m, sc.dqkv_k, 2 * d, a.kn, d, o.wk, 2 * d, d, Mk, sd));
+        RC(dgrad(m, sc.dqkv_q, d, o.wq, sc.dqn, Mq, d, d, EPI_RESID, sc.dx, d, st));
+        if (Mk > 0) RC(dgrad(m, sc.dqkv_k, 2 * d, o.wk, sc.dkn, Mk, 2 * d, d, EPI_NONE, nullptr, 0, st));
+        if (side) { RC(fork_side(m, st)); MEBT_HIP_CHECK(hipStreamWaitEvent(st, m->ev_e1, 0)); }
+        if (mode == MEBT_MODE_LATENT_ENC) {
+            RC(ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0));
+            if (Mk > 0) {   // contexts feed every latent_enc block: accumulate in fp32
+                RC(ln1(x.ctx, sc.dkn, nullptr, a.mean1k, a.rstd1k, x.g_C, 1, x.gC_defined ? 1 : 0, Mk, 0, 0, 0));
+                x.gC_defined = true;
+            }
+        } else if (mode == MEBT_MODE_LATENT_DEC) {
+            RC(ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_T, 0, 0, Mq, 0, 0, 0));
+            RC(ln1(a.k_in, sc.dkn, nullptr, a.mean1k, a.rstd1k, x.g_S, 0, x.gS_defined ? 1 : 0, Mk, 0, 0, 0));
+            x.gS_defined = true;
+        } else {   // lt2l: key rows [0,NS) come from the same LN as the query
+            RC(ln1(a.q_in, sc.dkn, sc.dqn, a.mean1k, a.rstd1k, x.g_S, 0, 0, B * NS, NS, NS + NT, 0));
+            RC(ln1(a.k_in, sc.dkn, nullptr, a.mean1k, a.rstd1k, x.g_T, 0, x.gT_defined ? 1 : 0, B * NT, NT, NS + NT, NS));
+            x.gT_defined = true;
         }
-    } else if (mode == MEBT_MODE_LATENT_DEC) {
-        RC(ln_bwd(m, a.q_in, x.dqn, nullptr, o.ln1w, o.ln1b, a.mean1q, a.rstd1q, x.g_T, 0, 0, Mq, 0, 0, 0, st));
-        RC(ln_bwd(m, a.k_in, x.dkn, nullptr, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, x.g_S, 0, x.gS_defined ? 1 : 0, Mk, 0, 0, 0, st));
-        x.gS_defined = true;
-    } else {   // lt2l: key rows [0,NS) come from the same LN as the query
-        RC(ln_bwd(m, a.q_in, x.dkn, x.dqn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, x.g_S, 0, 0, B * NS, NS, NS + NT, 0, st));
-        RC(ln_bwd(m, a.k_in, x.dkn, nullptr, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, x.g_T, 0, x.gT_defined ? 1 : 0, B * NT, NT, NS + NT, NS, st));
-        x.gT_defined = true;
     }
+    if (side) MEBT_HIP_CHECK(hipEventRecord(m->ev_layer[i & 1], sd));   // this scratch set is free once the side stream gets here
     return MEBT_OK;
 }
 
@@ -638,7 +722,7 @@ extern "C" int mebt_backward_layers(mebt_model* m, void* ws, int32_t layer_hi, i
     if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("backward: no training-mode forward on this workspace"); return MEBT_EINVAL; }
     if (layer_hi >= m->d.n_layer || layer_lo < 0 || layer_lo > layer_hi) { mebt_set_error("backward_layers: bad layer range"); return MEBT_EINVAL; }
     for (int i = layer_hi; i >= layer_lo; --i) RC(backward_layer(m, i, S(stream)));
-    return MEBT_OK;
+    return join_side(m, S(stream));          // the caller may all-reduce these gradients next
 }
 
 extern "C" int mebt_backward_embed(mebt_model* m, void* ws, mebt_stream_t stream) {

@@ -43,10 +43,11 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
         for (int j = 0; j < 4; ++j) atomicAdd(c + j, v[j]);
         return;
     }
+    constexpr bool fast = sizeof(TA) == 2;       // bf16 kernel: cheap erf (1.5e-7 abs error)
     if (p.epilogue == EPI_GELU) {
         f32x4 g;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = gelu_f(v[j]);
+        for (int j = 0; j < 4; ++j) g[j] = fast ? gelu_fast(v[j]) : gelu_f(v[j]);
         store4<TA>(reinterpret_cast<TA*>(p.C2) + ci, g);
     } else if (p.epilogue == EPI_RESID) {
         if (p.drop.thresh) {
@@ -58,7 +59,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
     } else if (p.epilogue == EPI_GELU_BWD) {
         const f32x4 x = load4<TA>(reinterpret_cast<const TA*>(p.aux) + (size_t)m * p.ld_aux + n);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_f(x[j]);
+        for (int j = 0; j < 4; ++j) v[j] *= fast ? gelu_grad_fast(x[j]) : gelu_grad_f(x[j]);
     }
     if (!p.C) return;                   // EPI_GELU in inference: only gelu(C) is needed
     if (p.c_f32) {
@@ -231,6 +232,148 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 kernel, direct-to-LDS variant: the same LDS images and fragment reads, but the tiles are
+// written by `buffer_load_dwordx4 ... lds` (no VGPR round trip, no ds_write) into a 3-stage ring, so
+// two k-tiles are in flight behind the one being multiplied.  An LDS-DMA wave-instruction writes 1 KiB
+// at a wave-uniform base + lane*16, so the XOR swizzle moves to the per-lane SOURCE address.  Waits
+// are counted (`s_waitcnt vmcnt(N)`, never 0 inside the loop) and the barrier is the raw s_barrier
+// (a __syncthreads() would drain the DMA queue).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+template <bool KC, int ROWS>
+struct DmaLoader {
+    static constexpr int NP = ROWS / 32;      // 1-KiB pieces per wave per tile (ROWS/8 pieces, 4 waves)
+    uint32_t goff[NP];
+    bool ok[NP];
+    uint32_t step;
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ void init(const void* base, int rows, int K, int ld, int r0, int wave, int lane) {
+        const bf16_t* b = reinterpret_cast<const bf16_t*>(base);
+        if (KC) {                             // piece = 8 rows x 128 B
+            rsrc = make_rsrc(b + (size_t)r0 * ld, (size_t)(rows - r0) * ld * 2);
+            step = BK * 2;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int row = 8 * (4 * i + wave) + (lane >> 3), slot = lane & 7;
+                const int c = slot ^ ((row >> 1) & 7);
+                goff[i] = ((uint32_t)row * ld + 8 * c) * 2;
+                ok[i] = true;
+            }
+        } else {
+            constexpr int CPR = ROWS / 8;     // 16-byte slots per k-row; piece = 64/CPR k-rows
+            constexpr int RPP = 64 / CPR;
+            rsrc = make_rsrc(b, (size_t)K * ld * 2);
+            step = (uint32_t)BK * ld * 2;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int krow = RPP * (4 * i + wave) + lane / CPR, slot = lane % CPR;
+                const int c = slot ^ rc_swizzle<ROWS>(krow);
+                const int col = r0 + 8 * c;
+                ok[i] = col < rows;
+                goff[i] = ((uint32_t)krow * ld + col) * 2;
+            }
+        }
+    }
+    // tile kt -> LDS image at `tile` (wave-uniform pointer)
+    __device__ __forceinline__ void issue(char* tile, int kt, int wave) const {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const uint32_t off = ok[i] ? goff[i] + (uint32_t)kt * step : (uint32_t)MEBT_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(tile + (4 * i + wave) * 1024), 16, off, 0, 0, 0);
+        }
+    }
+};
+
+template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
+__global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = (TBM + TBN) * BK * 2;
+    constexpr int TM = TBM / 32, TN = TBN / 32;
+    constexpr int LPT = (TBM + TBN) / 32;              // DMA instructions per wave per tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntx = gridDim.x, nty = gridDim.y, ntiles = ntx * nty;
+    int bid = blockIdx.y * ntx + blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / ntx) * TBM, n0 = (bid % ntx) * TBN;
+    const int nkt = (p.K + BK - 1) / BK;
+    const int per = (nkt + gridDim.z - 1) / gridDim.z;
+    const int kt0 = blockIdx.z * per;
+    const int kt1 = min(nkt, kt0 + per);
+    if (kt0 >= kt1) return;
+    const int nk = kt1 - kt0;
+
+    DmaLoader<A_KC, TBM> la;
+    DmaLoader<B_KC, TBN> lb;
+    la.init(p.A, p.M, p.K, p.lda, m0, wave, lane);
+    lb.init(p.B, p.N, p.K, p.ldb, n0, wave, lane);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int AHEAD = NSTAGE - 1;                   // tiles in flight behind the one being multiplied
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        if (a < nk) {
+            la.issue(smem + a * STAGE, kt0 + a, wave);
+            lb.issue(smem + a * STAGE + TBM * BK * 2, kt0 + a, wave);
+        }
+    int st = 0;                                          // ring slot of tile t
+    for (int t = 0; t < nk; ++t) {
+        // tile t must have landed; the (up to AHEAD-1) younger tiles may stay in flight.  vmcnt takes an
+        // immediate, so the tail (fewer younger tiles than AHEAD-1) selects the count by a uniform switch.
+        const int younger = min(AHEAD - 1, nk - 1 - t);
+        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + AHEAD < nk) {                            // slot of tile t-1: every wave is past its reads
+            int s2 = st + AHEAD; if (s2 >= NSTAGE) s2 -= NSTAGE;
+            la.issue(smem + s2 * STAGE, kt0 + t + AHEAD, wave);
+            lb.issue(smem + s2 * STAGE + TBM * BK * 2, kt0 + t + AHEAD, wave);
+        }
+        const char* sA = smem + st * STAGE;
+        const char* sB = sA + TBM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = read_frag<A_KC, TBM>(sA, wm * TM + i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = read_frag<B_KC, TBN>(sB, wn * TN + j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (++st == NSTAGE) st = 0;
+    }
+
+    const bool atomic = gridDim.z > 1;
+    const bool add_bias = blockIdx.z == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (TBM / 2) + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (TBN / 2) + j * 16 + 4 * (lane >> 4);
+            if (m < p.M && n < p.N) epilogue_store<bf16_t>(p, m, n, acc[i][j], add_bias, atomic);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // f32 kernel (parity mode).  LDS image is always [k][row] (row fastest); KC operands are
 // transposed by the staging write, RC operands are copied.  BK = 16.
 // ------------------------------------------------------------------------------------------------
@@ -367,6 +510,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 // ------------------------------------------------------------------------------------------------
 static int g_gemm_force_split = 0;
 static int g_gemm_force_tile = 0;     // (BM << 8) | BN, benchmarking only
+static int g_gemm_dma = -1;           // -1 heuristic; forced: 0 register-staged, 2 LDS-DMA 2 stages, 1 LDS-DMA 3 stages
+extern "C" void mebt_debug_gemm_variant(int dma) { g_gemm_dma = dma; }
 void mebt_gemm_force_split(int s) { g_gemm_force_split = s; }
 extern "C" void mebt_debug_gemm_tile(int bm, int bn) { g_gemm_force_tile = (bm && bn) ? ((bm << 8) | bn) : 0; }
 
@@ -382,14 +527,26 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     if ((!p.a_kc && (p.M % 8)) || (!p.b_kc && (p.N % 8))) { mebt_set_error("gemm: row extent of an RC operand must be a multiple of 8"); return MEBT_ESHAPE; }
     if (dtype == MEBT_F32) p.c_f32 = 1;
     if (p.K <= 0) { mebt_set_error("gemm: K must be positive (empty reductions are handled by the caller)"); return MEBT_ESHAPE; }
-    // tile selection (bf16): the largest tile that still yields ~one workgroup per CU
-    int tbm = 128, tbn = 128;
+    // tile / staging selection (bf16), measured on MI355X with tools/gemm_bench.py --variants
+    // (profiles/r01_gemm_variants.txt): staging 0 = register-staged 2 stages, 2 = LDS-DMA 2 stages,
+    // 3 = LDS-DMA 3-stage ring.
+    int tbm = 128, tbn = 128, staging = 2;
     if (dtype == MEBT_BF16) {
-        auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+        const long n128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        if (!p.a_kc || !p.b_kc) {        // dgrad / wgrad: an operand is read column-wise; register staging wins (cold operands)
+            staging = 0;
+            if (n128 >= 900) { tbm = 128; tbn = 128; staging = 2; }
+            else if (n128 >= 700) { tbm = 128; tbn = 128; }
+            else if (n128 >= 256) { tbm = 128; tbn = 64; }
+            else { tbm = 64; tbn = 64; }
+        } else {                         // forward: both operands k-contiguous; deeper LDS-DMA rings when few tiles
+            if (n128 >= 384) { tbm = 128; tbn = 128; staging = 2; }
+            else if (n128 > 256) { tbm = 128; tbn = 64; staging = 2; }
+            else if (n128 >= 160) { tbm = 128; tbn = 128; staging = 3; }
+            else { tbm = 128; tbn = 64; staging = 4; }
+        }
         if (g_gemm_force_tile) { tbm = g_gemm_force_tile >> 8; tbn = g_gemm_force_tile & 255; }
-        else if (wgs(128, 128) >= 700) { tbm = 128; tbn = 128; }      // measured on MI355X (tools/gemm_bench.py --variants)
-        else if (wgs(128, 128) >= 256) { tbm = 128; tbn = 64; }
-        else { tbm = 64; tbn = 64; }
+        if (g_gemm_dma >= 0) staging = g_gemm_dma == 1 ? 3 : g_gemm_dma;       // forced: 0 reg, 2..5 LDS-DMA stages (1 = 3)
     }
     dim3 grid((p.N + tbn - 1) / tbn, (p.M + tbm - 1) / tbm, 1);
     int split = 1;
@@ -405,7 +562,14 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         MEBT_HIP_CHECK(hipMemset2DAsync(p.C, (size_t)p.ldc * 4, 0, (size_t)p.N * 4, p.M, stream));
     }
     if (dtype == MEBT_BF16) {
-#define LAUNCH_T(AK, BKC, TM_, TN_) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC, TM_, TN_>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p)
+#define LAUNCH_T(AK, BKC, TM_, TN_)                                                                                   \
+        do {                                                                                                         \
+            if (staging == 5 && 5 * (TM_ + TN_) * BK * 2 <= 160 * 1024) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, (5 * (TM_ + TN_) * BK * 2 <= 160 * 1024 ? 5 : 2)>), grid, dim3(256), 5 * (TM_ + TN_) * BK * 2, stream, p); \
+            else if (staging >= 4) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 4>), grid, dim3(256), 4 * (TM_ + TN_) * BK * 2, stream, p); \
+            else if (staging == 3) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 3>), grid, dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, p); \
+            else if (staging == 2) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 2>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p); \
+            else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC, TM_, TN_>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p);          \
+        } while (0)
 #define LAUNCH_BF16(AK, BKC)                                           \
         do {                                                           \
             if (tbm == 128 && tbn == 128) LAUNCH_T(AK, BKC, 128, 128); \
@@ -436,7 +600,14 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
 
 int gemm_init_attributes() {
     // dynamic LDS up to 64 KiB
-#define SET_T(AK, BKC, TM_, TN_) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AK, BKC, TM_, TN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2))
+#define SET_T(AK, BKC, TM_, TN_)                                                                                                  \
+    do {                                                                                                                         \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AK, BKC, TM_, TN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2)); \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM_ + TN_) * BK * 2)); \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2)); \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (TM_ + TN_) * BK * 2)); \
+        if (5 * (TM_ + TN_) * BK * 2 <= 160 * 1024) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, (5 * (TM_ + TN_) * BK * 2 <= 160 * 1024 ? 5 : 2)>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (TM_ + TN_) * BK * 2)); \
+    } while (0)
 #define SET_ATTR(AK, BKC) do { SET_T(AK, BKC, 128, 128); SET_T(AK, BKC, 128, 64); SET_T(AK, BKC, 64, 128); SET_T(AK, BKC, 64, 64); } while (0)
     SET_ATTR(true, true);
     SET_ATTR(true, false);

@@ -83,7 +83,8 @@ struct LnBwdParams {
     float* dgamma; float* dbeta;                                 // fp32, atomically accumulated
     int rows, d; int seg, seg_stride, seg_off;
 };
-int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream);
+// dx on `stream`; the dgamma/dbeta reduction on `param_stream` (a side stream, or the same one)
+int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream, hipStream_t param_stream = nullptr, bool use_param_stream = false);
 
 // dst[i] = src[i] * keep(site, i)  (dropout mask re-applied in backward); TS/TD chosen by flags
 int launch_apply_dropout(const void* src, void* dst, size_t n, int src_f32, int dst_f32, const DropCfg& d, hipStream_t stream);

@@ -5,6 +5,7 @@ state_dict / load_state_dict / optimiser param_groups keep working with the refe
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -65,6 +66,8 @@ class NativeModel:
         nw, np_ = C.c_int64(), C.c_int64()
         check(self.lib.mebt_model_param_counts(self.h, C.byref(nw), C.byref(np_)))
         self.n_w, self.n_p = nw.value, np_.value
+        if os.environ.get("MEBT_SIDE_STREAM", "1") == "0":
+            self.lib.mebt_debug_side_stream(self.h, 0)
         self.n_layer, self.n_embd, self.vocab, self.n_latent = n_layer, n_embd, vocab, n_latent
         self.W = self.P = self.gW = self.gP = self.Wlp = None
         self.ws = None

@@ -66,20 +66,24 @@ def test_gemm_layouts_exact_integers(dtype, a_kc, b_kc, M, N, K):
     assert torch.equal(out.double(), ref), (out.double() - ref).abs().max()
 
 
+@pytest.mark.parametrize("staging", [0, 2, 1])
 @pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 128), (64, 64)])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0), (0, 1)])
-def test_gemm_every_tile_variant(tile, a_kc, b_kc):
-    """each block-tile instantiation of the bf16 kernel, forced, on ragged integer operands"""
+def test_gemm_every_tile_variant(tile, a_kc, b_kc, staging):
+    """each block-tile x staging instantiation of the bf16 kernel (register-staged, LDS-DMA 2-stage,
+    LDS-DMA 3-stage ring), forced, on ragged integer operands"""
     M, N, K = 328, 200, 192
     Am, Bm = rnd(M, K, seed=11, ints=True), rnd(N, K, seed=12, ints=True)
     ref = Am.double() @ Bm.double().t()
     A = Am if a_kc else Am.t().contiguous()
     B = Bm if b_kc else Bm.t().contiguous()
     lib().mebt_debug_gemm_tile(*tile)
+    lib().mebt_debug_gemm_variant(staging)
     try:
         out, _ = run_gemm(_lib.BF16, A, B, M, N, K, a_kc, b_kc, c_f32=1)
     finally:
         lib().mebt_debug_gemm_tile(0, 0)
+        lib().mebt_debug_gemm_variant(-1)
     assert torch.equal(out.double(), ref), (out.double() - ref).abs().max()
 
 

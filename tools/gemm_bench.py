@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--variants", action="store_true")
+ap.add_argument("--cold", action="store_true", help="rotate operands through a >600 MB pool (HBM-cold, like in the real step)")
 args = ap.parse_args()
 lib = _lib.load()
 dt = _lib.BF16 if args.dtype == "bf16" else _lib.F32
@@ -36,11 +37,17 @@ shapes += [("fwd qkv self", 6, 1536, 3 * d, d, 1, 1, 0, 1), ("fwd kv enc", 7, 30
 tot_ms = tot_fl = 0.0
 print(f"{'shape':24s} {'cnt':>3s} {'M':>6s} {'N':>6s} {'K':>6s}  {'us':>8s} {'TF/s':>7s}")
 for label, cnt, M, N, K, akc, bkc, cf32, split in shapes:
-    A = torch.randn((M, K) if akc else (K, M), device="cuda").to(tt)
-    B = torch.randn((N, K) if bkc else (K, N), device="cuda").to(tt)
+    esz = 2 if args.dtype == "bf16" else 4
+    pool = max(1, int(6e8 // ((M * K + N * K) * esz))) if args.cold else 1
+    A = torch.randn((pool,) + ((M, K) if akc else (K, M)), device="cuda").to(tt)
+    B = torch.randn((pool,) + ((N, K) if bkc else (K, N)), device="cuda").to(tt)
     C = torch.empty(M, N, device="cuda", dtype=torch.float32 if (cf32 or dt == _lib.F32) else tt)
-    lda, ldb = A.shape[1], B.shape[1]
-    run = lambda: check(lib.mebt_op_gemm(dt, ptr(A), ptr(B), ptr(C), None, None, None, M, N, K, lda, ldb, N, N, akc, bkc, 0, cf32, 0, split, cur_stream()))
+    lda, ldb = A.shape[2], B.shape[2]
+    ctr = [0]
+    def run():
+        i = ctr[0] % pool
+        ctr[0] += 1
+        check(lib.mebt_op_gemm(dt, A[i].data_ptr(), B[i].data_ptr(), ptr(C), None, None, None, M, N, K, lda, ldb, N, N, akc, bkc, 0, cf32, 0, split, cur_stream()))
     def timeit():
         for _ in range(3):
             run()
@@ -51,6 +58,7 @@ for label, cnt, M, N, K, akc, bkc, cf32, split in shapes:
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / args.iters
+    lib.mebt_debug_gemm_variant(-1)
     us = timeit()
     fl = 2.0 * M * N * K
     tot_ms += cnt * us * 1e-3
@@ -59,7 +67,12 @@ for label, cnt, M, N, K, akc, bkc, cf32, split in shapes:
     if args.dtype == "bf16" and args.variants:
         for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64)):
             lib.mebt_debug_gemm_tile(bm, bn)
-            var += f"  {bm}x{bn}:{fl / timeit() / 1e6:6.0f}"
+            r = []
+            for v in (0, 2, 3, 4, 5):    # register-staged / LDS-DMA with 2,3,4,5 ring stages
+                lib.mebt_debug_gemm_variant(v)
+                r.append(f"{fl / timeit() / 1e6:4.0f}")
+            var += f" |{bm}x{bn} " + "/".join(r)
         lib.mebt_debug_gemm_tile(0, 0)
+        lib.mebt_debug_gemm_variant(-1)
     print(f"{label:24s} {cnt:3d} {M:6d} {N:6d} {K:6d}  {us:8.1f} {fl / us / 1e6:7.1f}{var}")
 print(f"step total: {tot_ms:.2f} ms, {tot_fl / 1e12:.2f} TFLOP -> {tot_fl / tot_ms / 1e9:.0f} TF/s")
