@@ -39,7 +39,7 @@ def synthetic_batch(B, shape, rank, device):
     return x.to(device), idx.to(device)
 
 
-def cpu_baseline(model_sd, cfg, t, sample_B=1):
+def cpu_baseline(model_sd, cfg, t, sample_B=6):
     """The CPU oracle (a port of the reference algorithm, pinned to it by tests/golden) timed on
     this box's host cores: one full train step (fwd + CE + bwd + AdamW) of the same network at
     batch `sample_B` and the same t."""
@@ -51,6 +51,7 @@ def cpu_baseline(model_sd, cfg, t, sample_B=1):
     torch.set_num_threads(cores)
     st = orc.TrainState({k: v.float().cpu() for k, v in model_sd.items()}, lr=cfg.exp.exact_lr)
     x, idx = synthetic_batch(sample_B, cfg.model.mask.params.shape, 0, "cpu")
+    orc.train_step(st, ocfg, x, idx, t)                      # untimed warm-up step (allocator, thread pool)
     t0 = time.perf_counter()
     r = orc.train_step(st, ocfg, x, idx, t)
     dt = time.perf_counter() - t0
@@ -64,7 +65,7 @@ def cpu_baseline(model_sd, cfg, t, sample_B=1):
     except OSError:
         pass
     return {"value": r["n_targets"] / dt, "unit": "masked tokens/s", "cores": cores, "kind": "port",
-            "sample": f"1 train step (fwd+CE+bwd+AdamW) at batch {sample_B}, NC=NT={r['n_targets'] // sample_B}, fp32, "
+            "sample": f"1 timed train step (fwd+CE+bwd+AdamW, after 1 warm-up) at batch {sample_B}, NC=NT={r['n_targets'] // sample_B}, fp32, "
                       f"torch {torch.__version__} CPU, {torch.get_num_threads()} threads, {model}; {dt:.1f} s"}
 
 
@@ -142,6 +143,8 @@ def main():
     n, tms, fl = C.c_double(), C.c_double(), C.c_double()
     if rank == 0:
         _lib.check(lib.mebt_profile_read(0, C.byref(n), C.byref(tms), C.byref(fl)))
+        nb, tb, by = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(lib.mebt_profile_read(1, C.byref(nb), C.byref(tb), C.byref(by)))
         lib.mebt_profile_enable(0)
     # the same two steps with every launch on one stream: per-kernel durations without the overlap of
     # the side stream (gradient leaves run concurrently with the dgrad chain in the shipped path)
@@ -160,9 +163,18 @@ def main():
     lib.mebt_debug_side_stream(loop.native.h, 1)
     if rank == 0:
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        # HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
+        # (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction): tools/pmc_traffic.py
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = round(json.load(f)["gemm_bf16"]["hbm_bytes_per_launch"]) if args.dtype == "bf16" else None
+        except (OSError, KeyError, ValueError):
+            pass
         achieved = fl.value / (tms.value * 1e-3) / 1e12 if tms.value > 0 else 0.0
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None,
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(by.value / max(1.0, nb.value)),
                 "kernel": "gemm_bf16_kernel (all layouts/tiles)" if args.dtype == "bf16" else "gemm_f32_kernel",
                 "launches_per_step": n.value / 2, "gemm_ms_per_step": round(tms.value / 2, 3),
                 "gemm_gflop_per_step": round(fl.value / 2 / 1e9, 1), "achieved_single_stream": ser}

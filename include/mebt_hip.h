@@ -139,7 +139,8 @@ int mebt_op_cast_bf16(const float* src, void* dst, int64_t n, mebt_stream_t stre
 
 /* ---- instrumentation ----------------------------------------------------------------------------- */
 /* Per-kernel-family timing with HIP events on the launch stream (bench.py roofline): enable, run,
- * then read {launches, total ms, total algorithmic flops} of the GEMM family. */
+ * then read {launches, total ms, total algorithmic flops} of the GEMM family (family 0), or the
+ * algorithmic operand + result bytes in place of the flops (family 1). */
 int mebt_profile_enable(int32_t on);
 int mebt_profile_read(int32_t family, double* launches, double* total_ms, double* total_flops);
 /* Tests only: multiplies out[0..n) (fp32, n % 4 == 0) in place by the dropout keep-scales (0 or 1/(1-p))

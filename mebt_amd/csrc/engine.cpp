@@ -95,7 +95,7 @@ static int join_side(mebt_model* m, hipStream_t st);
 // profiling of the GEMM family with HIP events on the launch stream
 // ---------------------------------------------------------------------------------------------------
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops, bytes; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_ev_pool;
@@ -116,7 +116,12 @@ static int gemm(const mebt_model* m, GemmParams p, hipStream_t st) {
     }
     ProfRec r;
     const bool prof = g_prof_on && p.M > 0 && p.N > 0;
-    if (prof) { r.a = get_event(); r.b = get_event(); r.flops = 2.0 * p.M * p.N * p.K; (void)hipEventRecord(r.a, st); }
+    if (prof) {
+        r.a = get_event(); r.b = get_event(); r.flops = 2.0 * p.M * p.N * p.K;
+        const double esz = m->d.dtype == MEBT_BF16 ? 2.0 : 4.0, csz = (p.c_f32 || m->d.dtype == MEBT_F32) ? 4.0 : 2.0;
+        r.bytes = ((double)p.M * p.K + (double)p.N * p.K) * esz + (double)p.M * p.N * (csz * (p.C ? 1 : 0) + (p.C2 ? esz : 0) + (p.aux ? esz : 0));
+        (void)hipEventRecord(r.a, st);
+    }
     const int rc = launch_gemm(p, m->d.dtype, st);
     if (prof) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
     return rc;
@@ -129,13 +134,12 @@ extern "C" int mebt_profile_enable(int32_t on) {
     return MEBT_OK;
 }
 extern "C" int mebt_profile_read(int32_t family, double* launches, double* total_ms, double* total_flops) {
-    (void)family;
     double ms = 0, fl = 0;
     for (auto& r : g_prof) {
         MEBT_HIP_CHECK(hipEventSynchronize(r.b));
         float t = 0;
         MEBT_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
-        ms += t; fl += r.flops;
+        ms += t; fl += family == 1 ? r.bytes : r.flops;    // family 1: algorithmic operand+result bytes instead of FLOPs
     }
     *launches = (double)g_prof.size(); *total_ms = ms; *total_flops = fl;
     return MEBT_OK;

@@ -1,0 +1,127 @@
+"""Full-size checks on MI355X: the Sky-Timelapse 16f network (BASELINE.json configs[1], 24L/1024d/16h,
+337 M parameters) against the CPU oracle on the same random weights, and size-independent properties
+at the UCF-128f geometry (configs[3]: block 8192, NC=7936/NT=256 revise forwards).  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mebt_amd import presets
+from oracle import mebt_oracle as orc
+
+DEV = "cuda"
+
+
+def oracle_cfg_of(cfg):
+    p, m = cfg.model.params, cfg.model.mask.params
+    return orc.OracleConfig(p.n_layer, p.n_head, p.n_embd, p.block_size, p.sos_emb, p.mode, shape=m.shape,
+                            schedule=m.schedule, budget=m.budget, avg_loss=1.0)
+
+
+@pytest.fixture(scope="module")
+def sky():
+    torch.manual_seed(7)
+    cfg = presets.sky_16f(dropout=0.0)
+    model = presets.build_model(cfg, compute_dtype="f32")
+    with torch.no_grad():                          # non-trivial biases / LN affine so nothing is skipped silently
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.02)
+            elif ".ln" in n and n.endswith("weight"):
+                p.add_(torch.randn_like(p) * 0.05)
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return cfg, model, P
+
+
+def test_sky16f_logits_and_loss_fp32_within_1e3(sky):
+    """north_star: logits match the reference CPU path within 1e-3 in fp32 on identical weights and
+    synthetic [B,4,16,16] token grids (the oracle is the reference's algorithm, pinned by tests/golden)."""
+    cfg, model, P = sky
+    ocfg = oracle_cfg_of(cfg)
+    g = torch.Generator().manual_seed(3)
+    B = 2
+    x = torch.randint(0, 16384, (B, 4, 16, 16), generator=g)
+    idx = torch.stack([torch.randperm(1024, generator=g) for _ in range(B)])
+    with torch.no_grad():
+        ref, z_t, ntw, seq_len = orc.forward(P, ocfg, x, idx, 0.5, training=True)
+        a1, a5, loss = orc.loss_and_acc(ref, z_t, ntw, seq_len, ocfg)
+    model.compute_dtype = "f32"
+    model.to(DEV).train()
+    with torch.no_grad():
+        logits, z2, ntw2, sl2 = model(x.to(DEV), None, t=0.5, indices=idx.to(DEV))
+    assert logits.shape == (B, 512, 16384) and torch.equal(z2.cpu(), z_t)
+    err = (logits.cpu() - ref).abs().max().item()
+    assert err < 1e-3, err                                  # measured ~1e-5
+    import random
+    orig = random.random
+    random.random = lambda: 0.5
+    try:
+        with torch.no_grad():
+            b1, b5, l2, _ = model.shared_step({"video": x.to(DEV), "indices": idx.to(DEV)}, 0)
+    finally:
+        random.random = orig
+    assert abs(float(l2) - float(loss)) < 1e-4 * float(loss)
+    assert abs(float(b1) - float(a1)) < 0.2 and abs(float(b5) - float(a5)) < 0.2
+
+
+def test_sky16f_bf16_close_to_fp32_and_training_reduces_loss():
+    torch.manual_seed(11)
+    cfg = presets.sky_16f(dropout=0.0)
+    cfg.exp.exact_lr = 3e-4
+    model = presets.build_model(cfg, compute_dtype="bf16").to(DEV).train()
+    from mebt_amd.trainer import TrainLoop
+    loop = TrainLoop(model)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 64, (6, 4, 16, 16), generator=g).to(DEV)      # a learnable (low-entropy) batch
+    idx = torch.stack([torch.randperm(1024, generator=g) for _ in range(6)]).to(DEV)
+    losses = [float(loop.step(x, idx, t=0.5)[4].cpu()) for _ in range(12)]
+    assert all(np.isfinite(losses)) and abs(losses[0] - np.log(16384)) < 0.5     # random-init CE ~ ln V
+    assert losses[-1] < losses[0] - 1.0, losses                                   # the optimiser step learns
+
+
+def test_ucf128f_geometry_revise_forward_properties():
+    """C4: block_size 8192, grid [32,16,16]; a revise forward has NC=7936, NT=256.
+    Properties: finite logits; bf16 agrees with fp32 loosely; permuting the CONTEXT order leaves the
+    logits unchanged (attention over contexts is permutation invariant); permuting targets permutes rows."""
+    torch.manual_seed(13)
+    cfg = presets.ucf_128f()
+    B, N, NT = 1, 8192, 256
+    g = torch.Generator().manual_seed(9)
+    x = torch.randint(0, 16384, (B, 32, 16, 16), generator=g).to(DEV)
+    perm = torch.randperm(N, generator=g)
+    ci, ti = perm[:N - NT].unsqueeze(0).to(DEV), perm[N - NT:].unsqueeze(0).to(DEV)
+    model = presets.build_model(cfg, compute_dtype="f32").to(DEV).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    l32, _ = model.reconstruct_mask(x, ci, ti)
+    assert l32.shape == (B, NT, 16384) and torch.isfinite(l32).all()
+    shuffled = ci[:, torch.randperm(N - NT, generator=g).to(DEV)]
+    l32b, _ = model.reconstruct_mask(x, shuffled, ti)
+    assert (l32b - l32).abs().max().item() < 2e-4
+    rp = torch.randperm(NT, generator=g).to(DEV)
+    l32c, _ = model.reconstruct_mask(x, ci, ti[:, rp])
+    assert (l32c - l32[:, rp]).abs().max().item() < 2e-4
+    m16 = presets.build_model(presets.ucf_128f(), compute_dtype="bf16")
+    m16.load_state_dict(sd)
+    m16 = m16.to(DEV).eval()
+    l16, _ = m16.reconstruct_mask(x, ci, ti)
+    assert (l16 - l32).abs().max().item() < 0.15 and (l16.argmax(-1) == l32.argmax(-1)).float().mean() > 0.5
+
+
+def test_sample_loop_full_size_invariants():
+    """32-step MaskGIT sampling at Sky size: every step's (NC,NT) partition stays a
+    partition of range(N); the final sample has no untouched position; greedy (T->0) is deterministic."""
+    torch.manual_seed(17)
+    cfg = presets.sky_16f(dropout=0.0)
+    cfg.model.mask.params.schedule = "cosine"
+    model = presets.build_model(cfg, compute_dtype="bf16").to(DEV).eval()
+    x0 = torch.full((2, 4, 16, 16), -1, dtype=torch.long, device=DEV).clamp(min=0)
+    out = model.sample(x0, None, 1.0, None, None, 8, None, None, context_temperature=6.0, skips=False, debug=True)
+    xs, ci, ti, hist, ctx_hist, probs = out
+    assert xs.shape == (2, 1024) and ti.shape[1] + ci.shape[1] == 1024
+    both = torch.cat([ci, ti], 1).sort(dim=1).values
+    assert torch.equal(both, torch.arange(1024, device=DEV).repeat(2, 1))
+    assert (probs.sum(-1) - 1).abs().max().item() < 1e-3          # every position got a distribution written
+    a = model.sample(x0, None, 0.0, None, None, 4, None, None, context_temperature=0.0, skips=False)[0]
+    b = model.sample(x0, None, 0.0, None, None, 4, None, None, context_temperature=0.0, skips=False)[0]
+    assert torch.equal(a, b)
