@@ -109,15 +109,19 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
 // counter-based RNG for dropout (Philox-like mixing of a 64-bit counter; one 32-bit draw per call).
 // The mask of element `idx` at site `site` of step `seed` is recomputed in backward, never stored.
 // ---------------------------------------------------------------------------------------------
+// One 32-bit mix (two multiplies) yields two 16-bit draws: elements idx and idx^1 share a hash.
 __device__ __forceinline__ uint32_t mix_hash(uint64_t seed, uint32_t site, uint64_t idx) {
-    uint64_t x = idx + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1) + seed;
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-    x ^= x >> 27; x *= 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    return (uint32_t)(x >> 32);
+    const uint64_t pair = idx >> 1;
+    uint32_t h = (uint32_t)pair * 0x9E3779B1u + (uint32_t)seed;
+    h ^= ((uint32_t)(pair >> 32) + site * 0x632BE5ABu) ^ (uint32_t)(seed >> 32);
+    h ^= h >> 15; h *= 0x85EBCA77u;
+    h ^= h >> 13; h *= 0xC2B2AE3Du;
+    h ^= h >> 16;
+    return (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
 }
-// Dropout descriptor: element `idx` of site `site` is kept iff hash >= thresh (thresh = p * 2^32);
-// kept values are scaled by inv_keep = 1/(1-p).  thresh == 0 disables the site.
+// Dropout descriptor: element `idx` of site `site` is kept iff its 16-bit draw >= thresh
+// (thresh = round(p * 65536)); kept values are scaled by inv_keep = 65536 / (65536 - thresh).
+// thresh == 0 disables the site.
 struct DropCfg {
     uint64_t seed;
     uint32_t site;

@@ -254,6 +254,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, i
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_grouped_kernel(const GroupedColsum c) {
+    __shared__ float red[16][64 + 4];
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < MEBT_MAX_GROUP; ++i)
+        if (i < c.n && (int)blockIdx.x >= c.blk_start[i]) g = i;
+    const GroupedColsum::Item& it = c.g[g];
+    const int b = blockIdx.x - c.blk_start[g];
+    const int bx = b % it.gx, by = b / it.gx;
+    const T* X = reinterpret_cast<const T*>(it.X);
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int n = bx * 64 + cg * 4;
+    const int m0 = by * it.rpb, m1 = min(it.M, m0 + it.rpb);
+    f32x4 acc = {0, 0, 0, 0};
+    if (n < it.N)
+        for (int m = m0 + rl; m < m1; m += 16) acc += load4<T>(X + (size_t)m * it.ldx + n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][cg * 4 + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+        const int col = bx * 64 + threadIdx.x;
+        if (col < it.N) atomicAdd(it.out + col, t);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // cross-entropy over V with label smoothing + rank of the target (top-1 / top-5 accuracy)
 // ------------------------------------------------------------------------------------------------
@@ -467,6 +496,31 @@ int launch_colsum(const void* X, int M, int N, int ldx, float* out, int dtype, h
     const dim3 grid(gx, (M + rpb - 1) / rpb);
     if (dtype == MEBT_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, stream, reinterpret_cast<const bf16_t*>(X), M, N, ldx, out, rpb);
     else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, reinterpret_cast<const float*>(X), M, N, ldx, out, rpb);
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+
+int launch_colsum_grouped(GroupedColsum& c, int dtype, hipStream_t stream) {
+    GroupedColsum k;
+    int n = 0, blocks = 0;
+    for (int i = 0; i < c.n; ++i) {
+        if (c.g[i].M <= 0 || c.g[i].N <= 0) continue;
+        if (c.g[i].N % 4) { mebt_set_error("colsum: N must be a multiple of 4"); return MEBT_ESHAPE; }
+        k.g[n] = c.g[i];
+        k.g[n].gx = (c.g[i].N + 63) / 64;
+        int rpb = 256;
+        while ((c.g[i].M + rpb - 1) / rpb > 32) rpb *= 2;
+        while (rpb > 64 && (long)k.g[n].gx * ((c.g[i].M + rpb - 1) / rpb) < 128) rpb /= 2;
+        k.g[n].rpb = rpb;
+        k.blk_start[n] = blocks;
+        blocks += k.g[n].gx * ((c.g[i].M + rpb - 1) / rpb);
+        ++n;
+    }
+    k.n = n;
+    for (int i = n; i <= MEBT_MAX_GROUP; ++i) k.blk_start[i] = blocks;
+    if (!blocks) return MEBT_OK;
+    if (dtype == MEBT_BF16) hipLaunchKernelGGL(colsum_grouped_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, k);
+    else hipLaunchKernelGGL(colsum_grouped_kernel<float>, dim3(blocks), dim3(256), 0, stream, k);
     CHECK_LAUNCH();
     return MEBT_OK;
 }

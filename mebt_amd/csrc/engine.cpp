@@ -203,7 +203,11 @@ extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) 
     }
     int rc = gemm_init_attributes();
     if (rc) { delete m; return rc; }
-    if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) { m->side = nullptr; m->use_side = false; (void)hipGetLastError(); }
+    {   // lowest priority: the leaves must never delay the critical path on the caller's stream
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, least) != hipSuccess) { m->side = nullptr; m->use_side = false; (void)hipGetLastError(); }
+    }
     if (m->side) {
         hipEvent_t* evs[] = {&m->ev_fork, &m->ev_e1, &m->ev_layer[0], &m->ev_layer[1], &m->ev_join};
         for (hipEvent_t* e : evs) MEBT_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -332,8 +336,8 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
             s.dqkv_k = c.take(Mmax * 2 * d * e);
             s.dqn = c.take(Mmax * d * e);
             s.dkn = c.take(Mmax * d * e);
-            s.dout_m = s.dx_m = nullptr;
-            if (m->d.resid_pdrop > 0.f) { s.dout_m = c.take(Mmax * d * e); s.dx_m = c.take(Mmax * d * e); }
+            s.dout_m = c.take(Mmax * d * e);
+            s.dx_m = m->d.resid_pdrop > 0.f ? c.take(Mmax * d * e) : nullptr;
         }
         x.delta = (float*)c.take((int64_t)B * H * (NS + NT) * 4);
     }
@@ -612,6 +616,57 @@ static int join_side(mebt_model* m, hipStream_t st) {
     return MEBT_OK;
 }
 
+// Gradient leaves of one block (weight / bias gradients): collected while the critical path
+// (dgrad chain, attention backward, LN dx) is enqueued on the main stream, then issued as ONE grouped
+// wgrad GEMM + ONE grouped column-sum on the side stream, where they overlap the next block's chain.
+struct Leaves {
+    GroupedWgrad w;
+    GroupedColsum c;
+    Leaves() { w.n = 0; c.n = 0; }
+    void wgrad(const void* dY, int ld_dy, const void* X, int ld_x, float* C, int n_out, int k_in, int tokens) {
+        GroupedWgrad::Item& it = w.g[w.n++];
+        it.A = dY; it.B = X; it.C = C; it.M = n_out; it.N = k_in; it.K = tokens; it.lda = ld_dy; it.ldb = ld_x; it.ldc = k_in; it.ntx = 0;
+    }
+    void colsum(const void* X, int M, int N, int ldx, float* out) {
+        GroupedColsum::Item& it = c.g[c.n++];
+        it.X = X; it.out = out; it.M = M; it.N = N; it.ldx = ldx; it.gx = 0; it.rpb = 0;
+    }
+};
+
+static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd) {
+    const int dt = m->d.dtype;
+    RC(launch_colsum_grouped(lv.c, dt, sd));
+    for (int i = 0; i < lv.w.n; ++i) {      // empty reductions (NC = 0): the gradient is zero
+        const GroupedWgrad::Item& it = lv.w.g[i];
+        if (it.K <= 0 && it.M > 0 && it.N > 0) MEBT_HIP_CHECK(hipMemset2DAsync(it.C, (size_t)it.ldc * 4, 0, (size_t)it.N * 4, it.M, sd));
+    }
+    if (dt == MEBT_BF16) {
+        ProfRec r;
+        const bool prof = g_prof_on;
+        if (prof) {
+            r.a = get_event(); r.b = get_event(); r.flops = 0; r.bytes = 0;
+            for (int i = 0; i < lv.w.n; ++i) {
+                const GroupedWgrad::Item& it = lv.w.g[i];
+                if (it.K <= 0) continue;
+                r.flops += 2.0 * it.M * it.N * it.K;
+                r.bytes += ((double)it.M * it.K + (double)it.N * it.K) * 2.0 + (double)it.M * it.N * 4.0;
+            }
+            (void)hipEventRecord(r.a, sd);
+        }
+        const int rc = launch_wgrad_grouped(lv.w, dt, sd);
+        if (prof) { (void)hipEventRecord(r.b, sd); g_prof.push_back(r); }
+        return rc;
+    }
+    for (int i = 0; i < lv.w.n; ++i) {
+        const GroupedWgrad::Item& it = lv.w.g[i];
+        if (it.K <= 0) continue;
+        GemmParams p = gp(it.A, it.B, it.C, it.M, it.N, it.K, it.lda, it.ldb, it.ldc, 0, 0);
+        p.c_f32 = 1;
+        RC(gemm(m, p, sd));
+    }
+    return MEBT_OK;
+}
+
 static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     FwdCtx& x = m->ctx;
     LayerAct& a = x.L[i];
@@ -627,29 +682,27 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     const void* dout = isdec ? x.g_T : x.g_S;
     const float p_res = x.drop_on ? m->d.resid_pdrop : 0.f, p_att = x.drop_on ? m->d.attn_pdrop : 0.f;
     const int f32 = dt == MEBT_F32;
-    // out = x + dropout(u W2^T + b2): the branch gradient is dout * mask (the mask is recomputed, never stored)
-    const void* dmlp = dout;
-    if (p_res > 0.f) {
-        RC(launch_apply_dropout(dout, sc.dout_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_MLP, p_res), st));
-        dmlp = sc.dout_m;
-    }
-    if (side) RC(fork_side(m, st));
-    RC(launch_colsum(dmlp, Mq, d, d, m->gP + o.b2, dt, sd));
-    RC(wgrad(m, dmlp, d, a.u, 4 * d, o.w2, d, 4 * d, Mq, sd));
-    if (side) MEBT_HIP_CHECK(hipEventRecord(m->ev_e1, sd));       // last side readers of `dout` itself
+    const size_t esz = m->esz();
+    Leaves lv;
+    // out = x + dropout(u W2^T + b2): the branch gradient is dout * mask (the mask is recomputed, never
+    // stored).  It is materialised in scratch either way: the leaves read it after this block's LN1
+    // backward has overwritten the stream gradient.
+    if (p_res > 0.f) RC(launch_apply_dropout(dout, sc.dout_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_MLP, p_res), st));
+    else MEBT_HIP_CHECK(hipMemcpyAsync(sc.dout_m, dout, (size_t)Mq * d * esz, hipMemcpyDeviceToDevice, st));
+    const void* dmlp = sc.dout_m;
+    lv.colsum(dmlp, Mq, d, d, m->gP + o.b2);
+    lv.wgrad(dmlp, d, a.u, 4 * d, m->gW + o.w2, d, 4 * d, Mq);
     RC(dgrad(m, dmlp, d, o.w2, sc.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, st));   // d(pre) = (dmlp W2) * gelu'(pre)
-    if (side) RC(fork_side(m, st));
-    RC(launch_colsum(sc.d4, Mq, 4 * d, 4 * d, m->gP + o.b1, dt, sd));
-    RC(wgrad(m, sc.d4, 4 * d, a.hn, d, o.w1, 4 * d, d, Mq, sd));
+    lv.colsum(sc.d4, Mq, 4 * d, 4 * d, m->gP + o.b1);
+    lv.wgrad(sc.d4, 4 * d, a.hn, d, m->gW + o.w1, 4 * d, d, Mq);
     RC(dgrad(m, sc.d4, 4 * d, o.w1, sc.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st));
     // dx = dout + LN2'(dh)   (dgamma/dbeta reduction on the side stream)
     if (side) RC(fork_side(m, st));
     {
         LnBwdParams p;
         p.x = a.x; p.dy = sc.dh; p.dy2 = nullptr; p.dx_add = dout; p.gamma = m->P + o.ln2w; p.mean = a.mean2; p.rstd = a.rstd2;
-        p.dx = sc.dx; p.dx_f32 = 0; p.dx_accumulate = 0; p.dgamma = m->gP + o.ln2w; p.dbeta = m->gP + o.ln2b;
+        p.dx = sc.dx; p.dx_f32 = f32; p.dx_accumulate = 0; p.dgamma = m->gP + o.ln2w; p.dbeta = m->gP + o.ln2b;
         p.rows = Mq; p.d = d; p.seg = 0; p.seg_stride = 0; p.seg_off = 0;
-        if (dt == MEBT_F32) p.dx_f32 = 1;
         RC(launch_ln_bwd(p, dt, st, sd, true));
     }
     // x = qn + dropout(att Wp^T + bp)
@@ -658,9 +711,8 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         RC(launch_apply_dropout(sc.dx, sc.dx_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_PROJ, p_res), st));
         dproj = sc.dx_m;
     }
-    if (side) RC(fork_side(m, st));
-    RC(launch_colsum(dproj, Mq, d, d, m->gP + o.bp, dt, sd));
-    RC(wgrad(m, dproj, d, a.att, d, o.wp, d, d, Mq, sd));
+    lv.colsum(dproj, Mq, d, d, m->gP + o.bp);
+    lv.wgrad(dproj, d, a.att, d, m->gW + o.wp, d, d, Mq);
     RC(dgrad(m, dproj, d, o.wp, x.datt, Mq, d, d, EPI_NONE, nullptr, 0, st));
     // attention backward
     AttnParams ap;
@@ -669,7 +721,6 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     ap.ldq = a.ldqkv_q; ap.ldk = a.ldqkv_k; ap.ldv = a.ldqkv_k; ap.ldo = d;
     ap.d_o = x.datt; ap.lddo = d; ap.delta = x.delta;
     ap.drop = make_drop(x.drop_seed, 16 * i + SITE_ATTN, p_att);
-    const int esz = m->esz();
     if (mode == MEBT_MODE_LATENT_SELF) {
         ap.dq = sc.dqkv_q; ap.dk = (char*)sc.dqkv_q + (size_t)d * esz; ap.dv = (char*)sc.dqkv_q + (size_t)2 * d * esz;
         ap.lddq = ap.lddk = ap.lddv = 3 * d;
@@ -678,30 +729,31 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         ap.dk = sc.dqkv_k; ap.dv = (char*)sc.dqkv_k + (size_t)d * esz; ap.lddk = ap.lddv = 2 * d;
     }
     RC(launch_attn_bwd(ap, dt, st));
-    if (side) RC(fork_side(m, st));
-    // LN1 backward helper: dx on the main stream (after the side readers of `dout` when it overwrites it), affine grads on the side stream
+    // LN1 backward helper: dx on the main stream, affine grads on the side stream
     auto ln1 = [&](const void* xin, const void* dy, const void* dy2, const float* mean, const float* rstd, void* dxp, int dx_f32, int acc,
                    int rows, int seg, int seg_stride, int seg_off) -> int {
         LnBwdParams p;
         p.x = xin; p.dy = dy; p.dy2 = dy2; p.dx_add = nullptr; p.gamma = m->P + o.ln1w; p.mean = mean; p.rstd = rstd;
-        p.dx = dxp; p.dx_f32 = dx_f32 || dt == MEBT_F32; p.dx_accumulate = acc; p.dgamma = m->gP + o.ln1w; p.dbeta = m->gP + o.ln1b;
+        p.dx = dxp; p.dx_f32 = dx_f32 || f32; p.dx_accumulate = acc; p.dgamma = m->gP + o.ln1w; p.dbeta = m->gP + o.ln1b;
         p.rows = rows; p.d = d; p.seg = seg; p.seg_stride = seg_stride; p.seg_off = seg_off;
         return launch_ln_bwd(p, dt, st, sd, true);
     };
     if (mode == MEBT_MODE_LATENT_SELF) {
-        RC(launch_colsum(sc.dqkv_q, Mq, 3 * d, 3 * d, m->gP + o.bq, dt, sd));
-        RC(wgrad(m, sc.dqkv_q, 3 * d, a.qn, d, o.wq, 3 * d, d, Mq, sd));
+        lv.colsum(sc.dqkv_q, Mq, 3 * d, 3 * d, m->gP + o.bq);
+        lv.wgrad(sc.dqkv_q, 3 * d, a.qn, d, m->gW + o.wq, 3 * d, d, Mq);
         RC(dgrad(m, sc.dqkv_q, 3 * d, o.wq, sc.dqn, Mq, 3 * d, d, EPI_RESID, sc.dx, d, st));   // + dx (residual on qn)
-        if (side) { RC(fork_side(m, st)); MEBT_HIP_CHECK(hipStreamWaitEvent(st, m->ev_e1, 0)); }
+        if (side) RC(fork_side(m, st));
+        RC(flush_leaves(m, lv, sd));
         RC(ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0));
     } else {
-        RC(launch_colsum(sc.dqkv_q, Mq, d, d, m->gP + o.bq, dt, sd));
-        RC(wgrad(m, sc.dqkv_q, d, a.qn, d, o.wq, d, d, Mq, sd));
-        RC(launch_colsum(sc.dqkv_k, Mk, 2 * d, 2 * d, m->gP + o.bk, dt, sd));
-        RC(wgrad(m, sc.dqkv_k, 2 * d, a.kn, d, o.wk, 2 * d, d, Mk, sd));
+        lv.colsum(sc.dqkv_q, Mq, d, d, m->gP + o.bq);
+        lv.wgrad(sc.dqkv_q, d, a.qn, d, m->gW + o.wq, d, d, Mq);
+        lv.colsum(sc.dqkv_k, Mk, 2 * d, 2 * d, m->gP + o.bk);
+        lv.wgrad(sc.dqkv_k, 2 * d, a.kn, d, m->gW + o.wk, 2 * d, d, Mk);
         RC(dgrad(m, sc.dqkv_q, d, o.wq, sc.dqn, Mq, d, d, EPI_RESID, sc.dx, d, st));
         if (Mk > 0) RC(dgrad(m, sc.dqkv_k, 2 * d, o.wk, sc.dkn, Mk, 2 * d, d, EPI_NONE, nullptr, 0, st));
-        if (side) { RC(fork_side(m, st)); MEBT_HIP_CHECK(hipStreamWaitEvent(st, m->ev_e1, 0)); }
+        if (side) RC(fork_side(m, st));
+        RC(flush_leaves(m, lv, sd));
         if (mode == MEBT_MODE_LATENT_ENC) {
             RC(ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0));
             if (Mk > 0) {   // contexts feed every latent_enc block: accumulate in fp32

@@ -147,29 +147,13 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int blk16 /*16-row
     }
 }
 
+// one output tile (m0, n0), k-tiles [kt0, kt1): register-staged 2-stage main loop + epilogue
 template <bool A_KC, bool B_KC, int TBM, int TBN>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_tile_regstaged(const GemmParams& p, int m0, int n0, int kt0, int kt1, char* smem, bool atomic, bool add_bias) {
     constexpr int STAGE = (TBM + TBN) * BK * 2;
     constexpr int TM = TBM / 32, TN = TBN / 32;         // MFMA tiles per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD
-    // a contiguous run of tiles along N (they share the same A rows -> L2 hits).
-    const int ntx = gridDim.x, nty = gridDim.y, ntiles = ntx * nty;
-    int bid = blockIdx.y * ntx + blockIdx.x;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int m0 = (bid / ntx) * TBM, n0 = (bid % ntx) * TBN;
-
-    const int nkt = (p.K + BK - 1) / BK;
-    const int per = (nkt + gridDim.z - 1) / gridDim.z;
-    const int kt0 = blockIdx.z * per;
-    const int kt1 = min(nkt, kt0 + per);
-    if (kt0 >= kt1) return;
-
     TileLoader<A_KC, TBM> la;
     TileLoader<B_KC, TBN> lb;
     la.init(p.A, p.M, p.K, p.lda, m0, tid);
@@ -217,9 +201,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
         }
         __syncthreads();
     }
-
-    const bool atomic = gridDim.z > 1;
-    const bool add_bias = blockIdx.z == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (TBM / 2) + i * 16 + (lane & 15);
@@ -229,6 +210,44 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
             if (m < p.M && n < p.N) epilogue_store<bf16_t>(p, m, n, acc[i][j], add_bias, atomic);
         }
     }
+}
+
+template <bool A_KC, bool B_KC, int TBM, int TBN>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD
+    // a contiguous run of tiles along N (they share the same A rows -> L2 hits).
+    const int ntx = gridDim.x, nty = gridDim.y, ntiles = ntx * nty;
+    int bid = blockIdx.y * ntx + blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / ntx) * TBM, n0 = (bid % ntx) * TBN;
+    const int nkt = (p.K + BK - 1) / BK;
+    const int per = (nkt + gridDim.z - 1) / gridDim.z;
+    const int kt0 = blockIdx.z * per;
+    const int kt1 = min(nkt, kt0 + per);
+    if (kt0 >= kt1) return;
+    gemm_tile_regstaged<A_KC, B_KC, TBM, TBN>(p, m0, n0, kt0, kt1, smem, gridDim.z > 1, blockIdx.z == 0);
+}
+
+// grouped weight gradients: blockIdx.x enumerates the tiles of all groups (RC x RC, fp32 result)
+template <int TBM, int TBN>
+__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < MEBT_MAX_GROUP; ++i)
+        if (i < w.n && (int)blockIdx.x >= w.tile_start[i]) g = i;
+    const GroupedWgrad::Item& it = w.g[g];
+    const int t = blockIdx.x - w.tile_start[g];
+    GemmParams p;
+    p.A = it.A; p.B = it.B; p.C = it.C; p.C2 = nullptr; p.bias = nullptr; p.aux = nullptr;
+    p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb; p.ldc = it.ldc; p.ld_aux = 0;
+    p.a_kc = 0; p.b_kc = 0; p.epilogue = EPI_NONE; p.c_f32 = 1; p.beta = 0; p.split_k = 1; p.drop.thresh = 0;
+    const int m0 = (t / it.ntx) * TBM, n0 = (t % it.ntx) * TBN;
+    gemm_tile_regstaged<false, false, TBM, TBN>(p, m0, n0, 0, (it.K + BK - 1) / BK, smem, false, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -598,7 +617,28 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     return MEBT_OK;
 }
 
+int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
+    if (dtype != MEBT_BF16) { mebt_set_error("grouped wgrad: bf16 only"); return MEBT_EDTYPE; }
+    int tiles = 0, n = 0;
+    GroupedWgrad c;
+    for (int i = 0; i < w.n; ++i) {          // drop empty products (their C was zero-filled by the caller)
+        if (w.g[i].M <= 0 || w.g[i].N <= 0 || w.g[i].K <= 0) continue;
+        c.g[n] = w.g[i];
+        c.g[n].ntx = (w.g[i].N + 127) / 128;
+        c.tile_start[n] = tiles;
+        tiles += ((w.g[i].M + 127) / 128) * c.g[n].ntx;
+        ++n;
+    }
+    c.n = n;
+    for (int i = n; i <= MEBT_MAX_GROUP; ++i) c.tile_start[i] = tiles;
+    if (!tiles) return MEBT_OK;
+    hipLaunchKernelGGL((wgrad_grouped_kernel<128, 128>), dim3(tiles), dim3(256), 2 * (128 + 128) * BK * 2, stream, c);
+    MEBT_HIP_CHECK(hipGetLastError());
+    return MEBT_OK;
+}
+
 int gemm_init_attributes() {
+    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * BK * 2));
     // dynamic LDS up to 64 KiB
 #define SET_T(AK, BKC, TM_, TN_)                                                                                                  \
     do {                                                                                                                         \

@@ -10,8 +10,8 @@ enum { SITE_ATTN = 0, SITE_PROJ = 1, SITE_MLP = 2, SITE_EMB_SOS = 0xFFFF0, SITE_
 static inline DropCfg make_drop(uint64_t seed, uint32_t site, float p) {
     DropCfg d;
     d.seed = seed; d.site = site;
-    d.thresh = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
-    d.inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    d.thresh = p > 0.f ? (uint32_t)((double)p * 65536.0 + 0.5) : 0u;
+    d.inv_keep = d.thresh ? (float)(65536.0 / (65536.0 - d.thresh)) : 1.0f;
     return d;
 }
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_GELU_BWD = 3 };
@@ -35,6 +35,21 @@ struct GemmParams {
     DropCfg drop;        // EPI_RESID: C = dropout(acc + bias) + aux   (resid_pdrop, reference gpt.py:140,154)
 };
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
+// Up to 8 independent weight-gradient products dW_g = dY_g^T X_g (both operands row-contiguous, fp32
+// result) in ONE launch: at batch 6 a single dW has 64-256 tiles, a layer's worth fills the chip.
+#define MEBT_MAX_GROUP 8
+struct GroupedWgrad {
+    int n;
+    int tile_start[MEBT_MAX_GROUP + 1];
+    struct Item { const void* A; const void* B; float* C; int M, N, K, lda, ldb, ldc, ntx; } g[MEBT_MAX_GROUP];
+};
+int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream);   // fills tile_start / ntx
+struct GroupedColsum {
+    int n;
+    int blk_start[MEBT_MAX_GROUP + 1];
+    struct Item { const void* X; float* out; int M, N, ldx, gx, rpb; } g[MEBT_MAX_GROUP];
+};
+int launch_colsum_grouped(GroupedColsum& c, int dtype, hipStream_t stream);
 int gemm_init_attributes();
 void mebt_gemm_force_split(int s);
 
