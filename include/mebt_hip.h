@@ -94,6 +94,14 @@ int mebt_backward_embed(mebt_model* m, void* ws, mebt_stream_t stream);
 int mebt_adamw_step(mebt_model* m, float* mW, float* vW, float* mP, float* vP, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int32_t step, float grad_scale, mebt_stream_t stream);
 
+/* The same update restricted to one gradient bucket — kind 0: head weight; 1: blocks layer_lo..layer_hi;
+ * 2: the P tail (ln_f + embeddings); 3: everything.  Buckets are disjoint: a caller may issue each on its
+ * own stream as soon as that bucket's gradients are final (after its all-reduce), overlapping the HBM-bound
+ * optimizer with the rest of backward. */
+int mebt_adamw_range(mebt_model* m, float* mW, float* vW, float* mP, float* vP, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int32_t step, float grad_scale, int32_t kind, int32_t layer_hi,
+                     int32_t layer_lo, mebt_stream_t stream);
+
 /* ---- operator entry points (building blocks; also what the parity tests call) ---------------------- */
 /* C[M,N] = sum_k A(m,k) B(n,k) + bias, epilogue 0 none / 1 GELU (C=pre, C2=gelu) / 2 +aux residual /
  * 3 * gelu'(aux).  a_kc/b_kc: 1 = operand stored [rows][K], 0 = stored [K][rows].  Replaces nn.Linear
@@ -154,6 +162,8 @@ void mebt_debug_gemm_tile(int32_t bm, int32_t bn);
 /* Benchmarking / tests only: force the bf16 GEMM staging: 0 register-staged, 2 LDS-DMA 2 stages, 1 LDS-DMA
  * 3-stage ring; -1 restores the measured heuristic. */
 void mebt_debug_gemm_variant(int32_t dma);
+/* Benchmarking only: LDS-DMA ring depth (2 or 3) of the grouped weight-gradient GEMM. */
+void mebt_debug_grouped_stages(int32_t n);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,7 @@ PROTOTYPES = {
     "mebt_backward_layers": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "mebt_backward_embed": (c_i32, [c_vp, c_vp, c_vp]),
     "mebt_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp]),
+    "mebt_adamw_range": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_i32, c_i32, c_i32, c_vp]),
     "mebt_op_gemm": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 13 + [c_vp]),
     "mebt_op_layernorm_fwd": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "mebt_op_layernorm_bwd": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
@@ -56,6 +57,7 @@ PROTOTYPES = {
     "mebt_debug_side_stream": (None, [c_vp, c_i32]),
     "mebt_debug_gemm_tile": (None, [c_i32, c_i32]),
     "mebt_debug_gemm_variant": (None, [c_i32]),
+    "mebt_debug_grouped_stages": (None, [c_i32]),
     "mebt_profile_enable": (c_i32, [c_i32]),
     "mebt_profile_read": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

@@ -74,6 +74,41 @@ __device__ __forceinline__ bf16x8 frag_cols(const char* tile, int cb, int kk, in
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
+// The fragment byte offsets depend only on the lane: computed once per kernel, the loop adds the stage base.
+struct FragOffsets {
+    int rows[4][2];        // frag_rows(blk16, ks)
+    int cols[4][2][2];     // frag_cols(cb, kk): the two transposed reads
+    __device__ __forceinline__ void init(int lane) {
+        const int g = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int row = b * 16 + i, c = 4 * ks + g;
+                rows[b][ks] = row * 128 + ((c ^ swz(row)) << 4);
+            }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ch = 2 * cb + (pp >> 1);
+                const int r0 = 32 * kk + 4 * g + q4, r1 = r0 + 16;
+                cols[cb][kk][0] = r0 * 128 + ((ch ^ swz(r0)) << 4) + 8 * (pp & 1);
+                cols[cb][kk][1] = r1 * 128 + ((ch ^ swz(r1)) << 4) + 8 * (pp & 1);
+            }
+    }
+    __device__ __forceinline__ bf16x8 row_frag(const char* tile, int b, int ks) const {
+        return *reinterpret_cast<const bf16x8*>(tile + rows[b][ks]);
+    }
+    __device__ __forceinline__ bf16x8 col_frag(const char* tile, int cb, int kk) const {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + cols[cb][kk][0]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + cols[cb][kk][1]));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+};
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; exp2(-inf) = 0
+
 // two 16-row accumulators (rows 4g+r of blocks 2kk and 2kk+1) -> B operand of the next product
 __device__ __forceinline__ bf16x8 pack_acc(const f32x4& a, const f32x4& b) {
     bf16x8 v = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
@@ -116,6 +151,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnParams p) {
     lv.init(V, p.NK, p.ldv, tid);
     const int ntiles = (p.NK + TILE - 1) / TILE;
     const float c = 0.125f * LOG2E;     // 1/sqrt(64) folded with log2(e)
+    FragOffsets fo;
+    fo.init(lane);
 
     f32x4 o[4];
 #pragma unroll
@@ -139,26 +176,29 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnParams p) {
         for (int kb = 0; kb < 4; ++kb) {
             s[kb] = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) s[kb] = MFMA(frag_rows(sK, kb, ks, lane), qf[ks], s[kb]);
+            for (int ks = 0; ks < 2; ++ks) s[kb] = MFMA(fo.row_frag(sK, kb, ks), qf[ks], s[kb]);
         }
         const int k0 = t * TILE;
         float tmax = -INFINITY;
+        if (k0 + TILE > p.NK) {         // ragged last tile only: keys beyond NK are masked out
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + 16 * kb + 4 * g + r >= p.NK) s[kb][r] = -INFINITY;
+        }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + 16 * kb + 4 * g + r;
-                s[kb][r] = key < p.NK ? s[kb][r] * c : -INFINITY;
-                tmax = fmaxf(tmax, s[kb][r]);
-            }
-        tmax = group_max(tmax);
+            for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kb][r]);
+        tmax = group_max(tmax) * c;                       // c > 0: max commutes with the scale
         const float mn = fmaxf(m, tmax);
-        const float alpha = exp2f(m - mn);
+        const float alpha = fast_exp2(m - mn);
         float ps = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[kb][r] = exp2f(s[kb][r] - mn); ps += s[kb][r]; }
+            for (int r = 0; r < 4; ++r) { s[kb][r] = fast_exp2(fmaf(s[kb][r], c, -mn)); ps += s[kb][r]; }
         ps = group_sum(ps);
         l = l * alpha + ps;
         m = mn;
@@ -176,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnParams p) {
         for (int kk = 0; kk < 2; ++kk) {
             const bf16x8 pf = pack_acc(s[2 * kk], s[2 * kk + 1]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = MFMA(frag_cols(sV, e, kk, lane), pf, o[e]);
+            for (int e = 0; e < 4; ++e) o[e] = MFMA(fo.col_frag(sV, e, kk), pf, o[e]);
         }
         if (more) {
             char* d = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
@@ -227,6 +267,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const AttnParams p) {
     lv.init(V, p.NK, p.ldv, tid);
     const int ntiles = (p.NK + TILE - 1) / TILE;
     const float c = 0.125f * LOG2E;
+    FragOffsets fo;
+    fo.init(lane);
 
     f32x4 dq[4];
 #pragma unroll
@@ -249,13 +291,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const AttnParams p) {
             f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                s = MFMA(frag_rows(sK, kb, ks, lane), qf[ks], s);      // S^T[key][q]
-                dp = MFMA(frag_rows(sV, kb, ks, lane), gf[ks], dp);    // dP^T[key][q] = V dO^T
+                s = MFMA(fo.row_frag(sK, kb, ks), qf[ks], s);      // S^T[key][q]
+                dp = MFMA(fo.row_frag(sV, kb, ks), gf[ks], dp);    // dP^T[key][q] = V dO^T
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + 16 * kb + 4 * g + r;
-                const float pr = key < p.NK ? exp2f(s[r] * c - lse2) : 0.f;
+                const float pr = key < p.NK ? fast_exp2(fmaf(s[r], c, -lse2)) : 0.f;
                 const float keep = p.drop.thresh ? drop_keep(p.drop, (((uint64_t)b * p.H + h) * p.NQ + q) * p.NK + key) : 1.0f;
                 ds[kb][r] = pr * (dp[r] * keep - delta) * 0.125f;
             }
@@ -265,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const AttnParams p) {
         for (int kk = 0; kk < 2; ++kk) {
             const bf16x8 df = pack_acc(ds[2 * kk], ds[2 * kk + 1]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dq[e] = MFMA(frag_cols(sK, e, kk, lane), df, dq[e]);
+            for (int e = 0; e < 4; ++e) dq[e] = MFMA(fo.col_frag(sK, e, kk), df, dq[e]);
         }
         if (more) {
             char* d = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
@@ -307,6 +349,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const AttnParams p) {
     lg.init(G, p.NQ, p.lddo, tid);
     const int ntiles = (p.NQ + TILE - 1) / TILE;
     const float c = 0.125f * LOG2E;
+    FragOffsets fo;
+    fo.init(lane);
 
     f32x4 dk[4], dv[4];
 #pragma unroll
@@ -340,13 +384,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const AttnParams p) {
             f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                s = MFMA(frag_rows(sQ, qb, ks, lane), kf[ks], s);      // S[q][key]
-                dp = MFMA(frag_rows(sG, qb, ks, lane), vf[ks], dp);    // dP[q][key] = dO V^T
+                s = MFMA(fo.row_frag(sQ, qb, ks), kf[ks], s);      // S[q][key]
+                dp = MFMA(fo.row_frag(sG, qb, ks), vf[ks], dp);    // dP[q][key] = dO V^T
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = 16 * qb + 4 * g + r;
-                const float pv = exp2f(s[r] * c - cl[qi]);
+                const float pv = fast_exp2(fmaf(s[r], c, -cl[qi]));
                 const float keep = p.drop.thresh ? drop_keep(p.drop, (((uint64_t)b * p.H + h) * p.NQ + t * TILE + qi) * p.NK + key) : 1.0f;
                 ds[qb][r] = pv * (dp[r] * keep - cd[qi]) * 0.125f;
                 pr[qb][r] = pv * keep;
@@ -359,8 +403,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const AttnParams p) {
             const bf16x8 df = pack_acc(ds[2 * kk], ds[2 * kk + 1]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                dv[e] = MFMA(frag_cols(sG, e, kk, lane), pf, dv[e]);
-                dk[e] = MFMA(frag_cols(sQ, e, kk, lane), df, dk[e]);
+                dv[e] = MFMA(fo.col_frag(sG, e, kk), pf, dv[e]);
+                dk[e] = MFMA(fo.col_frag(sQ, e, kk), df, dk[e]);
             }
         }
         if (more) {

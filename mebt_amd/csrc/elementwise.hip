@@ -68,27 +68,25 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedBwdParams p) 
     if (row >= per_b * p.B) return;
     const int b = (int)(row / per_b);
     const int r = (int)(row % per_b);
+    // float atomics run at full rate only when a wave-instruction covers contiguous bytes: lane l adds
+    // element l + 64k (256 contiguous bytes per instruction), not 4 consecutive elements per lane
     if (r < p.NC) {
         const long pos = p.ci[(size_t)b * p.NC + r];
         const long tok = p.x_ids[(size_t)b * p.N + pos];
         const float* g = p.g_ctx + ((size_t)b * p.NC + r) * p.d;
         float* gt = p.g_tok_emb + (size_t)tok * p.d;
         float* gp = p.g_pos_emb + (size_t)pos * p.d;
-        for (int e = lane * 4; e < p.d; e += 256) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(g + e);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { atomicAdd(gt + e + j, v[j]); atomicAdd(gp + e + j, v[j]); }
+        for (int e = lane; e < p.d; e += 64) {
+            const float v = g[e];
+            atomicAdd(gt + e, v);
+            atomicAdd(gp + e, v);
         }
     } else {
         const int j0 = r - p.NC;
         const long pos = p.ti[(size_t)b * p.NT + j0];
         const T* g = reinterpret_cast<const T*>(p.g_tgt) + ((size_t)b * p.NT + j0) * p.d;
         float* gp = p.g_pos_emb + (size_t)pos * p.d;
-        for (int e = lane * 4; e < p.d; e += 256) {
-            const f32x4 v = load4<T>(g + e);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(gp + e + j, v[j]);
-        }
+        for (int e = lane; e < p.d; e += 64) atomicAdd(gp + e, to_f32<T>(g[e]));
     }
 }
 

@@ -807,10 +807,15 @@ extern "C" int mebt_backward_embed(mebt_model* m, void* ws, mebt_stream_t stream
 // ---------------------------------------------------------------------------------------------------
 // optimiser
 // ---------------------------------------------------------------------------------------------------
-extern "C" int mebt_adamw_step(mebt_model* m, float* mW, float* vW, float* mP, float* vP, float lr, float beta1, float beta2,
-                               float eps, float weight_decay, int32_t step, float grad_scale, mebt_stream_t stream) {
+// AdamW over one gradient bucket: kind 0 = head weight, 1 = blocks layer_lo..layer_hi (their W and P
+// slices), 2 = the P tail (ln_f, mask/sos/pos/tok embeddings), 3 = everything.  Buckets are disjoint,
+// so the caller may run each one on its own stream as soon as that bucket's gradients are final.
+extern "C" int mebt_adamw_range(mebt_model* m, float* mW, float* vW, float* mP, float* vP, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, int32_t step, float grad_scale, int32_t kind, int32_t layer_hi,
+                                int32_t layer_lo, mebt_stream_t stream) {
     if (!m || !m->W || !m->gW || !m->gP) { mebt_set_error("adamw: model / gradients not bound"); return MEBT_EINVAL; }
     if (step < 1) { mebt_set_error("adamw: step must be >= 1"); return MEBT_EINVAL; }
+    if (kind == 1 && (layer_hi >= m->d.n_layer || layer_lo < 0 || layer_lo > layer_hi)) { mebt_set_error("adamw: bad layer range"); return MEBT_EINVAL; }
     hipStream_t st = S(stream);
     AdamWParams a;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale;
@@ -821,21 +826,29 @@ extern "C" int mebt_adamw_step(mebt_model* m, float* mW, float* vW, float* mP, f
         a.p_bf16 = lp ? (void*)((char*)lp + off * 2) : nullptr;
         return launch_adamw(a, st);
     };
-    // contiguous runs of live layers (torch skips parameters whose grad is None)
-    int i = 0;
-    while (i < m->d.n_layer) {
-        if (!m->live[i]) { ++i; continue; }
-        int j = i;
-        while (j + 1 < m->d.n_layer && m->live[j + 1]) ++j;
-        RC(run(m->W, m->gW, mW, vW, m->Wlp, m->lo[i].wq, (int64_t)(j - i + 1) * 12 * d * d, weight_decay));
-        RC(run(m->P, m->gP, mP, vP, nullptr, m->lo[i].ln1w, (int64_t)(j - i + 1) * 13 * d, 0.f));
-        i = j + 1;
+    if (kind == 1 || kind == 3) {   // contiguous runs of live layers (torch skips parameters whose grad is None)
+        const int lo = kind == 3 ? 0 : layer_lo, hi = kind == 3 ? m->d.n_layer - 1 : layer_hi;
+        int i = lo;
+        while (i <= hi) {
+            if (!m->live[i]) { ++i; continue; }
+            int j = i;
+            while (j + 1 <= hi && m->live[j + 1]) ++j;
+            RC(run(m->W, m->gW, mW, vW, m->Wlp, m->lo[i].wq, (int64_t)(j - i + 1) * 12 * d * d, weight_decay));
+            RC(run(m->P, m->gP, mP, vP, nullptr, m->lo[i].ln1w, (int64_t)(j - i + 1) * 13 * d, 0.f));
+            i = j + 1;
+        }
     }
-    RC(run(m->W, m->gW, mW, vW, m->Wlp, m->head_w, (int64_t)m->d.vocab * d, weight_decay));
-    // ln_f, mask_emb, sos_emb, pos_emb (always reached) and tok_emb (only through a live latent_enc)
-    const int64_t tail_n = (m->tok_live ? m->n_p : m->tok_emb) - m->lnf_w;
-    RC(run(m->P, m->gP, mP, vP, nullptr, m->lnf_w, tail_n, 0.f));
+    if (kind == 0 || kind == 3) RC(run(m->W, m->gW, mW, vW, m->Wlp, m->head_w, (int64_t)m->d.vocab * d, weight_decay));
+    if (kind == 2 || kind == 3) {   // ln_f, mask_emb, sos_emb, pos_emb (always reached) and tok_emb (only through a live latent_enc)
+        const int64_t tail_n = (m->tok_live ? m->n_p : m->tok_emb) - m->lnf_w;
+        RC(run(m->P, m->gP, mP, vP, nullptr, m->lnf_w, tail_n, 0.f));
+    }
     return MEBT_OK;
+}
+
+extern "C" int mebt_adamw_step(mebt_model* m, float* mW, float* vW, float* mP, float* vP, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int32_t step, float grad_scale, mebt_stream_t stream) {
+    return mebt_adamw_range(m, mW, vW, mP, vP, lr, beta1, beta2, eps, weight_decay, step, grad_scale, 3, 0, 0, stream);
 }
 
 // Test hook: the keep-scale (0 or 1/(1-p)) of elements 0..n-1 of a dropout site, as the kernels compute it.

@@ -71,6 +71,39 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
     }
 }
 
+// Epilogue through LDS.  The MFMA accumulators hold, per lane, 4 consecutive columns of ONE row of each
+// 16x16 fragment, so a direct store instruction touches 16 rows x 32 bytes — a quarter of every 128-byte
+// line for the C store and for the aux / residual loads.  After the k-loop the LDS ring is idle: each
+// wave parks its (TM*16) x (TN*16) fp32 tile there (padded rows: conflict-free ds_write_b128), then walks
+// it row-contiguously, 4 columns per lane, so every global access of the epilogue covers whole rows of the
+// wave's tile (TN*32 bytes of bf16 per row).
+template <int TM, int TN, typename TA>
+__device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x4 (&acc)[TM][TN], char* smem, int wave, int lane,
+                                                 int mbase, int nbase, bool add_bias, bool atomic) {
+    constexpr int COLS = TN * 16, LD = COLS + 4;          // fp32 elements per staged row
+    float* st = reinterpret_cast<float*>(smem) + wave * (16 * LD);   // one 16-row slab per wave (<= 4.3 KiB)
+    constexpr int LPR = COLS / 4;                         // lanes per row
+    constexpr int RPI = 64 / LPR;                         // rows per pass
+    const int r0 = lane / LPR, c4 = (lane % LPR) * 4;
+    __syncthreads();                                      // every wave is done reading the last k-tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            *reinterpret_cast<f32x4*>(st + (lane & 15) * LD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+        // the same wave reads back what it wrote (LDS operations of a wave execute in order): only its LDS
+        // queue has to drain, no workgroup barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; r += RPI) {
+            const int row = r + r0;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * LD + c4);
+            const int m = mbase + i * 16 + row, n = nbase + c4;
+            if (m < p.M && n < p.N) epilogue_store<TA>(p, m, n, v, add_bias, atomic);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16 kernel, templated on the block tile (TBM x TBN in {128,64}) so that small outputs still fill
 // 256 CUs: 4 waves as 2x2, each wave (TBM/2) x (TBN/2) = (TBM/32) x (TBN/32) MFMA tiles of 16x16.
@@ -201,15 +234,7 @@ __device__ __forceinline__ void gemm_tile_regstaged(const GemmParams& p, int m0,
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (TBM / 2) + i * 16 + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (TBN / 2) + j * 16 + 4 * (lane >> 4);
-            if (m < p.M && n < p.N) epilogue_store<bf16_t>(p, m, n, acc[i][j], add_bias, atomic);
-        }
-    }
+    epilogue_via_lds<TM, TN, bf16_t>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
 }
 
 template <bool A_KC, bool B_KC, int TBM, int TBN>
@@ -232,24 +257,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     gemm_tile_regstaged<A_KC, B_KC, TBM, TBN>(p, m0, n0, kt0, kt1, smem, gridDim.z > 1, blockIdx.z == 0);
 }
 
-// grouped weight gradients: blockIdx.x enumerates the tiles of all groups (RC x RC, fp32 result)
-template <int TBM, int TBN>
-__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int g = 0;
-#pragma unroll
-    for (int i = 1; i < MEBT_MAX_GROUP; ++i)
-        if (i < w.n && (int)blockIdx.x >= w.tile_start[i]) g = i;
-    const GroupedWgrad::Item& it = w.g[g];
-    const int t = blockIdx.x - w.tile_start[g];
-    GemmParams p;
-    p.A = it.A; p.B = it.B; p.C = it.C; p.C2 = nullptr; p.bias = nullptr; p.aux = nullptr;
-    p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb; p.ldc = it.ldc; p.ld_aux = 0;
-    p.a_kc = 0; p.b_kc = 0; p.epilogue = EPI_NONE; p.c_f32 = 1; p.beta = 0; p.split_k = 1; p.drop.thresh = 0;
-    const int m0 = (t / it.ntx) * TBM, n0 = (t % it.ntx) * TBN;
-    gemm_tile_regstaged<false, false, TBM, TBN>(p, m0, n0, 0, (it.K + BK - 1) / BK, smem, false, false);
-}
-
 // ------------------------------------------------------------------------------------------------
 // bf16 kernel, direct-to-LDS variant: the same LDS images and fragment reads, but the tiles are
 // written by `buffer_load_dwordx4 ... lds` (no VGPR round trip, no ds_write) into a 3-stage ring, so
@@ -259,6 +266,19 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w
 // (a __syncthreads() would drain the DMA queue).
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+// One LDS-DMA instruction as inline asm: hipcc models the builtin form as a store to LDS and then drains
+// the whole DMA queue (s_waitcnt vmcnt(0)) in front of every ds_read_b64_tr_b16, which defeats the ring
+// for the transposed-operand layouts.  In asm the compiler sees no memory operation; completion is
+// tracked by the counted waits of the kernel.  M0 (the LDS base of the DMA) is saved and restored inside
+// the statement because the compiler owns it.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(rsrc)
+                 : "memory");
+}
 
 template <bool KC, int ROWS>
 struct DmaLoader {
@@ -299,32 +319,20 @@ struct DmaLoader {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const uint32_t off = ok[i] ? goff[i] + (uint32_t)kt * step : (uint32_t)MEBT_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(tile + (4 * i + wave) * 1024), 16, off, 0, 0, 0);
+            dma16(rsrc, (unsigned)(size_t)(lds_char_ptr)(tile + (4 * i + wave) * 1024), off);
         }
     }
 };
 
+// one output tile (m0, n0), k-tiles [kt0, kt1): LDS-DMA ring main loop + epilogue
 template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n0, int kt0, int kt1, char* smem, bool atomic, bool add_bias) {
     constexpr int STAGE = (TBM + TBN) * BK * 2;
     constexpr int TM = TBM / 32, TN = TBN / 32;
     constexpr int LPT = (TBM + TBN) / 32;              // DMA instructions per wave per tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntx = gridDim.x, nty = gridDim.y, ntiles = ntx * nty;
-    int bid = blockIdx.y * ntx + blockIdx.x;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int m0 = (bid / ntx) * TBM, n0 = (bid % ntx) * TBN;
-    const int nkt = (p.K + BK - 1) / BK;
-    const int per = (nkt + gridDim.z - 1) / gridDim.z;
-    const int kt0 = blockIdx.z * per;
-    const int kt1 = min(nkt, kt0 + per);
-    if (kt0 >= kt1) return;
     const int nk = kt1 - kt0;
 
     DmaLoader<A_KC, TBM> la;
@@ -378,18 +386,43 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams p) 
         }
         if (++st == NSTAGE) st = 0;
     }
+    epilogue_via_lds<TM, TN, bf16_t>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
+}
 
-    const bool atomic = gridDim.z > 1;
-    const bool add_bias = blockIdx.z == 0;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (TBM / 2) + i * 16 + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (TBN / 2) + j * 16 + 4 * (lane >> 4);
-            if (m < p.M && n < p.N) epilogue_store<bf16_t>(p, m, n, acc[i][j], add_bias, atomic);
-        }
+template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
+__global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntx = gridDim.x, nty = gridDim.y, ntiles = ntx * nty;
+    int bid = blockIdx.y * ntx + blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int m0 = (bid / ntx) * TBM, n0 = (bid % ntx) * TBN;
+    const int nkt = (p.K + BK - 1) / BK;
+    const int per = (nkt + gridDim.z - 1) / gridDim.z;
+    const int kt0 = blockIdx.z * per;
+    const int kt1 = min(nkt, kt0 + per);
+    if (kt0 >= kt1) return;
+    gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE>(p, m0, n0, kt0, kt1, smem, gridDim.z > 1, blockIdx.z == 0);
+}
+
+// grouped weight gradients: blockIdx.x enumerates the tiles of all groups (RC x RC, fp32 result)
+template <int TBM, int TBN, int NSTAGE>
+__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < MEBT_MAX_GROUP; ++i)
+        if (i < w.n && (int)blockIdx.x >= w.tile_start[i]) g = i;
+    const GroupedWgrad::Item& it = w.g[g];
+    const int t = blockIdx.x - w.tile_start[g];
+    GemmParams p;
+    p.A = it.A; p.B = it.B; p.C = it.C; p.C2 = nullptr; p.bias = nullptr; p.aux = nullptr;
+    p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb; p.ldc = it.ldc; p.ld_aux = 0;
+    p.a_kc = 0; p.b_kc = 0; p.epilogue = EPI_NONE; p.c_f32 = 1; p.beta = 0; p.split_k = 1; p.drop.thresh = 0;
+    const int m0 = (t / it.ntx) * TBM, n0 = (t % it.ntx) * TBN;
+    gemm_tile_dma<false, false, TBM, TBN, NSTAGE>(p, m0, n0, 0, (it.K + BK - 1) / BK, smem, false, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -529,6 +562,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 // ------------------------------------------------------------------------------------------------
 static int g_gemm_force_split = 0;
 static int g_gemm_force_tile = 0;     // (BM << 8) | BN, benchmarking only
+static int g_grouped_stages = 2;
+extern "C" void mebt_debug_grouped_stages(int n) { g_grouped_stages = n; }
 static int g_gemm_dma = -1;           // -1 heuristic; forced: 0 register-staged, 2 LDS-DMA 2 stages, 1 LDS-DMA 3 stages
 extern "C" void mebt_debug_gemm_variant(int dma) { g_gemm_dma = dma; }
 void mebt_gemm_force_split(int s) { g_gemm_force_split = s; }
@@ -552,18 +587,13 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     int tbm = 128, tbn = 128, staging = 2;
     if (dtype == MEBT_BF16) {
         const long n128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-        if (!p.a_kc || !p.b_kc) {        // dgrad / wgrad: an operand is read column-wise; register staging wins (cold operands)
-            staging = 0;
-            if (n128 >= 900) { tbm = 128; tbn = 128; staging = 2; }
-            else if (n128 >= 700) { tbm = 128; tbn = 128; }
-            else if (n128 >= 256) { tbm = 128; tbn = 64; }
-            else { tbm = 64; tbn = 64; }
-        } else {                         // forward: both operands k-contiguous; deeper LDS-DMA rings when few tiles
-            if (n128 >= 384) { tbm = 128; tbn = 128; staging = 2; }
-            else if (n128 > 256) { tbm = 128; tbn = 64; staging = 2; }
-            else if (n128 >= 160) { tbm = 128; tbn = 128; staging = 3; }
-            else { tbm = 128; tbn = 64; staging = 4; }
-        }
+        // cold-operand measurements (profiles/r01_gemm_variants_cold.txt), all three layouts alike:
+        // many tiles -> 128x128 with 2 stages (2 workgroups/CU); a chip's worth or less -> deeper rings
+        if (n128 >= 384) { tbm = 128; tbn = 128; staging = 2; }
+        else if (n128 > 256) { tbm = 128; tbn = 64; staging = 2; }
+        else if (n128 >= 160) { tbm = 128; tbn = 128; staging = 3; }
+        else if (n128 > 64) { tbm = 64; tbn = 128; staging = p.K >= 2048 ? 4 : 3; }
+        else { tbm = 64; tbn = 64; staging = 4; }
         if (g_gemm_force_tile) { tbm = g_gemm_force_tile >> 8; tbn = g_gemm_force_tile & 255; }
         if (g_gemm_dma >= 0) staging = g_gemm_dma == 1 ? 3 : g_gemm_dma;       // forced: 0 reg, 2..5 LDS-DMA stages (1 = 3)
     }
@@ -632,13 +662,15 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
     c.n = n;
     for (int i = n; i <= MEBT_MAX_GROUP; ++i) c.tile_start[i] = tiles;
     if (!tiles) return MEBT_OK;
-    hipLaunchKernelGGL((wgrad_grouped_kernel<128, 128>), dim3(tiles), dim3(256), 2 * (128 + 128) * BK * 2, stream, c);
+    if (g_grouped_stages == 3) hipLaunchKernelGGL((wgrad_grouped_kernel<128, 128, 3>), dim3(tiles), dim3(256), 3 * (128 + 128) * BK * 2, stream, c);
+    else hipLaunchKernelGGL((wgrad_grouped_kernel<128, 128, 2>), dim3(tiles), dim3(256), 2 * (128 + 128) * BK * 2, stream, c);
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;
 }
 
 int gemm_init_attributes() {
-    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * BK * 2));
+    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<128, 128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * BK * 2));
+    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<128, 128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BK * 2));
     // dynamic LDS up to 64 KiB
 #define SET_T(AK, BKC, TM_, TN_)                                                                                                  \
     do {                                                                                                                         \

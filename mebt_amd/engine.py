@@ -66,6 +66,8 @@ class NativeModel:
         nw, np_ = C.c_int64(), C.c_int64()
         check(self.lib.mebt_model_param_counts(self.h, C.byref(nw), C.byref(np_)))
         self.n_w, self.n_p = nw.value, np_.value
+        if os.environ.get("MEBT_GROUPED_STAGES"):
+            self.lib.mebt_debug_grouped_stages(int(os.environ["MEBT_GROUPED_STAGES"]))
         if os.environ.get("MEBT_SIDE_STREAM", "1") == "0":
             self.lib.mebt_debug_side_stream(self.h, 0)
         self.n_layer, self.n_embd, self.vocab, self.n_latent = n_layer, n_embd, vocab, n_latent
@@ -195,9 +197,21 @@ class NativeModel:
         if between:
             between("embed", None, None)
 
-    def adamw_step(self, lr, weight_decay, step, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0):
+    def _adam_state(self):
         if self.adam is None:
             self.adam = [torch.zeros_like(self.W), torch.zeros_like(self.W), torch.zeros_like(self.P), torch.zeros_like(self.P)]
+        return self.adam
+
+    def adamw_range(self, kind, hi, lo, lr, weight_decay, step, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0, stream=None):
+        """AdamW on one gradient bucket ('head' | 'layers' | 'embed'), on `stream` (default: current)."""
+        mW, vW, mP, vP = self._adam_state()
+        k = {"head": 0, "layers": 1, "embed": 2, "all": 3}[kind]
+        check(self.lib.mebt_adamw_range(self.h, ptr(mW), ptr(vW), ptr(mP), ptr(vP), float(lr), float(betas[0]), float(betas[1]),
+                                        float(eps), float(weight_decay), int(step), float(grad_scale), k, int(hi or 0), int(lo or 0),
+                                        stream if stream is not None else cur_stream()))
+
+    def adamw_step(self, lr, weight_decay, step, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0):
+        self._adam_state()
         mW, vW, mP, vP = self.adam
         check(self.lib.mebt_adamw_step(self.h, ptr(mW), ptr(vW), ptr(mP), ptr(vP), float(lr), float(betas[0]),
                                        float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale),
@@ -224,3 +238,12 @@ class NativeModel:
 
     def head_w_range(self):
         return self.n_layer * 12 * self.n_embd * self.n_embd, self.n_w
+
+    def layer_p_range(self, hi, lo):
+        """[start, end) element range in P / gP of the LN-affine and bias slices of layers lo..hi."""
+        per = 13 * self.n_embd
+        return lo * per, (hi + 1) * per
+
+    def tail_p_range(self):
+        """ln_f + mask/sos/pos/tok embeddings"""
+        return self.n_layer * 13 * self.n_embd, self.n_p

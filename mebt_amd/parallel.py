@@ -24,20 +24,28 @@ class GradReducer:
         self.pending = []
         self.bytes_reduced = 0
 
-    # called by the engine right after the kernels producing a bucket have been enqueued
+    # called right after the kernels producing a bucket have been enqueued on the current stream
     def bucket_ready(self, native, stage, hi, lo):
+        """Launch the asynchronous all-reduce(s) of the gradient slices that `stage` finalised; returns the
+        list of work handles (empty when world_size == 1)."""
         if self.world_size == 1:
-            return
+            return []
         if stage == "head":
             a, b = native.head_w_range()
-            view = native.gW[a:b]
+            views = [native.gW[a:b]]
         elif stage == "layers":
             a, b = native.layer_w_range(hi, lo)
-            view = native.gW[a:b]
-        else:                       # 'embed': every P-side gradient (LN, biases, embeddings) is final
-            view = native.gP
-        self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self.bytes_reduced += view.numel() * view.element_size()
+            c, d = native.layer_p_range(hi, lo)
+            views = [native.gW[a:b], native.gP[c:d]]
+        else:                       # 'embed': ln_f + embedding gradients are final
+            c, d = native.tail_p_range()
+            views = [native.gP[c:d]]
+        works = []
+        for v in views:
+            works.append(dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.bytes_reduced += v.numel() * v.element_size()
+        self.pending += works
+        return works
 
     def wait(self):
         """make the compute stream wait for every outstanding bucket (no host synchronisation on GPU)"""

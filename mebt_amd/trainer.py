@@ -2,6 +2,7 @@
 bucketed all-reduce overlap -> fused AdamW, all on the engine, no host synchronisation inside.
 Counterpart of what Lightning's fit loop does around the reference's training_step / optimizer_step
 (SURVEY.md §3.1)."""
+import os
 import random
 
 import numpy as np
@@ -11,7 +12,10 @@ from .parallel import GradReducer
 
 
 class TrainLoop:
-    def __init__(self, model, reducer=None, max_steps=0):
+    def __init__(self, model, reducer=None, max_steps=0, overlap_optimizer=None):
+        if overlap_optimizer is None:   # pays when there is an all-reduce to hide behind; on one GPU both contend for HBM
+            world = reducer.world_size if reducer is not None else 1
+            overlap_optimizer = os.environ.get("MEBT_OVERLAP_OPT", "1" if world > 1 else "0") != "0"
         """model: mebt_amd.transformer.Net2NetTransformer on its GPU, with learning_rate /
         warmup_steps / weight_decay / cosine_lr set (train_transformer.py:54-66)."""
         self.model = model
@@ -22,6 +26,10 @@ class TrainLoop:
         self.step_count = 0
         model.trainer.max_steps = max_steps
         self.reducer.broadcast_parameters(self.native)
+        # the optimizer runs bucket by bucket on its own stream, as soon as a bucket's gradients are final
+        # (after its all-reduce when data-parallel): AdamW streams 30 B/parameter through HBM while the rest
+        # of backward is latency/compute-bound, so the two overlap almost perfectly
+        self.opt_stream = torch.cuda.Stream(device=self.native.device) if overlap_optimizer else None
 
     def step(self, x, indices, t=None):
         """x [B,T,H,W] int64 tokens, indices [B,N] permutations.  Returns a device tensor
@@ -36,13 +44,28 @@ class TrainLoop:
         ci, ti = ci.contiguous(), ti.contiguous()
         ratio = float(seq_len - ci.shape[1]) / float(seq_len)
         scale = 1.0 / (B * seq_len * ratio ** m.config.avg_loss)
-        logits = nm.forward(x_ids, ci, ti, training=True, dropout_seed=m._next_seed())
-        stats = nm.loss_stats(logits)
-        nm.backward(logits, scale, between=lambda s, hi, lo: red.bucket_ready(nm, s, hi, lo))
-        red.wait()
         lr = m.learning_rate * m.lr_scale()
         self.step_count += 1
-        nm.adamw_step(lr, m.weight_decay, self.step_count, grad_scale=red.grad_scale)
+        logits = nm.forward(x_ids, ci, ti, training=True, dropout_seed=m._next_seed())
+        stats = nm.loss_stats(logits)
+        if self.opt_stream is None:
+            nm.backward(logits, scale, between=lambda s, hi, lo: red.bucket_ready(nm, s, hi, lo))
+            red.wait()
+            nm.adamw_step(lr, m.weight_decay, self.step_count, grad_scale=red.grad_scale)
+        else:
+            main, opt = torch.cuda.current_stream(), self.opt_stream
+
+            def bucket(stage, hi, lo):
+                works = red.bucket_ready(nm, stage, hi, lo)         # async all-reduce of this bucket's slices ([] when N = 1)
+                opt.wait_stream(main)                               # the bucket's gradients are enqueued on `main`
+                with torch.cuda.stream(opt):
+                    for w in works:
+                        w.wait()                                    # ... and reduced across ranks
+                    nm.adamw_range(stage, hi, lo, lr, m.weight_decay, self.step_count, grad_scale=red.grad_scale)
+
+            nm.backward(logits, scale, between=bucket)
+            red.pending = []
+            main.wait_stream(opt)                                   # the next forward reads the updated weights
         m.trainer.global_step += 1
         m.global_step += 1
         return torch.cat([stats, (stats[0] * scale).reshape(1)])

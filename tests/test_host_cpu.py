@@ -132,6 +132,10 @@ def _dp_worker(rank, world, port, ret):
                 return lo * per_l, (hi + 1) * per_l
             def head_w_range(self):
                 return self.n_layer * 12 * self.n_embd * self.n_embd, self.gW.numel()
+            def layer_p_range(self, hi, lo):
+                return lo * 13 * self.n_embd, (hi + 1) * 13 * self.n_embd
+            def tail_p_range(self):
+                return self.n_layer * 13 * self.n_embd, self.gP.numel()
         nat = FakeNative()
         Wn, Pn = flat_layout(cfg.n_layer)
         st = orc.TrainState(P, lr=1e-3, weight_decay=0.05)
