@@ -15,7 +15,8 @@ def per_kernel(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        k = "gemm_bf16" if "gemm_bf16" in r["Kernel_Name"] else r["Kernel_Name"].split("(")[0][-60:]
+        name = r["Kernel_Name"]
+        k = "gemm_bf16" if ("gemm_bf16" in name or "wgrad_grouped" in name) else name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
         tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"])
         n[k] = n.get(k, 0) + 1
     return tot, n
