@@ -441,11 +441,12 @@ def scatter_ids(partial, ti, ids):
 
 def sample(P, cfg, x, n_steps, temperature, top_k, top_p, context_temperature, noise_fn,
            strategy="maskgit", ctemp_schedule="linear", schedule=None, ci=None, ti=None,
-           edit=False, logits_fn=None, trace=None):
+           edit=False, logits_fn=None, trace=None, return_probs=False):
     """mebt/transformer.py:353-447.  `noise_fn(tag, shape)` supplies every random draw in call
     order: tags 'sample' (:407 -> :837), 'mask' (:444 -> mask_sampler.py:182), 'randn'
     (mask_sampler.py:207).  `logits_fn(x_ids, ci, ti)` overrides the network (used to drive the
-    oracle's bookkeeping from HIP logits).  Returns (x [B,N], ci, ti)."""
+    oracle's bookkeeping from HIP logits).  Returns (x [B,N], ci, ti), plus the `debug=True`
+    probability map [B,N,V] (-1 where never sampled, :395,:426-436) with `return_probs`."""
     B = x.shape[0]
     N = int(np.prod(x.shape[1:]))
     edit_N = ti.shape[1] if edit else N                                   # :373-376
@@ -459,6 +460,7 @@ def sample(P, cfg, x, n_steps, temperature, top_k, top_p, context_temperature, n
     if logits_fn is None:
         logits_fn = lambda xi, c, t_: reconstruct_mask(P, cfg, xi, c, t_)
     partial = x
+    partial_probs = -torch.ones(B, N, cfg.vocab_size) if return_probs else None   # :395
     for t_next in np.linspace(0, 1, n_steps + 1)[1:]:                     # :391,:397
         tt = torch.full((B,), fill_value=t_next)                          # :398 (float32 on purpose)
         n_masked = torch.ceil(schedule_value(sched, tt) * edit_N)         # :399
@@ -469,6 +471,8 @@ def sample(P, cfg, x, n_steps, temperature, top_k, top_p, context_temperature, n
                                         noise_fn("sample", logits.shape))  # :407
         scores = probs.gather(-1, ids.unsqueeze(-1)).squeeze(-1)          # :409
         partial = scatter_ids(partial, ti, ids)                           # :413-439
+        if return_probs:                                                  # :426-436
+            partial_probs.scatter_(1, ti.unsqueeze(-1).expand(-1, -1, probs.shape[-1]), probs)
         ctemp = context_temperature * ctemp_factor(ctemp_schedule, t_next)  # :440
         if trace is not None:
             trace.append({"NC": ci.shape[1], "NT": ti.shape[1], "ids": ids.clone(),
@@ -476,7 +480,63 @@ def sample(P, cfg, x, n_steps, temperature, top_k, top_p, context_temperature, n
         rn = noise_fn("randn", scores.shape) if strategy in ("random", "bootstrap") else None
         ci, ti = generate_next_mask(ci, ti, scores, n_masked[0].long(), strategy, ctemp,
                                     lambda: noise_fn("mask", scores.shape), rn)   # :444
+    if return_probs:
+        return partial.view(B, -1), ci, ti, partial_probs
     return partial.view(B, -1), ci, ti
+
+
+def bidirect_sample(P, cfg, batch_size, total_length, step_size, context_size, temperature, top_k, top_p,
+                    vid_n_steps, vid_c_temp, noise_fn, ctemp_schedule="linear", strategy="maskgit", bootstrap=0):
+    """sample_vqgan_transformer_videos.py:22-94 without the VQGAN decode: returns (code_map
+    [B,T',H,W], score [B]).  The score gathers over the first window only (the reference's gather
+    :89-92 only type-checks when no sliding-window continuation happened)."""
+    T, H, W = cfg.shape
+    step, ctx = int(step_size * 0.25), int(context_size * 0.25)           # :29-31
+    shape = (batch_size, step, H, W)
+    x = torch.zeros(shape, dtype=torch.long)
+    ci = ti = boot = None
+    if bootstrap > 0:                                                     # :41-42
+        x, ci, ti, boot = sample(P, cfg, x, bootstrap, 1., None, None, vid_c_temp, noise_fn, strategy="bootstrap",
+                                 ctemp_schedule=ctemp_schedule, ci=ci, ti=ti, return_probs=True)
+    x, ci, _, final = sample(P, cfg, x.reshape(shape), vid_n_steps, temperature, top_k, top_p, vid_c_temp, noise_fn,
+                             strategy=strategy, ctemp_schedule=ctemp_schedule, ci=ci, ti=ti, return_probs=True)   # :43-46
+    vq = x.reshape(shape)
+    code_map, curr_t = [vq], step
+    while curr_t < total_length * 0.25:                                   # :55-71
+        new_x = torch.zeros(shape, dtype=torch.long)
+        new_x[:, :ctx] = vq[:, -ctx:]
+        ci = torch.arange(H * W * ctx).repeat(batch_size, 1)
+        ti = torch.arange((step - ctx) * H * W).repeat(batch_size, 1) + H * W * ctx
+        x = sample(P, cfg, new_x, vid_n_steps, temperature, top_k, top_p, vid_c_temp, noise_fn, strategy=strategy,
+                   ctemp_schedule=ctemp_schedule, ci=ci, ti=ti)[0]
+        vq = x.reshape(shape)
+        code_map.append(vq[:, ctx:])
+        curr_t += step - ctx
+    code_map = torch.cat(code_map, 1)
+    prob_map = final if boot is None else torch.where(final < 0., boot, final)        # :86-88
+    first = code_map.reshape(batch_size, -1)[:, :prob_map.shape[1]]
+    score = torch.gather(prob_map, -1, first.unsqueeze(-1)).squeeze(-1).log().sum(-1)  # :89-92
+    return code_map, score
+
+
+def extrapolate(P, cfg, vq_input, total_length, step_size, context_size, temperature, top_k, top_p,
+                vid_n_steps, vid_c_temp, noise_fn):
+    """sample_vqgan_transformer_videos.py:96-157 without the VQGAN decode: returns the code map."""
+    B, T, H, W = vq_input.shape
+    step, ctx = int(step_size * 0.25), int(context_size * 0.25)
+    assert T == step                                                      # :106
+    jump = step - ctx
+    n_jumps = int(np.ceil((int(total_length * 0.25) - step) / jump))      # :108-112
+    idx = torch.arange(H * W * step).repeat(B, 1).view(B, step, H, W)
+    ci, ti = idx[:, :ctx].reshape(B, -1), idx[:, ctx:].reshape(B, -1)     # :128-131
+    code_map, x = [vq_input.clone()], vq_input
+    for _ in range(n_jumps):                                              # :135-145
+        nxt = torch.zeros_like(x)
+        nxt[:, :ctx] = code_map[-1][:, -ctx:]
+        x = sample(P, cfg, nxt.view(B, -1), vid_n_steps, temperature, top_k, top_p, vid_c_temp, noise_fn,
+                   ci=ci, ti=ti, edit=True)[0].view(B, step, H, W)
+        code_map.append(x[:, ctx:].clone())
+    return torch.cat(code_map, 1)
 
 
 def gibbs_revise_masks(ci, ti, n_steps, perms):

@@ -427,6 +427,58 @@ def gen_train():
         save(f"train_{name}", **out)
 
 
+def gen_script_drivers():
+    """bidirect_sample / extrapolate of reference sample_vqgan_transformer_videos.py:22-157 on the
+    micro config.  Only import-time names of the script are stubbed (matplotlib, omegaconf, the heavy
+    `mebt` package attributes); the pixel decode (3D-VQGAN, outside this path) is a dummy."""
+    import importlib.util
+    for name in ("matplotlib", "matplotlib.pyplot", "omegaconf", "mebt.data", "pytorch_lightning.callbacks"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["matplotlib"].pyplot = sys.modules["matplotlib.pyplot"]
+    sys.modules["omegaconf"].OmegaConf = object
+    sys.modules["mebt.data"].preprocess = None
+    sys.modules["pytorch_lightning.callbacks"].ModelCheckpoint = object
+    sys.modules["pytorch_lightning"].callbacks = sys.modules["pytorch_lightning.callbacks"]
+    import mebt
+    import mebt.utils as mu
+    from mebt.transformer import Net2NetTransformer
+    for n in ("VideoData", "load_vqgan", "load_transformer"):
+        setattr(mebt, n, None)
+    mebt.Net2NetTransformer = Net2NetTransformer
+    if not hasattr(mu, "save_video_grid"):
+        mu.save_video_grid = None
+    spec = importlib.util.spec_from_file_location("ref_sample_script", f"{REF}/sample_vqgan_transformer_videos.py")
+    script = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(script)
+
+    class DummyDecoder:                      # stands in for the VQGAN decode: [B,T,H,W] ids -> [B,3,4T,8H,8W] zeros
+        def decode(self, code_map):
+            b, t, h, w = code_map.shape
+            return torch.zeros(b, 3, 4 * t, 8 * h, 8 * w)
+
+    out = {}
+    model, _ = build_reference("micro", schedule="cosine")
+    model.eval()
+    model.first_stage_model = DummyDecoder()
+    rng = ClosedFormRNG()
+    patch_rng(rng)
+    log = script.bidirect_sample(model, 2, 8, 8, 4, temperature=1.0, top_k=None, top_p=None, vid_n_steps=4, vid_c_temp=3.0,
+                                 ctemp_schedule='linear', strategy='maskgit', bootstrap=3)
+    out["bi_code_maps"], out["bi_score"], out["bi_ndraws"] = log["code_maps"], log["score"], np.array(rng.k)
+    rng = ClosedFormRNG()
+    patch_rng(rng)
+    log = script.bidirect_sample(model, 2, 8, 8, 4, temperature=0.9, top_k=64, top_p=None, vid_n_steps=3, vid_c_temp=2.0,
+                                 ctemp_schedule='linear', strategy='maskgit', bootstrap=0)
+    out["bi2_code_maps"], out["bi2_score"], out["bi2_ndraws"] = log["code_maps"], log["score"], np.array(rng.k)
+    rng = ClosedFormRNG()
+    patch_rng(rng)
+    vq0, _ = inputs("micro", 2, "extrap")
+    log = script.extrapolate(model, vq0, 16, 8, 4, temperature=1.0, top_k=None, top_p=None, vid_n_steps=3, vid_c_temp=2.5)
+    out["ex_vq0"], out["ex_code_maps"], out["ex_ndraws"] = vq0, log["code_maps"], np.array(rng.k)
+    save("script_drivers", **out)
+
+
 def _shared_step_with_t(model, x, idx, t):
     """shared_step (:717-732) with the python RNG draw `t` (:228) forced."""
     orig = random.random
@@ -446,6 +498,7 @@ def main():
     gen_sampler_ops()
     gen_sample_loops()
     gen_train()
+    gen_script_drivers()
 
 
 if __name__ == "__main__":

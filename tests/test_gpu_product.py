@@ -87,6 +87,40 @@ def test_draft_and_revise_bit_exact():
         assert (xs.cpu().numpy() == g[f"d{i}_x"]).all(), i
 
 
+def test_script_drivers_bit_exact():
+    """bidirect_sample / extrapolate (sample_vqgan_transformer_videos.py:22-157) against vectors produced by
+    the reference script's own functions (tests/golden/make_golden.py:gen_script_drivers)."""
+    from mebt_amd.sampling import bidirect_sample, extrapolate
+    g = load_golden("script_drivers")
+    model = build_product("micro", "f32", schedule="cosine").eval()
+    hook, state = closed_form_hook()
+    model.noise_hook = hook
+    log = bidirect_sample(model, 2, 8, 8, 4, temperature=1.0, top_k=None, top_p=None, vid_n_steps=4, vid_c_temp=3.0,
+                          ctemp_schedule='linear', strategy='maskgit', bootstrap=3)
+    assert state["k"] == int(g["bi_ndraws"]) and (log["code_maps"].cpu().numpy() == g["bi_code_maps"]).all()
+    np.testing.assert_allclose(log["score"].cpu().numpy(), g["bi_score"], rtol=1e-4)
+    assert "samples" not in log and log["class_label"].shape == (2, 1)
+    hook, state = closed_form_hook()
+    model.noise_hook = hook
+    log = bidirect_sample(model, 2, 8, 8, 4, temperature=0.9, top_k=64, top_p=None, vid_n_steps=3, vid_c_temp=2.0)
+    assert state["k"] == int(g["bi2_ndraws"]) and (log["code_maps"].cpu().numpy() == g["bi2_code_maps"]).all()
+    np.testing.assert_allclose(log["score"].cpu().numpy(), g["bi2_score"], rtol=1e-4)
+    hook, state = closed_form_hook()
+    model.noise_hook = hook
+    log = extrapolate(model, torch.from_numpy(g["ex_vq0"]).to(DEV), 16, 8, 4, temperature=1.0, vid_n_steps=3, vid_c_temp=2.5)
+    assert state["k"] == int(g["ex_ndraws"]) and (log["code_maps"].cpu().numpy() == g["ex_code_maps"]).all()
+    # sliding-window continuation: equals the oracle driven by the same noise
+    hook, _ = closed_form_hook()
+    model.noise_hook = hook
+    log = bidirect_sample(model, 2, 16, 8, 4, vid_n_steps=3, vid_c_temp=2.0)
+    noise_fn, _, _ = mg.oracle_noise_fns()
+    cfg = mg.oracle_cfg("micro", schedule="cosine")
+    with torch.no_grad():
+        cm, score = orc.bidirect_sample(orc.closed_form_params(cfg), cfg, 2, 16, 8, 4, 1.0, None, None, 3, 2.0, noise_fn)
+    assert (log["code_maps"].cpu() == cm).all()
+    np.testing.assert_allclose(log["score"].cpu().numpy(), score.numpy(), rtol=1e-4)
+
+
 def test_sample_debug_tuple_and_gpt_forward_boundary():
     model = build_product("micro", "f32", schedule="cosine").eval()
     hook, _ = closed_form_hook()

@@ -138,6 +138,28 @@ def test_sample_loops():
         assert (xs.numpy() == g[f"d{i}_x"]).all(), i
 
 
+def test_script_drivers():
+    """bidirect_sample / extrapolate (sample_vqgan_transformer_videos.py:22-157)."""
+    g = load("script_drivers")
+    P, cfg = params("micro"), mg.oracle_cfg("micro", schedule="cosine")
+    with torch.no_grad():
+        noise_fn, _, st = mg.oracle_noise_fns()
+        cm, score = orc.bidirect_sample(P, cfg, 2, 8, 8, 4, 1.0, None, None, 4, 3.0, noise_fn, bootstrap=3)
+        assert st["k"] == int(g["bi_ndraws"]) and (cm.numpy() == g["bi_code_maps"]).all()
+        np.testing.assert_allclose(score.numpy(), g["bi_score"], rtol=1e-5)
+        noise_fn, _, st = mg.oracle_noise_fns()
+        cm, score = orc.bidirect_sample(P, cfg, 2, 8, 8, 4, 0.9, 64, None, 3, 2.0, noise_fn)
+        assert st["k"] == int(g["bi2_ndraws"]) and (cm.numpy() == g["bi2_code_maps"]).all()
+        np.testing.assert_allclose(score.numpy(), g["bi2_score"], rtol=1e-5)
+        noise_fn, _, st = mg.oracle_noise_fns()
+        cm = orc.extrapolate(P, cfg, torch.from_numpy(g["ex_vq0"]), 16, 8, 4, 1.0, None, None, 3, 2.5, noise_fn)
+        assert st["k"] == int(g["ex_ndraws"]) and cm.shape == (2, 4, 4, 4) and (cm.numpy() == g["ex_code_maps"]).all()
+        # sliding-window continuation of bidirect_sample (the reference cannot score this case): shape + context carry-over
+        noise_fn, _, _ = mg.oracle_noise_fns()
+        cm, score = orc.bidirect_sample(P, cfg, 2, 16, 8, 4, 1.0, None, None, 3, 2.0, noise_fn)
+        assert cm.shape == (2, 4, 4, 4) and torch.isfinite(score).all()
+
+
 @pytest.mark.parametrize("name", ["micro", "micro_budget"])
 def test_train_steps(name):
     g = load("train_" + name)
