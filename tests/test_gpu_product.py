@@ -179,3 +179,33 @@ def test_lightning_style_training_steps(name, path):
         model.trainer.global_step += 1
         pn = np.array([float(sd[n].detach().double().norm()) for n in names])
         np.testing.assert_allclose(pn, g[f"s{s}_pnorm"], rtol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["micro", "micro_budget"])
+@pytest.mark.parametrize("overlap", [False, True])
+def test_trainloop_steps_vs_golden(name, overlap):
+    """TrainLoop (what bench.py and the launcher drive): loss and parameter norms after each step equal the
+    reference's (tests/golden/train_*.npz); with `overlap_optimizer` the bucket-wise `mebt_adamw_range` calls
+    on the optimizer stream must give the same parameters as the single `mebt_adamw_step` (not bitwise: the
+    embedding gradients are accumulated with float atomics, whose order differs from run to run)."""
+    from mebt_amd.trainer import TrainLoop
+    g = load_golden("train_" + name)
+    names = [str(n) for n in g["names"]]
+    finals = []
+    for ov in ([False, True] if overlap else [False]):
+        model = build_product(name, "f32").train()
+        model.learning_rate, model.weight_decay, model.warmup_steps, model.cosine_lr = float(g["lr"]), float(g["wd"]), 0, False
+        loop = TrainLoop(model, overlap_optimizer=ov)
+        for s, t in enumerate(g["ts"]):
+            x, idx = torch.from_numpy(g[f"s{s}_x"]).to(DEV), torch.from_numpy(g[f"s{s}_indices"]).to(DEV)
+            stats = loop.step(x, idx, t=float(t)).cpu().numpy()
+            meta = g[f"s{s}_meta"]
+            assert abs(stats[4] - meta[0]) < 5e-5 * abs(meta[0]), (s, stats[4], meta[0])
+            sd = model.state_dict()
+            pn = np.array([float(sd[n].double().norm()) for n in names])
+            np.testing.assert_allclose(pn, g[f"s{s}_pnorm"], rtol=2e-5)
+        finals.append({k: v.clone() for k, v in model.state_dict().items()})
+    if overlap:
+        for k in finals[0]:
+            d = (finals[0][k] - finals[1][k]).abs().max().item()
+            assert d < 1e-6, (k, d)
