@@ -91,11 +91,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = "nccl"                                      # RCCL
+    if os.environ.get("MEBT_BENCH_SHARE_GPU") == "1":     # functional check of the N>1 path on a 1-GPU box: all ranks on GPU 0, gloo
+        local_rank, backend = 0, "gloo"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=device if backend == "nccl" else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     # the Sky config trains with embd/resid/attn dropout 0.1 (configs/stl/mebt_16f.yaml:12-14): the measured

@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--variants", action="store_true")
+ap.add_argument("--torch", action="store_true", help="calibration column: torch.matmul (hipBLASLt/rocBLAS) on the same operands")
 ap.add_argument("--cold", action="store_true", help="rotate operands through a >600 MB pool (HBM-cold, like in the real step)")
 args = ap.parse_args()
 lib = _lib.load()
@@ -74,5 +75,19 @@ for label, cnt, M, N, K, akc, bkc, cf32, split in shapes:
             var += f" |{bm}x{bn} " + "/".join(r)
         lib.mebt_debug_gemm_tile(0, 0)
         lib.mebt_debug_gemm_variant(-1)
+    if args.torch:
+        Ct = torch.empty(M, N, device="cuda", dtype=tt)
+        def run():
+            i = ctr[0] % pool
+            ctr[0] += 1
+            a = A[i] if akc else A[i].t()
+            b = B[i].t() if bkc else B[i]
+            torch.matmul(a, b, out=Ct)
+        ust = timeit()
+        tot_t = globals().get("tot_t", 0.0) + cnt * ust * 1e-3
+        globals()["tot_t"] = tot_t
+        var += f" | torch {ust:7.1f} us {fl / ust / 1e6:6.0f} TF/s"
     print(f"{label:24s} {cnt:3d} {M:6d} {N:6d} {K:6d}  {us:8.1f} {fl / us / 1e6:7.1f}{var}")
+if args.torch:
+    print(f"torch.matmul step total: {globals()['tot_t']:.2f} ms")
 print(f"step total: {tot_ms:.2f} ms, {tot_fl / 1e12:.2f} TFLOP -> {tot_fl / tot_ms / 1e9:.0f} TF/s")
