@@ -99,10 +99,19 @@ __device__ __forceinline__ long map_row(long r, int seg, int seg_stride, int seg
     return seg > 0 ? (r / seg) * (long)seg_stride + seg_off + (r % seg) : r;
 }
 
+struct LnFwdMulti { LnFwdParams j[MEBT_LN_MAXJ]; int blk_start[MEBT_LN_MAXJ + 1]; int n; };
+struct LnBwdMulti { LnBwdParams j[MEBT_LN_MAXJ]; int blk_start[MEBT_LN_MAXJ + 1]; int rpw[MEBT_LN_MAXJ]; int n; };
+
+// one wave per row, 4 rows per workgroup; the workgroups of all jobs are enumerated by blockIdx.x
 template <typename T>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdParams p) {
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdMulti mj) {
+    int job = 0;
+#pragma unroll
+    for (int i = 1; i < MEBT_LN_MAXJ; ++i)
+        if (i < mj.n && (int)blockIdx.x >= mj.blk_start[i]) job = i;
+    const LnFwdParams& p = mj.j[job];
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long row = (long)(blockIdx.x - mj.blk_start[job]) * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const T* x = reinterpret_cast<const T*>(p.x) + (size_t)row * p.d;
     f32x4 v[LN_MAXC];
@@ -143,73 +152,266 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdParams p) {
     if (p.mean && lane == 0) { p.mean[orow] = mean; p.rstd[orow] = rstd; }
 }
 
-// LayerNorm backward, two kernels:
-//  (1) dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) [+ dx_add] — one wave per row, full grid;
+// LayerNorm backward, two kernels (each takes several jobs per launch):
+//  (1) dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) [+ dx_add] (+ optional dropout'd copy dx2)
+//      — one wave per row, 4 rows per workgroup;
 //  (2) dgamma += sum_rows dy*xhat, dbeta += sum_rows dy — column reduction (64 columns x a chunk of
 //      rows per workgroup, LDS reduce, ONE atomic per column per workgroup: float atomics collapse
-//      when hundreds of workgroups meet on the same 2*d addresses).
-template <typename T, typename TDX>
-__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const LnBwdParams p) {
+//      when hundreds of workgroups meet on the same 2*d addresses — a fused variant with one adder per
+//      16 rows ran 4x slower than both kernels together).
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const LnBwdMulti mj) {
+    int job = 0;
+#pragma unroll
+    for (int i = 1; i < MEBT_LN_MAXJ; ++i)
+        if (i < mj.n && (int)blockIdx.x >= mj.blk_start[i]) job = i;
+    const LnBwdParams& p = mj.j[job];
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int d = p.d;
+    const long row = (long)(blockIdx.x - mj.blk_start[job]) * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const long mrow = map_row(row, p.seg, p.seg_stride, p.seg_off);
-    const T* x = reinterpret_cast<const T*>(p.x) + (size_t)row * p.d;
-    const T* dy = reinterpret_cast<const T*>(p.dy) + (size_t)mrow * p.d;
-    const T* dy2 = p.dy2 ? reinterpret_cast<const T*>(p.dy2) + (size_t)row * p.d : nullptr;
+    const T* x = reinterpret_cast<const T*>(p.x) + (size_t)row * d;
+    const T* dy = reinterpret_cast<const T*>(p.dy) + (size_t)mrow * d;
+    const T* dy2 = p.dy2 ? reinterpret_cast<const T*>(p.dy2) + (size_t)row * d : nullptr;
     const float mean = p.mean[mrow], rstd = p.rstd[mrow];
     f32x4 xh[LN_MAXC], gy[LN_MAXC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < LN_MAXC; ++c) {
         const int e = lane * 4 + 256 * c;
-        if (e < p.d) {
+        if (e < d) {
             const f32x4 xv = load4<T>(x + e);
-            f32x4 d = load4<T>(dy + e);
-            if (dy2) d += load4<T>(dy2 + e);
+            f32x4 dv = load4<T>(dy + e);
+            if (dy2) dv += load4<T>(dy2 + e);
             const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + e);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 xh[c][j] = (xv[j] - mean) * rstd;
-                gy[c][j] = d[j] * g[j];
+                gy[c][j] = dv[j] * g[j];
                 s1 += gy[c][j];
                 s2 += gy[c][j] * xh[c][j];
             }
         }
     }
-    const float m1 = wave_sum(s1) / p.d, m2 = wave_sum(s2) / p.d;
-    TDX* dx = reinterpret_cast<TDX*>(p.dx) + (size_t)row * p.d;
+    const float m1 = wave_sum(s1) / d, m2 = wave_sum(s2) / d;
+    const bool f32out = sizeof(T) == 4 || p.dx_f32;           // job-uniform: fp32 gradient accumulators (contexts) or T
 #pragma unroll
     for (int c = 0; c < LN_MAXC; ++c) {
         const int e = lane * 4 + 256 * c;
-        if (e < p.d) {
+        if (e < d) {
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = rstd * (gy[c][j] - m1 - xh[c][j] * m2);
-            if (p.dx_add) o += load4<T>(reinterpret_cast<const T*>(p.dx_add) + (size_t)row * p.d + e);
-            if (p.dx_accumulate) o += load4<TDX>(dx + e);
-            store4<TDX>(dx + e, o);
+            if (p.dx_add) o += load4<T>(reinterpret_cast<const T*>(p.dx_add) + (size_t)row * d + e);
+            const size_t oi = (size_t)row * d + e;
+            if (f32out) {
+                float* dx = reinterpret_cast<float*>(p.dx) + oi;
+                if (p.dx_accumulate) o += load4<float>(dx);
+                store4<float>(dx, o);
+            } else {
+                T* dx = reinterpret_cast<T*>(p.dx) + oi;
+                if (p.dx_accumulate) o += load4<T>(dx);
+                store4<T>(dx, o);
+            }
+            if (p.dx2) {
+                f32x4 m = o;                        // mask the value as stored (rounded to the type of dx)
+                if (!f32out) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m[j] = (float)(T)o[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] *= drop_keep(p.drop2, (uint64_t)oi + j);
+                if (f32out) store4<float>(reinterpret_cast<float*>(p.dx2) + oi, m);
+                else store4<T>(reinterpret_cast<T*>(p.dx2) + oi, m);
+            }
         }
     }
 }
 
+// ---- fast paths: d == NCH * 64 * V with V = 16 bytes of T per lane -------------------------------------
+// The generic kernels above guard every 256-element chunk with `e < d` (runtime d): hipcc then branches
+// around each load and waits for it (s_waitcnt vmcnt(0) per chunk), i.e. the row is fetched as a chain of
+// dependent round trips (1.5 TB/s measured).  With the chunk count a template parameter every load of
+// the row is issued before the first use.
+template <typename T> struct LaneVec;
+template <> struct LaneVec<float> { static constexpr int V = 4; };
+template <> struct LaneVec<bf16_t> { static constexpr int V = 8; };
+template <typename T, int V> __device__ __forceinline__ void loadv(const T* p, float (&o)[V]);
+template <> __device__ __forceinline__ void loadv<float, 4>(const float* p, float (&o)[4]) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = v[j];
+}
+template <> __device__ __forceinline__ void loadv<bf16_t, 8>(const bf16_t* p, float (&o)[8]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+}
+template <typename T, int V> __device__ __forceinline__ void storev(T* p, const float (&o)[V]);
+template <> __device__ __forceinline__ void storev<float, 4>(float* p, const float (&o)[4]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+}
+template <> __device__ __forceinline__ void storev<bf16_t, 8>(bf16_t* p, const float (&o)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)o[j];
+    *reinterpret_cast<bf16x8*>(p) = v;
+}
+template <int V> __device__ __forceinline__ void loadf(const float* p, float (&o)[V]) {
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[4 * q + j] = v[j];
+    }
+}
+template <int V> __device__ __forceinline__ void storef(float* p, const float (&o)[V]) {
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) *reinterpret_cast<f32x4*>(p + 4 * q) = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const LnFwdMulti mj) {
+    constexpr int V = LaneVec<T>::V, D = NCH * 64 * V;
+    int job = 0;
+#pragma unroll
+    for (int i = 1; i < MEBT_LN_MAXJ; ++i)
+        if (i < mj.n && (int)blockIdx.x >= mj.blk_start[i]) job = i;
+    const LnFwdParams& p = mj.j[job];
+    const int lane = threadIdx.x & 63;
+    const long row = (long)(blockIdx.x - mj.blk_start[job]) * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const T* x = reinterpret_cast<const T*>(p.x) + (size_t)row * D + lane * V;
+    float v[NCH][V], g[NCH][V], b[NCH][V];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) loadv<T, V>(x + c * 64 * V, v[c]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { loadf<V>(p.gamma + c * 64 * V + lane * V, g[c]); loadf<V>(p.beta + c * 64 * V + lane * V, b[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < V; ++j) s += v[c][j];
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const float t = v[c][j] - mean; q += t * t; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+    const long orow = map_row(row, p.seg, p.seg_stride, p.seg_off);
+    T* y = reinterpret_cast<T*>(p.y) + (size_t)orow * D + lane * V;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float o[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = (v[c][j] - mean) * rstd * g[c][j] + b[c][j];
+        storev<T, V>(y + c * 64 * V, o);
+    }
+    if (p.mean && lane == 0) { p.mean[orow] = mean; p.rstd[orow] = rstd; }
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_dx_fast_kernel(const LnBwdMulti mj) {
+    constexpr int V = LaneVec<T>::V, D = NCH * 64 * V;
+    int job = 0;
+#pragma unroll
+    for (int i = 1; i < MEBT_LN_MAXJ; ++i)
+        if (i < mj.n && (int)blockIdx.x >= mj.blk_start[i]) job = i;
+    const LnBwdParams& p = mj.j[job];
+    const int lane = threadIdx.x & 63;
+    const long row = (long)(blockIdx.x - mj.blk_start[job]) * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const long mrow = map_row(row, p.seg, p.seg_stride, p.seg_off);
+    const size_t ro = (size_t)row * D + lane * V, mo = (size_t)mrow * D + lane * V;
+    const bool f32out = sizeof(T) == 4 || p.dx_f32;
+    // optional operands are loaded unconditionally (from the x row, scaled by 0, when absent): a branch
+    // around a load makes hipcc drain the load queue at the join
+    const T* dy2p = p.dy2 ? reinterpret_cast<const T*>(p.dy2) + ro : reinterpret_cast<const T*>(p.x) + ro;
+    const T* addp = p.dx_add ? reinterpret_cast<const T*>(p.dx_add) + ro : reinterpret_cast<const T*>(p.x) + ro;
+    const float k2 = p.dy2 ? 1.f : 0.f, ka = p.dx_add ? 1.f : 0.f;
+    float xv[NCH][V], dv[NCH][V], g[NCH][V], add[NCH][V], d2[NCH][V];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        loadv<T, V>(reinterpret_cast<const T*>(p.x) + ro + c * 64 * V, xv[c]);
+        loadv<T, V>(reinterpret_cast<const T*>(p.dy) + mo + c * 64 * V, dv[c]);
+        loadv<T, V>(dy2p + c * 64 * V, d2[c]);
+        loadv<T, V>(addp + c * 64 * V, add[c]);
+        loadf<V>(p.gamma + c * 64 * V + lane * V, g[c]);
+    }
+    const float mean = p.mean[mrow], rstd = p.rstd[mrow];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < V; ++j) { dv[c][j] += k2 * d2[c][j]; add[c][j] *= ka; }
+    if (p.dx_accumulate) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float t[V];
+            if (f32out) loadf<V>(reinterpret_cast<const float*>(p.dx) + ro + c * 64 * V, t);
+            else loadv<T, V>(reinterpret_cast<const T*>(p.dx) + ro + c * 64 * V, t);
+#pragma unroll
+            for (int j = 0; j < V; ++j) add[c][j] += t[j];
+        }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            xv[c][j] = (xv[c][j] - mean) * rstd;        // xhat
+            dv[c][j] *= g[c][j];                        // dy * gamma
+            s1 += dv[c][j];
+            s2 += dv[c][j] * xv[c][j];
+        }
+    const float m1 = wave_sum(s1) * (1.0f / D), m2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float o[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = rstd * (dv[c][j] - m1 - xv[c][j] * m2) + add[c][j];
+        const size_t oi = ro + c * 64 * V;
+        if (f32out) storef<V>(reinterpret_cast<float*>(p.dx) + oi, o);
+        else storev<T, V>(reinterpret_cast<T*>(p.dx) + oi, o);
+        if (p.dx2) {
+            float m[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) m[j] = (f32out ? o[j] : (float)(T)o[j]) * drop_keep(p.drop2, (uint64_t)oi + j);
+            if (f32out) storef<V>(reinterpret_cast<float*>(p.dx2) + oi, m);
+            else storev<T, V>(reinterpret_cast<T*>(p.dx2) + oi, m);
+        }
+    }
+}
+
+// blocks of job j: gx = ceil(d/64) column groups x ceil(rows/rpw) row chunks (rpw = rows per workgroup here)
 template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_param_kernel(const LnBwdParams p, int rows_per_block) {
+__global__ __launch_bounds__(256) void ln_bwd_param_kernel(const LnBwdMulti mj) {
     __shared__ float red[2][16][64 + 4];
+    int job = 0;
+#pragma unroll
+    for (int i = 1; i < MEBT_LN_MAXJ; ++i)
+        if (i < mj.n && (int)blockIdx.x >= mj.blk_start[i]) job = i;
+    const LnBwdParams& p = mj.j[job];
+    const int rows_per_block = mj.rpw[job];
+    const int gx = (p.d + 63) / 64;
+    const int lb = blockIdx.x - mj.blk_start[job];
+    const int bx = lb % gx, by = lb / gx;
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int n = blockIdx.x * 64 + cg * 4;
-    const long m0 = (long)blockIdx.y * rows_per_block;
+    const int n = bx * 64 + cg * 4;
+    const long m0 = (long)by * rows_per_block;
     const long m1 = m0 + rows_per_block < p.rows ? m0 + rows_per_block : p.rows;
     f32x4 ag = {0, 0, 0, 0}, ab = {0, 0, 0, 0};
     if (n < p.d)
+#pragma unroll 4
         for (long m = m0 + rl; m < m1; m += 16) {
             const long mrow = map_row(m, p.seg, p.seg_stride, p.seg_off);
             const f32x4 xv = load4<T>(reinterpret_cast<const T*>(p.x) + (size_t)m * p.d + n);
-            f32x4 d = load4<T>(reinterpret_cast<const T*>(p.dy) + (size_t)mrow * p.d + n);
-            if (p.dy2) d += load4<T>(reinterpret_cast<const T*>(p.dy2) + (size_t)m * p.d + n);
+            f32x4 dv = load4<T>(reinterpret_cast<const T*>(p.dy) + (size_t)mrow * p.d + n);
+            if (p.dy2) dv += load4<T>(reinterpret_cast<const T*>(p.dy2) + (size_t)m * p.d + n);
             const float mean = p.mean[mrow], rstd = p.rstd[mrow];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { ag[j] += d[j] * ((xv[j] - mean) * rstd); ab[j] += d[j]; }
+            for (int j = 0; j < 4; ++j) { ag[j] += dv[j] * ((xv[j] - mean) * rstd); ab[j] += dv[j]; }
         }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { red[0][rl][cg * 4 + j] = ag[j]; red[1][rl][cg * 4 + j] = ab[j]; }
@@ -219,7 +421,7 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const LnBwdParams p, 
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += red[which][r][col];
-        const int c = blockIdx.x * 64 + col;
+        const int c = bx * 64 + col;
         if (c < p.d) atomicAdd((which ? p.dbeta : p.dgamma) + c, t);
     }
 }
@@ -239,6 +441,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, i
     const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
     f32x4 acc = {0, 0, 0, 0};
     if (n < N)
+#pragma unroll 8
         for (int m = m0 + rl; m < m1; m += 16) acc += load4<T>(X + (size_t)m * ldx + n);
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[rl][cg * 4 + j] = acc[j];
@@ -268,6 +471,7 @@ __global__ __launch_bounds__(256) void colsum_grouped_kernel(const GroupedColsum
     const int m0 = by * it.rpb, m1 = min(it.M, m0 + it.rpb);
     f32x4 acc = {0, 0, 0, 0};
     if (n < it.N)
+#pragma unroll 8
         for (int m = m0 + rl; m < m1; m += 16) acc += load4<T>(X + (size_t)m * it.ldx + n);
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[rl][cg * 4 + j] = acc[j];
@@ -452,37 +656,86 @@ int launch_embed_bwd(const EmbedBwdParams& p, int dtype, hipStream_t stream) {
     return rc;
 }
 
-int launch_ln_fwd(const LnFwdParams& p, int dtype, hipStream_t stream) {
-    if (p.rows <= 0) return MEBT_OK;
-    if (p.d % 4 || p.d > 256 * LN_MAXC) { mebt_set_error("layernorm: d must be a multiple of 4 and <= 2048"); return MEBT_ESHAPE; }
-    const dim3 grid((p.rows + 3) / 4);
-    if (dtype == MEBT_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, stream, p);
-    CHECK_LAUNCH();
-    return MEBT_OK;
-}
-
-int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream, hipStream_t param_stream, bool use_param_stream) {
-    hipStream_t ps = use_param_stream ? param_stream : stream;
-    if (p.rows <= 0) return MEBT_OK;
-    if (p.d % 4 || p.d > 256 * LN_MAXC) { mebt_set_error("layernorm: d must be a multiple of 4 and <= 2048"); return MEBT_ESHAPE; }
-    const dim3 grid((p.rows + 3) / 4);
-    const int gx = (p.d + 63) / 64;
-    int rpb = 256;
-    while ((p.rows + rpb - 1) / rpb > 32) rpb *= 2;
-    while (rpb > 64 && (long)gx * ((p.rows + rpb - 1) / rpb) < 256) rpb /= 2;
-    const dim3 pgrid(gx, (p.rows + rpb - 1) / rpb);
+int launch_ln_fwd_multi(const LnFwdParams* jobs, int n, int dtype, hipStream_t stream) {
+    LnFwdMulti mj;
+    int k = 0, blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const LnFwdParams& p = jobs[i];
+        if (p.rows <= 0) continue;
+        if (p.d % 4 || p.d > 256 * LN_MAXC) { mebt_set_error("layernorm: d must be a multiple of 4 and <= 2048"); return MEBT_ESHAPE; }
+        if (k == MEBT_LN_MAXJ) { mebt_set_error("layernorm: too many jobs in one launch"); return MEBT_EINVAL; }
+        mj.j[k] = p;
+        mj.blk_start[k] = blocks;
+        blocks += (p.rows + 3) / 4;
+        ++k;
+    }
+    if (!k) return MEBT_OK;
+    mj.n = k;
+    for (int i = k; i <= MEBT_LN_MAXJ; ++i) mj.blk_start[i] = blocks;
+    bool same_d = true;
+    for (int i = 1; i < k; ++i) same_d = same_d && mj.j[i].d == mj.j[0].d;
+    const int d0 = mj.j[0].d;
     if (dtype == MEBT_BF16) {
-        if (p.dx_f32) hipLaunchKernelGGL((ln_bwd_dx_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((ln_bwd_dx_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(ln_bwd_param_kernel<bf16_t>, pgrid, dim3(256), 0, ps, p, rpb);
+        if (same_d && d0 == 1024) hipLaunchKernelGGL((ln_fwd_fast_kernel<bf16_t, 2>), dim3(blocks), dim3(256), 0, stream, mj);
+        else if (same_d && d0 == 512) hipLaunchKernelGGL((ln_fwd_fast_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, stream, mj);
+        else if (same_d && d0 == 2048) hipLaunchKernelGGL((ln_fwd_fast_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 0, stream, mj);
+        else hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, mj);
     } else {
-        hipLaunchKernelGGL((ln_bwd_dx_kernel<float, float>), grid, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(ln_bwd_param_kernel<float>, pgrid, dim3(256), 0, ps, p, rpb);
+        if (same_d && d0 == 1024) hipLaunchKernelGGL((ln_fwd_fast_kernel<float, 4>), dim3(blocks), dim3(256), 0, stream, mj);
+        else if (same_d && d0 == 256) hipLaunchKernelGGL((ln_fwd_fast_kernel<float, 1>), dim3(blocks), dim3(256), 0, stream, mj);
+        else hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, mj);
     }
     CHECK_LAUNCH();
     return MEBT_OK;
 }
+
+int launch_ln_fwd(const LnFwdParams& p, int dtype, hipStream_t stream) { return launch_ln_fwd_multi(&p, 1, dtype, stream); }
+
+int launch_ln_bwd_multi(const LnBwdParams* jobs, int n, int dtype, hipStream_t stream, hipStream_t param_stream) {
+    LnBwdMulti mj, mp;
+    int k = 0, blocks = 0, pblocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const LnBwdParams& p = jobs[i];
+        if (p.rows <= 0) continue;
+        if (p.d % 4 || p.d > 256 * LN_MAXC) { mebt_set_error("layernorm: d must be a multiple of 4 and <= 2048"); return MEBT_ESHAPE; }
+        if (k == MEBT_LN_MAXJ) { mebt_set_error("layernorm: too many jobs in one launch"); return MEBT_EINVAL; }
+        mj.j[k] = p; mp.j[k] = p;
+        mj.rpw[k] = 1;
+        mj.blk_start[k] = blocks;
+        blocks += (p.rows + 3) / 4;
+        const int gx = (p.d + 63) / 64;
+        int rpb = 256;
+        while ((p.rows + rpb - 1) / rpb > 32) rpb *= 2;                                   // <= 32 adders per address
+        while (rpb > 64 && (long)gx * ((p.rows + rpb - 1) / rpb) < 256) rpb /= 2;         // but fill the chip
+        mp.rpw[k] = rpb;
+        mp.blk_start[k] = pblocks;
+        pblocks += gx * ((p.rows + rpb - 1) / rpb);
+        ++k;
+    }
+    if (!k) return MEBT_OK;
+    mj.n = mp.n = k;
+    for (int i = k; i <= MEBT_LN_MAXJ; ++i) { mj.blk_start[i] = blocks; mp.blk_start[i] = pblocks; }
+    hipStream_t ps = param_stream ? param_stream : stream;
+    bool same_d = true;
+    for (int i = 1; i < k; ++i) same_d = same_d && mj.j[i].d == mj.j[0].d;
+    const int d0 = mj.j[0].d;
+    if (dtype == MEBT_BF16) {
+        if (same_d && d0 == 1024) hipLaunchKernelGGL((ln_bwd_dx_fast_kernel<bf16_t, 2>), dim3(blocks), dim3(256), 0, stream, mj);
+        else if (same_d && d0 == 512) hipLaunchKernelGGL((ln_bwd_dx_fast_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, stream, mj);
+        else if (same_d && d0 == 2048) hipLaunchKernelGGL((ln_bwd_dx_fast_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 0, stream, mj);
+        else hipLaunchKernelGGL(ln_bwd_dx_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, mj);
+        hipLaunchKernelGGL(ln_bwd_param_kernel<bf16_t>, dim3(pblocks), dim3(256), 0, ps, mp);
+    } else {
+        if (same_d && d0 == 1024) hipLaunchKernelGGL((ln_bwd_dx_fast_kernel<float, 4>), dim3(blocks), dim3(256), 0, stream, mj);
+        else if (same_d && d0 == 256) hipLaunchKernelGGL((ln_bwd_dx_fast_kernel<float, 1>), dim3(blocks), dim3(256), 0, stream, mj);
+        else hipLaunchKernelGGL(ln_bwd_dx_kernel<float>, dim3(blocks), dim3(256), 0, stream, mj);
+        hipLaunchKernelGGL(ln_bwd_param_kernel<float>, dim3(pblocks), dim3(256), 0, ps, mp);
+    }
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+
+int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream, hipStream_t param_stream) { return launch_ln_bwd_multi(&p, 1, dtype, stream, param_stream); }
 
 int launch_colsum(const void* X, int M, int N, int ldx, float* out, int dtype, hipStream_t stream) {
     if (M <= 0 || N <= 0) return MEBT_OK;

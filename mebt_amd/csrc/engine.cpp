@@ -426,21 +426,31 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         // (LN + KV projection) is independent of the query side: it runs on the side stream.
         const bool side = m->use_side && mode != MEBT_MODE_LATENT_SELF && Mk > 0;
         hipStream_t sk = side ? m->side : st;
-        if (side) RC(fork_side(m, st));
-        RC(ln_fwd(m, a.q_in, a.qn, o.ln1w, o.ln1b, a.mean1q, a.rstd1q, Mq, 0, 0, 0, st));
-        if (mode == MEBT_MODE_LATENT_ENC) {
-            a.k_in = x.ctx;
-            RC(ln_fwd(m, x.ctx, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, Mk, 0, 0, 0, sk));
-        } else if (mode == MEBT_MODE_LATENT_DEC) {
-            a.k_in = Sv;
-            RC(ln_fwd(m, Sv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, Mk, 0, 0, 0, sk));
-        } else if (mode == MEBT_MODE_LT2L) {   // key = LN1(cat[sos, targets]) (gpt.py:175,181)
-            a.k_in = Tv;
-            RC(ln_fwd(m, Sv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, B * NS, NS, NS + NT, 0, sk));
-            RC(ln_fwd(m, Tv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, B * NT, NT, NS + NT, NS, sk));
-        } else {
-            a.k_in = nullptr;
+        {
+            LnFwdParams lj[MEBT_LN_MAXJ];
+            int nj = 0;
+            auto job = [&](const void* xin, void* y, float* mean, float* rstd, int rows, int seg, int seg_stride, int seg_off) {
+                LnFwdParams& p = lj[nj++];
+                p.x = xin; p.y = y; p.gamma = m->P + o.ln1w; p.beta = m->P + o.ln1b; p.mean = mean; p.rstd = rstd;
+                p.rows = rows; p.d = d; p.seg = seg; p.seg_stride = seg_stride; p.seg_off = seg_off;
+            };
+            job(a.q_in, a.qn, a.mean1q, a.rstd1q, Mq, 0, 0, 0);
+            if (mode == MEBT_MODE_LATENT_ENC) {
+                a.k_in = x.ctx;
+                job(x.ctx, a.kn, a.mean1k, a.rstd1k, Mk, 0, 0, 0);
+            } else if (mode == MEBT_MODE_LATENT_DEC) {
+                a.k_in = Sv;
+                job(Sv, a.kn, a.mean1k, a.rstd1k, Mk, 0, 0, 0);
+            } else if (mode == MEBT_MODE_LT2L) {   // key = LN1(cat[sos, targets]) (gpt.py:175,181)
+                a.k_in = Tv;
+                job(Sv, a.kn, a.mean1k, a.rstd1k, B * NS, NS, NS + NT, 0);
+                job(Tv, a.kn, a.mean1k, a.rstd1k, B * NT, NT, NS + NT, NS);
+            } else {
+                a.k_in = nullptr;
+            }
+            RC(launch_ln_fwd_multi(lj, nj, dt, st));
         }
+        if (side) RC(fork_side(m, st));
         if (mode == MEBT_MODE_LATENT_SELF) {
             GemmParams p = gp(a.qn, m->Wop(o.wq), a.q, Mq, 3 * d, d, d, d, 3 * d, 1, 1);
             p.bias = m->P + o.bq;
@@ -696,20 +706,20 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     lv.colsum(sc.d4, Mq, 4 * d, 4 * d, m->gP + o.b1);
     lv.wgrad(sc.d4, 4 * d, a.hn, d, m->gW + o.w1, 4 * d, d, Mq);
     RC(dgrad(m, sc.d4, 4 * d, o.w1, sc.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st));
-    // dx = dout + LN2'(dh)   (dgamma/dbeta reduction on the side stream)
-    if (side) RC(fork_side(m, st));
+    // dx = dout + LN2'(dh); the same kernel reduces dgamma/dbeta and writes the dropout-masked copy the
+    // projection branch reads (x = qn + dropout(att Wp^T + bp))
+    const void* dproj = sc.dx;
     {
         LnBwdParams p;
         p.x = a.x; p.dy = sc.dh; p.dy2 = nullptr; p.dx_add = dout; p.gamma = m->P + o.ln2w; p.mean = a.mean2; p.rstd = a.rstd2;
         p.dx = sc.dx; p.dx_f32 = f32; p.dx_accumulate = 0; p.dgamma = m->gP + o.ln2w; p.dbeta = m->gP + o.ln2b;
         p.rows = Mq; p.d = d; p.seg = 0; p.seg_stride = 0; p.seg_off = 0;
-        RC(launch_ln_bwd(p, dt, st, sd, true));
-    }
-    // x = qn + dropout(att Wp^T + bp)
-    const void* dproj = sc.dx;
-    if (p_res > 0.f) {
-        RC(launch_apply_dropout(sc.dx, sc.dx_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_PROJ, p_res), st));
-        dproj = sc.dx_m;
+        if (p_res > 0.f) {
+            p.dx2 = sc.dx_m; p.drop2 = make_drop(x.drop_seed, 16 * i + SITE_PROJ, p_res);
+            dproj = sc.dx_m;
+        }
+        if (side) RC(fork_side(m, st));
+        RC(launch_ln_bwd(p, dt, st, sd));
     }
     lv.colsum(dproj, Mq, d, d, m->gP + o.bp);
     lv.wgrad(dproj, d, a.att, d, m->gW + o.wp, d, d, Mq);
@@ -729,14 +739,15 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         ap.dk = sc.dqkv_k; ap.dv = (char*)sc.dqkv_k + (size_t)d * esz; ap.lddk = ap.lddv = 2 * d;
     }
     RC(launch_attn_bwd(ap, dt, st));
-    // LN1 backward helper: dx on the main stream, affine grads on the side stream
+    // LN1 backward of the query and key sides: one launch (they share LN1's dgamma/dbeta)
+    LnBwdParams lj[MEBT_LN_MAXJ];
+    int nj = 0;
     auto ln1 = [&](const void* xin, const void* dy, const void* dy2, const float* mean, const float* rstd, void* dxp, int dx_f32, int acc,
-                   int rows, int seg, int seg_stride, int seg_off) -> int {
-        LnBwdParams p;
+                   int rows, int seg, int seg_stride, int seg_off) {
+        LnBwdParams& p = lj[nj++];
         p.x = xin; p.dy = dy; p.dy2 = dy2; p.dx_add = nullptr; p.gamma = m->P + o.ln1w; p.mean = mean; p.rstd = rstd;
         p.dx = dxp; p.dx_f32 = dx_f32 || f32; p.dx_accumulate = acc; p.dgamma = m->gP + o.ln1w; p.dbeta = m->gP + o.ln1b;
         p.rows = rows; p.d = d; p.seg = seg; p.seg_stride = seg_stride; p.seg_off = seg_off;
-        return launch_ln_bwd(p, dt, st, sd, true);
     };
     if (mode == MEBT_MODE_LATENT_SELF) {
         lv.colsum(sc.dqkv_q, Mq, 3 * d, 3 * d, m->gP + o.bq);
@@ -744,7 +755,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         RC(dgrad(m, sc.dqkv_q, 3 * d, o.wq, sc.dqn, Mq, 3 * d, d, EPI_RESID, sc.dx, d, st));   // + dx (residual on qn)
         if (side) RC(fork_side(m, st));
         RC(flush_leaves(m, lv, sd));
-        RC(ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0));
+        ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0);
     } else {
         lv.colsum(sc.dqkv_q, Mq, d, d, m->gP + o.bq);
         lv.wgrad(sc.dqkv_q, d, a.qn, d, m->gW + o.wq, d, d, Mq);
@@ -755,21 +766,22 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         if (side) RC(fork_side(m, st));
         RC(flush_leaves(m, lv, sd));
         if (mode == MEBT_MODE_LATENT_ENC) {
-            RC(ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0));
+            ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0);
             if (Mk > 0) {   // contexts feed every latent_enc block: accumulate in fp32
-                RC(ln1(x.ctx, sc.dkn, nullptr, a.mean1k, a.rstd1k, x.g_C, 1, x.gC_defined ? 1 : 0, Mk, 0, 0, 0));
+                ln1(x.ctx, sc.dkn, nullptr, a.mean1k, a.rstd1k, x.g_C, 1, x.gC_defined ? 1 : 0, Mk, 0, 0, 0);
                 x.gC_defined = true;
             }
         } else if (mode == MEBT_MODE_LATENT_DEC) {
-            RC(ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_T, 0, 0, Mq, 0, 0, 0));
-            RC(ln1(a.k_in, sc.dkn, nullptr, a.mean1k, a.rstd1k, x.g_S, 0, x.gS_defined ? 1 : 0, Mk, 0, 0, 0));
+            ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_T, 0, 0, Mq, 0, 0, 0);
+            ln1(a.k_in, sc.dkn, nullptr, a.mean1k, a.rstd1k, x.g_S, 0, x.gS_defined ? 1 : 0, Mk, 0, 0, 0);
             x.gS_defined = true;
         } else {   // lt2l: key rows [0,NS) come from the same LN as the query
-            RC(ln1(a.q_in, sc.dkn, sc.dqn, a.mean1k, a.rstd1k, x.g_S, 0, 0, B * NS, NS, NS + NT, 0));
-            RC(ln1(a.k_in, sc.dkn, nullptr, a.mean1k, a.rstd1k, x.g_T, 0, x.gT_defined ? 1 : 0, B * NT, NT, NS + NT, NS));
+            ln1(a.q_in, sc.dkn, sc.dqn, a.mean1k, a.rstd1k, x.g_S, 0, 0, B * NS, NS, NS + NT, 0);
+            ln1(a.k_in, sc.dkn, nullptr, a.mean1k, a.rstd1k, x.g_T, 0, x.gT_defined ? 1 : 0, B * NT, NT, NS + NT, NS);
             x.gT_defined = true;
         }
     }
+    RC(launch_ln_bwd_multi(lj, nj, dt, st, sd));
     if (side) MEBT_HIP_CHECK(hipEventRecord(m->ev_layer[i & 1], sd));   // this scratch set is free once the side stream gets here
     return MEBT_OK;
 }

@@ -88,6 +88,9 @@ struct LnFwdParams {
     int rows, d; int seg, seg_stride, seg_off;
 };
 int launch_ln_fwd(const LnFwdParams& p, int dtype, hipStream_t stream);
+// several LayerNorms in ONE launch (the query and key sides of a block share LN1: gpt.py:180-181)
+constexpr int MEBT_LN_MAXJ = 3;
+int launch_ln_fwd_multi(const LnFwdParams* jobs, int n, int dtype, hipStream_t stream);
 struct LnBwdParams {
     const void* x;                // LN input rows [rows,d] T
     const void* dy;               // grad wrt LN output, rows mapped like LnFwdParams (seg..)
@@ -97,9 +100,12 @@ struct LnBwdParams {
     void* dx; int dx_f32; int dx_accumulate;                     // dx (+)= ...
     float* dgamma; float* dbeta;                                 // fp32, atomically accumulated
     int rows, d; int seg, seg_stride, seg_off;
+    void* dx2 = nullptr;          // optional second output: dx * dropout mask `drop2` (element index row*d + e), type of dx
+    DropCfg drop2 = {0, 0, 0, 1.0f};
 };
-// dx on `stream`; the dgamma/dbeta reduction on `param_stream` (a side stream, or the same one)
-int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream, hipStream_t param_stream = nullptr, bool use_param_stream = false);
+// dx on `stream`, the dgamma/dbeta column reduction on `param_stream` (null: the same stream); `n` jobs per launch
+int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream, hipStream_t param_stream = nullptr);
+int launch_ln_bwd_multi(const LnBwdParams* jobs, int n, int dtype, hipStream_t stream, hipStream_t param_stream = nullptr);
 
 // dst[i] = src[i] * keep(site, i)  (dropout mask re-applied in backward); TS/TD chosen by flags
 int launch_apply_dropout(const void* src, void* dst, size_t n, int src_f32, int dst_f32, const DropCfg& d, hipStream_t stream);
