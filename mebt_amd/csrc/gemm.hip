@@ -22,6 +22,9 @@
 // chain (no TF32-like truncation exists on gfx950).
 #include "common.h"
 #include "kernels.h"
+#include <cstdio>
+#include <cstdlib>
+#include <unordered_map>
 
 namespace {
 
@@ -77,14 +80,38 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
 // wave parks its (TM*16) x (TN*16) fp32 tile there (padded rows: conflict-free ds_write_b128), then walks
 // it row-contiguously, 4 columns per lane, so every global access of the epilogue covers whole rows of the
 // wave's tile (TN*32 bytes of bf16 per row).
-template <int TM, int TN, typename TA>
+//
+// Every operand the epilogue reads (bias: one f32x4 per lane, the same for all rows; aux: one 8-byte
+// vector per row pass) is fetched BEFORE the accumulators are staged, all loads back to back at clamped
+// (always valid) addresses: a load under a per-row bounds/epilogue branch makes hipcc wait for it inside
+// the branch, which turned the 16 row passes of a wave into 16-32 dependent L2/HBM round trips.
+template <int TM, int TN>
 __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x4 (&acc)[TM][TN], char* smem, int wave, int lane,
                                                  int mbase, int nbase, bool add_bias, bool atomic) {
+    typedef bf16_t TA;
     constexpr int COLS = TN * 16, LD = COLS + 4;          // fp32 elements per staged row
     float* st = reinterpret_cast<float*>(smem) + wave * (16 * LD);   // one 16-row slab per wave (<= 4.3 KiB)
     constexpr int LPR = COLS / 4;                         // lanes per row
     constexpr int RPI = 64 / LPR;                         // rows per pass
+    constexpr int NPASS = 16 / RPI;
     const int r0 = lane / LPR, c4 = (lane % LPR) * 4;
+    const int n = nbase + c4;
+    const bool n_ok = n < p.N;
+    const int nc = n_ok ? n : 0;
+    const bool need_aux = p.epilogue == EPI_RESID || p.epilogue == EPI_GELU_BWD;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (add_bias && p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + nc);
+    bf16x4 auxr[TM][NPASS];
+    if (need_aux) {
+        const TA* aux = reinterpret_cast<const TA*>(p.aux) + nc;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < NPASS; ++r) {
+                const int m = min(mbase + i * 16 + r * RPI + r0, p.M - 1);
+                auxr[i][r] = *reinterpret_cast<const bf16x4*>(aux + (size_t)m * p.ld_aux);
+            }
+    }
     __syncthreads();                                      // every wave is done reading the last k-tile
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -95,11 +122,44 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x
         // queue has to drain, no workgroup barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < 16; r += RPI) {
-            const int row = r + r0;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * LD + c4);
-            const int m = mbase + i * 16 + row, n = nbase + c4;
-            if (m < p.M && n < p.N) epilogue_store<TA>(p, m, n, v, add_bias, atomic);
+        for (int r = 0; r < NPASS; ++r) {
+            const int row = r * RPI + r0;
+            f32x4 v = *reinterpret_cast<const f32x4*>(st + row * LD + c4);
+            const int m = mbase + i * 16 + row;
+            if (!(m < p.M && n_ok)) continue;
+            v += bias;
+            const size_t ci = (size_t)m * p.ldc + n;
+            if (atomic) {
+                float* c = reinterpret_cast<float*>(p.C) + ci;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(c + j, v[j]);
+                continue;
+            }
+            if (p.epilogue == EPI_GELU) {
+                f32x4 g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = gelu_fast(v[j]);
+                store4<TA>(reinterpret_cast<TA*>(p.C2) + ci, g);
+            } else if (p.epilogue == EPI_RESID) {
+                if (p.drop.thresh) {
+                    const uint64_t e0 = (uint64_t)m * p.N + n;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= drop_keep(p.drop, e0 + j);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)auxr[i][r][j];
+            } else if (p.epilogue == EPI_GELU_BWD) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_fast((float)auxr[i][r][j]);
+            }
+            if (!p.C) continue;                 // EPI_GELU in inference: only gelu(C) is needed
+            if (p.c_f32) {
+                float* c = reinterpret_cast<float*>(p.C) + ci;
+                if (p.beta) v += *reinterpret_cast<const f32x4*>(c);
+                *reinterpret_cast<f32x4*>(c) = v;
+            } else {
+                store4<TA>(reinterpret_cast<TA*>(p.C) + ci, v);
+            }
         }
     }
 }
@@ -114,6 +174,11 @@ constexpr int BM = 128, BN = 128, BK = 64;
 template <int ROWS> __device__ __forceinline__ int rc_swizzle(int krow);
 template <> __device__ __forceinline__ int rc_swizzle<128>(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }          // 256-B rows
 template <> __device__ __forceinline__ int rc_swizzle<64>(int krow) { return (((krow >> 1) & 1) << 1) | (((krow >> 3) & 1) << 2); }   // 128-B rows
+// 192-B rows: k-rows q = 0..3 of a 16-lane group already land 64 B apart; rows r and r+8 (the two groups of a
+// 32-lane half) coincide mod 256 B -> move the second group to the neighbouring 32-B pair
+template <> __device__ __forceinline__ int rc_swizzle<96>(int krow) { return ((krow >> 3) & 1) << 1; }
+// 384-B rows: rows q and q+2 coincide mod 256 B, and so do r and r+8
+template <> __device__ __forceinline__ int rc_swizzle<192>(int krow) { return (((krow >> 1) & 1) << 1) | (((krow >> 3) & 1) << 2); }
 
 template <bool KC, int ROWS>
 struct TileLoader {
@@ -234,7 +299,7 @@ __device__ __forceinline__ void gemm_tile_regstaged(const GemmParams& p, int m0,
         }
         __syncthreads();
     }
-    epilogue_via_lds<TM, TN, bf16_t>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
+    epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
 }
 
 template <bool A_KC, bool B_KC, int TBM, int TBN>
@@ -300,13 +365,13 @@ struct DmaLoader {
                 ok[i] = true;
             }
         } else {
-            constexpr int CPR = ROWS / 8;     // 16-byte slots per k-row; piece = 64/CPR k-rows
-            constexpr int RPP = 64 / CPR;
+            constexpr int CPR = ROWS / 8;     // 16-byte slots per k-row; a 1-KiB piece = 64 consecutive slots of the image
             rsrc = make_rsrc(b, (size_t)K * ld * 2);
             step = (uint32_t)BK * ld * 2;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const int krow = RPP * (4 * i + wave) + lane / CPR, slot = lane % CPR;
+                const int id = 64 * (4 * i + wave) + lane;
+                const int krow = id / CPR, slot = id % CPR;
                 const int c = slot ^ rc_swizzle<ROWS>(krow);
                 const int col = r0 + 8 * c;
                 ok[i] = col < rows;
@@ -386,7 +451,7 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
         }
         if (++st == NSTAGE) st = 0;
     }
-    epilogue_via_lds<TM, TN, bf16_t>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
+    epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
 }
 
 template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
@@ -565,9 +630,110 @@ static int g_gemm_force_tile = 0;     // (BM << 8) | BN, benchmarking only
 static int g_grouped_stages = 2;
 extern "C" void mebt_debug_grouped_stages(int n) { g_grouped_stages = n; }
 static int g_gemm_dma = -1;           // -1 heuristic; forced: 0 register-staged, 2 LDS-DMA 2 stages, 1 LDS-DMA 3 stages
-extern "C" void mebt_debug_gemm_variant(int dma) { g_gemm_dma = dma; }
+static int g_gemm_nostore = 0;        // experiments only (variant >= 100): skip the C store of plain epilogues
+extern "C" void mebt_debug_gemm_variant(int dma) { g_gemm_nostore = dma >= 100; g_gemm_dma = dma >= 100 ? (dma == 199 ? -1 : dma - 100) : dma; }
 void mebt_gemm_force_split(int s) { g_gemm_force_split = s; }
 extern "C" void mebt_debug_gemm_tile(int bm, int bn) { g_gemm_force_tile = (bm && bn) ? ((bm << 8) | bn) : 0; }
+
+// one bf16 launch with an explicit (block tile, staging) choice; staging 0 = register-staged 2 stages,
+// 2..5 = LDS-DMA ring with that many stages (clamped to what the tile's LDS footprint admits)
+static void launch_bf16_config(const GemmParams& p, int tbm, int tbn, int staging, int split, hipStream_t stream) {
+    const dim3 grid((p.N + tbn - 1) / tbn, (p.M + tbm - 1) / tbm, split);
+#define LAUNCH_T(AK, BKC, TM_, TN_)                                                                                   \
+        do {                                                                                                         \
+            if (staging == 5 && 5 * (TM_ + TN_) * BK * 2 <= 160 * 1024) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, (5 * (TM_ + TN_) * BK * 2 <= 160 * 1024 ? 5 : 2)>), grid, dim3(256), 5 * (TM_ + TN_) * BK * 2, stream, p); \
+            else if (staging >= 4) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 4>), grid, dim3(256), 4 * (TM_ + TN_) * BK * 2, stream, p); \
+            else if (staging == 3) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 3>), grid, dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, p); \
+            else if (staging == 2) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 2>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p); \
+            else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC, TM_, TN_>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p);          \
+        } while (0)
+        /* tiles that exist as LDS-DMA kernels only (2..4 stages) */
+#define LAUNCH_D(AK, BKC, TM_, TN_)                                                                                   \
+        do {                                                                                                         \
+            if (staging >= 4 && 4 * (TM_ + TN_) * BK * 2 <= 128 * 1024) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024 ? 4 : 2)>), grid, dim3(256), 4 * (TM_ + TN_) * BK * 2, stream, p); \
+            else if (staging >= 3) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 3>), grid, dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, p); \
+            else hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 2>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p); \
+        } while (0)
+#define LAUNCH_BF16(AK, BKC)                                           \
+        do {                                                           \
+            if (tbm == 128 && tbn == 128) LAUNCH_T(AK, BKC, 128, 128); \
+            else if (tbm == 192 && tbn == 128) LAUNCH_D(AK, BKC, 192, 128); \
+            else if (tbm == 96 && tbn == 128) LAUNCH_D(AK, BKC, 96, 128); \
+            else if (tbm == 96 && tbn == 64) LAUNCH_D(AK, BKC, 96, 64); \
+            else if (tbm == 128 && tbn == 64) LAUNCH_T(AK, BKC, 128, 64); \
+            else if (tbm == 64 && tbn == 128) LAUNCH_T(AK, BKC, 64, 128); \
+            else LAUNCH_T(AK, BKC, 64, 64);                            \
+        } while (0)
+    if (p.a_kc && p.b_kc) LAUNCH_BF16(true, true);
+    else if (p.a_kc && !p.b_kc) LAUNCH_BF16(true, false);
+    else if (!p.a_kc && !p.b_kc) LAUNCH_BF16(false, false);
+    else LAUNCH_BF16(false, true);
+#undef LAUNCH_BF16
+#undef LAUNCH_D
+#undef LAUNCH_T
+}
+
+// ------------------------------------------------------------------------------------------------
+// In-situ autotuning.  A train step has ~25 distinct GEMM signatures and for each one the best block
+// tile is the one whose tile count lands on a whole number of workgroup slots of the 256 CUs
+// (profiles/r01_gemm_variants_cold.txt: up to 1.35x between neighbouring tiles, no closed-form rule
+// survives all shapes).  The first launch of a signature times every (tile, ring depth) candidate on the
+// caller's stream with the caller's operands and keeps the fastest; every candidate computes the same
+// bits (same k order per output element), so results do not depend on the choice.  Only idempotent
+// launches are tuned (no beta accumulation, no split-K atomics).  MEBT_GEMM_AUTOTUNE=0 disables it
+// (heuristic below), MEBT_GEMM_TUNE_LOG=1 prints the choices.
+// ------------------------------------------------------------------------------------------------
+struct TuneKey {
+    int M, N, K, flags;
+    bool operator==(const TuneKey& o) const { return M == o.M && N == o.N && K == o.K && flags == o.flags; }
+};
+struct TuneHash {
+    size_t operator()(const TuneKey& k) const {
+        uint64_t h = (uint64_t)k.M * 0x9E3779B97F4A7C15ull ^ ((uint64_t)k.N << 21) ^ ((uint64_t)k.K << 42) ^ (uint64_t)k.flags * 0xC2B2AE3D27D4EB4Full;
+        return (size_t)(h ^ (h >> 29));
+    }
+};
+static std::unordered_map<TuneKey, int, TuneHash> g_tuned;      // -> (tbm << 16) | (tbn << 8) | staging
+static int g_autotune = -1, g_tune_log = 0;
+
+static void heuristic_config(const GemmParams& p, int& tbm, int& tbn, int& staging) {
+    // cold-operand measurements (profiles/r01_gemm_variants_cold.txt), all three layouts alike:
+    // many tiles -> 128x128 with 2 stages (2 workgroups/CU); a chip's worth or less -> deeper rings
+    const long n128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (n128 >= 384) { tbm = 128; tbn = 128; staging = 2; }
+    else if (n128 > 256) { tbm = 128; tbn = 64; staging = 2; }
+    else if (n128 >= 160) { tbm = 128; tbn = 128; staging = 3; }
+    else if (n128 > 64) { tbm = 64; tbn = 128; staging = p.K >= 2048 ? 4 : 3; }
+    else { tbm = 64; tbn = 64; staging = 4; }
+}
+
+static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, int& tbn, int& staging) {
+    static hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!e0) { MEBT_HIP_CHECK(hipEventCreate(&e0)); MEBT_HIP_CHECK(hipEventCreate(&e1)); }
+    static const int tiles[7][2] = {{192, 128}, {128, 128}, {96, 128}, {128, 64}, {64, 128}, {96, 64}, {64, 64}};
+    const long out = (long)p.M * p.N;
+    float best = 1e30f;
+    for (int t = 0; t < 7; ++t) {
+        const int bm = tiles[t][0], bn = tiles[t][1];
+        const long nt = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+        if (nt < 96 && (long)bm * bn > 64 * 64 && out > 64 * 64) continue;      // would leave most of the chip idle
+        for (int st = 2; st <= 4; ++st) {
+            if (st * (bm + bn) * BK * 2 > 128 * 1024) continue;
+            launch_bf16_config(p, bm, bn, st, 1, stream);                        // warm-up (code object, L2)
+            MEBT_HIP_CHECK(hipEventRecord(e0, stream));
+            for (int r = 0; r < 3; ++r) launch_bf16_config(p, bm, bn, st, 1, stream);
+            MEBT_HIP_CHECK(hipEventRecord(e1, stream));
+            MEBT_HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            MEBT_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = st; }
+        }
+    }
+    if (g_tune_log)
+        fprintf(stderr, "[mebt gemm autotune] M=%d N=%d K=%d a_kc=%d b_kc=%d epi=%d c_f32=%d -> %dx%d ring %d (%.1f us)\n", p.M, p.N, p.K,
+                p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, staging, best * 1e3f / 3);
+    return MEBT_OK;
+}
 
 int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     GemmParams p = p_in;
@@ -580,24 +746,8 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     if (!p.b_kc && (size_t)p.K * p.ldb * esz >= 0x7FFFFFFFull) { mebt_set_error("gemm: RC operand B exceeds 2 GiB"); return MEBT_ESHAPE; }
     if ((!p.a_kc && (p.M % 8)) || (!p.b_kc && (p.N % 8))) { mebt_set_error("gemm: row extent of an RC operand must be a multiple of 8"); return MEBT_ESHAPE; }
     if (dtype == MEBT_F32) p.c_f32 = 1;
+    if (g_gemm_nostore && p.epilogue == EPI_NONE) p.C = nullptr;
     if (p.K <= 0) { mebt_set_error("gemm: K must be positive (empty reductions are handled by the caller)"); return MEBT_ESHAPE; }
-    // tile / staging selection (bf16), measured on MI355X with tools/gemm_bench.py --variants
-    // (profiles/r01_gemm_variants.txt): staging 0 = register-staged 2 stages, 2 = LDS-DMA 2 stages,
-    // 3 = LDS-DMA 3-stage ring.
-    int tbm = 128, tbn = 128, staging = 2;
-    if (dtype == MEBT_BF16) {
-        const long n128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-        // cold-operand measurements (profiles/r01_gemm_variants_cold.txt), all three layouts alike:
-        // many tiles -> 128x128 with 2 stages (2 workgroups/CU); a chip's worth or less -> deeper rings
-        if (n128 >= 384) { tbm = 128; tbn = 128; staging = 2; }
-        else if (n128 > 256) { tbm = 128; tbn = 64; staging = 2; }
-        else if (n128 >= 160) { tbm = 128; tbn = 128; staging = 3; }
-        else if (n128 > 64) { tbm = 64; tbn = 128; staging = p.K >= 2048 ? 4 : 3; }
-        else { tbm = 64; tbn = 64; staging = 4; }
-        if (g_gemm_force_tile) { tbm = g_gemm_force_tile >> 8; tbn = g_gemm_force_tile & 255; }
-        if (g_gemm_dma >= 0) staging = g_gemm_dma == 1 ? 3 : g_gemm_dma;       // forced: 0 reg, 2..5 LDS-DMA stages (1 = 3)
-    }
-    dim3 grid((p.N + tbn - 1) / tbn, (p.M + tbm - 1) / tbm, 1);
     int split = 1;
     const bool can_split = p.c_f32 && p.epilogue == EPI_NONE && p.split_k > 1;   // atomics split-K only on request
     if (can_split) {
@@ -605,34 +755,37 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         split = max(1, min(p.split_k, nkt));
     }
     if (g_gemm_force_split > 0 && p.c_f32 && p.epilogue == EPI_NONE) split = g_gemm_force_split;
-    grid.z = split;
     if (split > 1 && !p.beta) {
         // split-K accumulates with fp32 atomics into a zeroed C
         MEBT_HIP_CHECK(hipMemset2DAsync(p.C, (size_t)p.ldc * 4, 0, (size_t)p.N * 4, p.M, stream));
     }
     if (dtype == MEBT_BF16) {
-#define LAUNCH_T(AK, BKC, TM_, TN_)                                                                                   \
-        do {                                                                                                         \
-            if (staging == 5 && 5 * (TM_ + TN_) * BK * 2 <= 160 * 1024) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, (5 * (TM_ + TN_) * BK * 2 <= 160 * 1024 ? 5 : 2)>), grid, dim3(256), 5 * (TM_ + TN_) * BK * 2, stream, p); \
-            else if (staging >= 4) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 4>), grid, dim3(256), 4 * (TM_ + TN_) * BK * 2, stream, p); \
-            else if (staging == 3) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 3>), grid, dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, p); \
-            else if (staging == 2) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 2>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p); \
-            else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC, TM_, TN_>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p);          \
-        } while (0)
-#define LAUNCH_BF16(AK, BKC)                                           \
-        do {                                                           \
-            if (tbm == 128 && tbn == 128) LAUNCH_T(AK, BKC, 128, 128); \
-            else if (tbm == 128 && tbn == 64) LAUNCH_T(AK, BKC, 128, 64); \
-            else if (tbm == 64 && tbn == 128) LAUNCH_T(AK, BKC, 64, 128); \
-            else LAUNCH_T(AK, BKC, 64, 64);                            \
-        } while (0)
-        if (p.a_kc && p.b_kc) LAUNCH_BF16(true, true);
-        else if (p.a_kc && !p.b_kc) LAUNCH_BF16(true, false);
-        else if (!p.a_kc && !p.b_kc) LAUNCH_BF16(false, false);
-        else LAUNCH_BF16(false, true);
-#undef LAUNCH_BF16
-#undef LAUNCH_T
+        if (g_autotune < 0) {
+            const char* e = getenv("MEBT_GEMM_AUTOTUNE");
+            g_autotune = (e && e[0] == '0') ? 0 : 1;
+            const char* l = getenv("MEBT_GEMM_TUNE_LOG");
+            g_tune_log = (l && l[0] == '1') ? 1 : 0;
+        }
+        int tbm = 128, tbn = 128, staging = 2;
+        const bool forced = g_gemm_force_tile || g_gemm_dma >= 0;
+        const bool idempotent = !p.beta && split == 1 && p.C != p.aux;
+        if (g_autotune && !forced && idempotent && (long)p.M * p.N >= 128 * 128) {
+            const TuneKey key{p.M, p.N, p.K, p.a_kc | (p.b_kc << 1) | (p.epilogue << 2) | (p.c_f32 << 5) | ((p.bias != nullptr) << 6) | ((p.drop.thresh != 0) << 7)};
+            auto it = g_tuned.find(key);
+            if (it == g_tuned.end()) {
+                heuristic_config(p, tbm, tbn, staging);
+                if (int rc = autotune_config(p, stream, tbm, tbn, staging)) return rc;
+                it = g_tuned.emplace(key, (tbm << 16) | (tbn << 8) | staging).first;
+            }
+            tbm = it->second >> 16; tbn = (it->second >> 8) & 255; staging = it->second & 255;
+        } else {
+            heuristic_config(p, tbm, tbn, staging);
+            if (g_gemm_force_tile) { tbm = g_gemm_force_tile >> 8; tbn = g_gemm_force_tile & 255; }
+            if (g_gemm_dma >= 0) staging = g_gemm_dma == 1 ? 3 : g_gemm_dma;       // forced: 0 reg, 2..5 LDS-DMA stages (1 = 3)
+        }
+        launch_bf16_config(p, tbm, tbn, staging, split, stream);
     } else if (dtype == MEBT_F32) {
+        dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, split);
 #define LAUNCH_F32(AK, BKC) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC>), grid, dim3(256), 0, stream, p)
         if (p.a_kc && p.b_kc) LAUNCH_F32(true, true);
         else if (p.a_kc && !p.b_kc) LAUNCH_F32(true, false);
@@ -680,12 +833,19 @@ int gemm_init_attributes() {
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (TM_ + TN_) * BK * 2)); \
         if (5 * (TM_ + TN_) * BK * 2 <= 160 * 1024) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, (5 * (TM_ + TN_) * BK * 2 <= 160 * 1024 ? 5 : 2)>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (TM_ + TN_) * BK * 2)); \
     } while (0)
-#define SET_ATTR(AK, BKC) do { SET_T(AK, BKC, 128, 128); SET_T(AK, BKC, 128, 64); SET_T(AK, BKC, 64, 128); SET_T(AK, BKC, 64, 64); } while (0)
+#define SET_D(AK, BKC, TM_, TN_)                                                                                                  \
+    do {                                                                                                                         \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2)); \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM_ + TN_) * BK * 2)); \
+        if (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024 ? 4 : 2)>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (TM_ + TN_) * BK * 2)); \
+    } while (0)
+#define SET_ATTR(AK, BKC) do { SET_T(AK, BKC, 128, 128); SET_T(AK, BKC, 128, 64); SET_T(AK, BKC, 64, 128); SET_T(AK, BKC, 64, 64); SET_D(AK, BKC, 192, 128); SET_D(AK, BKC, 96, 128); SET_D(AK, BKC, 96, 64); } while (0)
     SET_ATTR(true, true);
     SET_ATTR(true, false);
     SET_ATTR(false, false);
     SET_ATTR(false, true);
 #undef SET_ATTR
+#undef SET_D
 #undef SET_T
     return MEBT_OK;
 }

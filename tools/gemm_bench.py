@@ -66,10 +66,10 @@ for label, cnt, M, N, K, akc, bkc, cf32, split in shapes:
     tot_fl += cnt * fl
     var = ""
     if args.dtype == "bf16" and args.variants:
-        for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64)):
+        for bm, bn in ((128, 128), (192, 128), (96, 128), (96, 64), (128, 64), (64, 128), (64, 64)):
             lib.mebt_debug_gemm_tile(bm, bn)
             r = []
-            for v in (0, 2, 3, 4, 5):    # register-staged / LDS-DMA with 2,3,4,5 ring stages
+            for v in ((2, 3, 4) if bm in (96, 192) else (0, 2, 3, 4, 5)):    # register-staged / LDS-DMA with 2,3,4,5 ring stages
                 lib.mebt_debug_gemm_variant(v)
                 r.append(f"{fl / timeit() / 1e6:4.0f}")
             var += f" |{bm}x{bn} " + "/".join(r)
