@@ -800,30 +800,92 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     return MEBT_OK;
 }
 
+// grouped weight gradients of one block.  Items are ordered by reduction length, longest first (the key
+// projection reduces over twice as many tokens as the rest: started last, its tiles were the tail of the
+// launch), and the block tile / ring depth are autotuned per group signature like the single GEMMs.
+static void launch_grouped_config(GroupedWgrad& c, int tbm, int tbn, int stages, hipStream_t stream) {
+    int tiles = 0;
+    for (int i = 0; i < c.n; ++i) {
+        c.g[i].ntx = (c.g[i].N + tbn - 1) / tbn;
+        c.tile_start[i] = tiles;
+        tiles += ((c.g[i].M + tbm - 1) / tbm) * c.g[i].ntx;
+    }
+    for (int i = c.n; i <= MEBT_MAX_GROUP; ++i) c.tile_start[i] = tiles;
+#define LAUNCH_G(TM_, TN_)                                                                                                                   \
+    do {                                                                                                                                    \
+        if (stages >= 4) hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 4>), dim3(tiles), dim3(256), 4 * (TM_ + TN_) * BK * 2, stream, c);      \
+        else if (stages == 3) hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 3>), dim3(tiles), dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, c); \
+        else hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 2>), dim3(tiles), dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, c);                 \
+    } while (0)
+    if (tbm == 128 && tbn == 128) LAUNCH_G(128, 128);
+    else if (tbm == 128 && tbn == 64) LAUNCH_G(128, 64);
+    else if (tbm == 64 && tbn == 128) LAUNCH_G(64, 128);
+    else LAUNCH_G(64, 64);
+#undef LAUNCH_G
+}
+
 int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
     if (dtype != MEBT_BF16) { mebt_set_error("grouped wgrad: bf16 only"); return MEBT_EDTYPE; }
-    int tiles = 0, n = 0;
+    int n = 0;
     GroupedWgrad c;
     for (int i = 0; i < w.n; ++i) {          // drop empty products (their C was zero-filled by the caller)
         if (w.g[i].M <= 0 || w.g[i].N <= 0 || w.g[i].K <= 0) continue;
-        c.g[n] = w.g[i];
-        c.g[n].ntx = (w.g[i].N + 127) / 128;
-        c.tile_start[n] = tiles;
-        tiles += ((w.g[i].M + 127) / 128) * c.g[n].ntx;
-        ++n;
+        c.g[n++] = w.g[i];
     }
     c.n = n;
-    for (int i = n; i <= MEBT_MAX_GROUP; ++i) c.tile_start[i] = tiles;
-    if (!tiles) return MEBT_OK;
-    if (g_grouped_stages == 3) hipLaunchKernelGGL((wgrad_grouped_kernel<128, 128, 3>), dim3(tiles), dim3(256), 3 * (128 + 128) * BK * 2, stream, c);
-    else hipLaunchKernelGGL((wgrad_grouped_kernel<128, 128, 2>), dim3(tiles), dim3(256), 2 * (128 + 128) * BK * 2, stream, c);
+    if (!n) return MEBT_OK;
+    for (int i = 1; i < n; ++i)              // insertion sort, K descending
+        for (int j = i; j > 0 && c.g[j].K > c.g[j - 1].K; --j) { const GroupedWgrad::Item t = c.g[j]; c.g[j] = c.g[j - 1]; c.g[j - 1] = t; }
+    if (g_autotune < 0) {
+        const char* e = getenv("MEBT_GEMM_AUTOTUNE");
+        g_autotune = (e && e[0] == '0') ? 0 : 1;
+        const char* l = getenv("MEBT_GEMM_TUNE_LOG");
+        g_tune_log = (l && l[0] == '1') ? 1 : 0;
+    }
+    int tbm = 128, tbn = 128, stages = g_grouped_stages == 3 ? 3 : 2;
+    if (g_autotune) {
+        TuneKey key{0, 0, 0, 0x40000000 | n};
+        for (int i = 0; i < n; ++i) { key.M = key.M * 31 + c.g[i].M; key.N = key.N * 31 + c.g[i].N; key.K = key.K * 31 + c.g[i].K; }
+        auto it = g_tuned.find(key);
+        if (it == g_tuned.end()) {
+            static hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (!e0) { MEBT_HIP_CHECK(hipEventCreate(&e0)); MEBT_HIP_CHECK(hipEventCreate(&e1)); }
+            static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+            float best = 1e30f;
+            for (int t = 0; t < 4; ++t)
+                for (int st = 2; st <= 4; ++st) {
+                    launch_grouped_config(c, tiles[t][0], tiles[t][1], st, stream);
+                    MEBT_HIP_CHECK(hipEventRecord(e0, stream));
+                    for (int r = 0; r < 3; ++r) launch_grouped_config(c, tiles[t][0], tiles[t][1], st, stream);
+                    MEBT_HIP_CHECK(hipEventRecord(e1, stream));
+                    MEBT_HIP_CHECK(hipEventSynchronize(e1));
+                    float ms = 0.f;
+                    MEBT_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best) { best = ms; tbm = tiles[t][0]; tbn = tiles[t][1]; stages = st; }
+                }
+            if (g_tune_log) {
+                fprintf(stderr, "[mebt gemm autotune] grouped wgrad");
+                for (int i = 0; i < n; ++i) fprintf(stderr, " %dx%dx%d", c.g[i].M, c.g[i].N, c.g[i].K);
+                fprintf(stderr, " -> %dx%d ring %d (%.1f us)\n", tbm, tbn, stages, best * 1e3f / 3);
+            }
+            it = g_tuned.emplace(key, (tbm << 16) | (tbn << 8) | stages).first;
+        }
+        tbm = it->second >> 16; tbn = (it->second >> 8) & 255; stages = it->second & 255;
+    }
+    launch_grouped_config(c, tbm, tbn, stages, stream);
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;
 }
 
 int gemm_init_attributes() {
-    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<128, 128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * BK * 2));
-    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<128, 128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * BK * 2));
+#define SET_G(TM_, TN_)                                                                                                                                        \
+    do {                                                                                                                                                  \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2)); \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM_ + TN_) * BK * 2)); \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TM_, TN_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (TM_ + TN_) * BK * 2)); \
+    } while (0)
+    SET_G(128, 128); SET_G(128, 64); SET_G(64, 128); SET_G(64, 64);
+#undef SET_G
     // dynamic LDS up to 64 KiB
 #define SET_T(AK, BKC, TM_, TN_)                                                                                                  \
     do {                                                                                                                         \
