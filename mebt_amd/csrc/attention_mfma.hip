@@ -2,10 +2,14 @@
 // Replaces reference mebt/modules/gpt.py:131-137 (q@k^T * 1/sqrt(hd) -> softmax -> @v) and its
 // autograd backward for the four routings (NQ x NK) = (NS,NC), (NS,NS), (NT,NS), (NS,NS+NT).
 //
-// Structure (all three kernels): a workgroup = 4 waves, each wave owns 16 rows (queries in
-// forward/dQ, keys in dK/dV) of one (batch, head); the other side is streamed in 64-row tiles
-// through LDS (register-staged, next tile's global loads issued before the MFMAs of the current
-// one, two LDS stages, one barrier per tile).  The score tile is computed TRANSPOSED with respect
+// Structure (all three kernels): a workgroup = 8 waves, each wave owns 16 rows (queries in
+// forward/dQ, keys in dK/dV) of one (batch, head); the other side is streamed through LDS in CHUNKS
+// of 256 rows (four 64-row tile images per operand), copied global->LDS by LDS-DMA into a two-deep
+// ring: for the shapes of this model (<= 768 streamed rows) every load of the kernel is in flight
+// within the first microsecond and the 64-row tiles of a chunk are multiplied back to back with no
+// barrier between them (the previous register-staged 64-row pipeline paid one exposed HBM round
+// trip and one barrier per tile: 20-29 us per launch for ~3 us of math).  Two barriers per chunk.
+// The score tile is computed TRANSPOSED with respect
 // to the owned rows so that (i) the softmax statistics of a row live in one lane (+2 shuffles
 // across the 4 lane groups) and (ii) the score accumulators are directly the B operand of the
 // next product (v_mfma_f32_16x16x32_bf16: lane = column, registers = 4 rows), with no LDS round
@@ -133,23 +137,66 @@ __device__ __forceinline__ float group_max(float v) {
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------------
+// chunked LDS-DMA staging shared by the three kernels
+// ------------------------------------------------------------------------------------------------
+constexpr int WAVES = 8;                         // 16 owned rows per wave -> 128 rows per workgroup
+constexpr int BLOCK_ROWS = WAVES * 16;
+constexpr int CHUNK_TILES = 4;                   // 64-row tiles per chunk
+constexpr int CHUNK = CHUNK_TILES * TILE;        // 256 streamed rows per chunk
+constexpr int CHUNK_BYTES = CHUNK_TILES * TILE_BYTES;          // one operand: 32 KiB
+constexpr int STAT_BYTES = CHUNK * 4;                          // one fp32 vector of a chunk (dK/dV kernel)
+constexpr int STAGE_BYTES = 2 * CHUNK_BYTES + 2 * STAT_BYTES;  // two operands (+ lse, delta)
+constexpr int ATTN_LDS = 2 * STAGE_BYTES;                      // 132 KiB
+constexpr int DMA_PER_WAVE = 2 * (CHUNK_BYTES / 1024) / WAVES; // 8 LDS-DMA instructions per wave per chunk
+
+// One operand of a chunk = 32 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces w, w+8, w+16, w+24.
+// A piece is written lane-linearly (lane l -> bytes 16 l), so the XOR swizzle of the tile image is applied
+// to the per-lane SOURCE address.  Rows beyond `rows` are zero-filled by the buffer bounds.
+struct ChunkDma {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t goff[4];
+    uint32_t step;
+    __device__ __forceinline__ void init(const bf16_t* base, int rows, int ld, int wave, int lane) {
+        rsrc = make_rsrc(base, rows > 0 ? ((size_t)(rows - 1) * ld + 64) * 2 : 0);
+        step = (uint32_t)CHUNK * ld * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * (wave + WAVES * i) + (lane >> 3), slot = lane & 7;
+            goff[i] = ((uint32_t)row * ld + 8 * (slot ^ swz(row))) * 2;
+        }
+    }
+    __device__ __forceinline__ void issue(char* dst, int chunk, int wave) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(rsrc, lds_addr_of(dst + (wave + WAVES * i) * 1024), goff[i] + (uint32_t)chunk * step);
+    }
+};
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // 2 stages x (K, V)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+__global__ __launch_bounds__(WAVES * 64) void attn_fwd_mfma(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
+    const int q = blockIdx.x * BLOCK_ROWS + wave * 16 + (lane & 15);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (size_t)b * p.NQ * p.ldq + h * 64;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (size_t)b * p.NK * p.ldk + h * 64;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * p.NK * p.ldv + h * 64;
     bf16x8 qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = frag_global(Q, q, p.NQ, p.ldq, ks, lane);
-    TileLoad lk, lv;
-    lk.init(K, p.NK, p.ldk, tid);
-    lv.init(V, p.NK, p.ldv, tid);
-    const int ntiles = (p.NK + TILE - 1) / TILE;
+    ChunkDma lk, lv;
+    lk.init(K, p.NK, p.ldk, wave, lane);
+    lv.init(V, p.NK, p.ldv, wave, lane);
+    const int nchunks = (p.NK + CHUNK - 1) / CHUNK;
+    lk.issue(smem, 0, wave);
+    lv.issue(smem + CHUNK_BYTES, 0, wave);
+    if (nchunks > 1) {
+        lk.issue(smem + STAGE_BYTES, 1, wave);
+        lv.issue(smem + STAGE_BYTES + CHUNK_BYTES, 1, wave);
+    }
     const float c = 0.125f * LOG2E;     // 1/sqrt(64) folded with log2(e)
     FragOffsets fo;
     fo.init(lane);
@@ -159,71 +206,66 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnParams p) {
     for (int e = 0; e < 4; ++e) o[e] = f32x4{0, 0, 0, 0};
     float m = -INFINITY, l = 0.f;
 
-    u32x4 rk[2], rv[2];
-    lk.load(rk, 0);
-    lv.load(rv, 0);
-    lk.store(smem, rk);
-    lv.store(smem + TILE_BYTES, rv);
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const char* sK = smem + (t & 1) * 2 * TILE_BYTES;
-        const char* sV = sK + TILE_BYTES;
-        const bool more = t + 1 < ntiles;
-        if (more) { lk.load(rk, t + 1); lv.load(rv, t + 1); }
-        // S^T[key][q] for the 64 keys of the tile
-        f32x4 s[4];
+    for (int ch = 0; ch < nchunks; ++ch) {
+        char* stage = smem + (ch & 1) * STAGE_BYTES;
+        if (ch + 1 < nchunks) wait_vm<DMA_PER_WAVE>(); else wait_vm<0>();     // this wave's pieces of chunk ch landed
+        __builtin_amdgcn_s_barrier();                                          // ... and everybody else's
+        const int nt = min(CHUNK_TILES, (p.NK - ch * CHUNK + TILE - 1) / TILE);
+        for (int t = 0; t < nt; ++t) {
+            const char* sK = stage + t * TILE_BYTES;
+            const char* sV = stage + CHUNK_BYTES + t * TILE_BYTES;
+            // S^T[key][q] for the 64 keys of the tile
+            f32x4 s[4];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            s[kb] = f32x4{0, 0, 0, 0};
+            for (int kb = 0; kb < 4; ++kb) {
+                s[kb] = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) s[kb] = MFMA(fo.row_frag(sK, kb, ks), qf[ks], s[kb]);
-        }
-        const int k0 = t * TILE;
-        float tmax = -INFINITY;
-        if (k0 + TILE > p.NK) {         // ragged last tile only: keys beyond NK are masked out
+                for (int ks = 0; ks < 2; ++ks) s[kb] = MFMA(fo.row_frag(sK, kb, ks), qf[ks], s[kb]);
+            }
+            const int k0 = ch * CHUNK + t * TILE;
+            float tmax = -INFINITY;
+            if (k0 + TILE > p.NK) {         // ragged last tile only: keys beyond NK are masked out
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (k0 + 16 * kb + 4 * g + r >= p.NK) s[kb][r] = -INFINITY;
-        }
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kb][r]);
-        tmax = group_max(tmax) * c;                       // c > 0: max commutes with the scale
-        const float mn = fmaxf(m, tmax);
-        const float alpha = fast_exp2(m - mn);
-        float ps = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s[kb][r] = fast_exp2(fmaf(s[kb][r], c, -mn)); ps += s[kb][r]; }
-        ps = group_sum(ps);
-        l = l * alpha + ps;
-        m = mn;
-        if (p.drop.thresh) {   // attn_drop on the probabilities (gpt.py:135); the row sum above stays undropped
-            const uint64_t dbase = (((uint64_t)b * p.H + h) * p.NQ + q) * p.NK + k0;
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + 16 * kb + 4 * g + r >= p.NK) s[kb][r] = -INFINITY;
+            }
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[kb][r] *= drop_keep(p.drop, dbase + 16 * kb + 4 * g + r);
-        }
+                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kb][r]);
+            tmax = group_max(tmax) * c;                       // c > 0: max commutes with the scale
+            const float mn = fmaxf(m, tmax);
+            const float alpha = fast_exp2(m - mn);
+            float ps = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] *= alpha;
-        // O^T[e][q] += V^T[e][key] P^T[key][q]
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const bf16x8 pf = pack_acc(s[2 * kk], s[2 * kk + 1]);
+                for (int r = 0; r < 4; ++r) { s[kb][r] = fast_exp2(fmaf(s[kb][r], c, -mn)); ps += s[kb][r]; }
+            ps = group_sum(ps);
+            l = l * alpha + ps;
+            m = mn;
+            if (p.drop.thresh) {   // attn_drop on the probabilities (gpt.py:135); the row sum above stays undropped
+                const uint64_t dbase = (((uint64_t)b * p.H + h) * p.NQ + q) * p.NK + k0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = MFMA(fo.col_frag(sV, e, kk), pf, o[e]);
+                for (int kb = 0; kb < 4; ++kb) s[kb] *= drop_keep4(p.drop, dbase + 16 * kb + 4 * g);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] *= alpha;
+            // O^T[e][q] += V^T[e][key] P^T[key][q]
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 pf = pack_acc(s[2 * kk], s[2 * kk + 1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = MFMA(fo.col_frag(sV, e, kk), pf, o[e]);
+            }
         }
-        if (more) {
-            char* d = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-            lk.store(d, rk);
-            lv.store(d + TILE_BYTES, rv);
+        if (ch + 2 < nchunks) {
+            __builtin_amdgcn_s_barrier();                     // every wave is done reading this stage
+            lk.issue(stage, ch + 2, wave);
+            lv.issue(stage + CHUNK_BYTES, ch + 2, wave);
         }
-        __syncthreads();
     }
     if (q < p.NQ) {
         const float inv = 1.0f / l;
@@ -235,37 +277,48 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: dQ (+ delta = rowsum(dO * O)).  One wave = 16 query rows; K/V tiles streamed.
+// backward: dQ (+ delta = rowsum(dO * O)).  One wave = 16 query rows; K/V chunks streamed.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_mfma(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q = blockIdx.x * 64 + wave * 16 + (lane & 15);
+    const int q = blockIdx.x * BLOCK_ROWS + wave * 16 + (lane & 15);
     const bool qv = q < p.NQ;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (size_t)b * p.NQ * p.ldq + h * 64;
     const bf16_t* G = reinterpret_cast<const bf16_t*>(p.d_o) + (size_t)b * p.NQ * p.lddo + h * 64;
     const bf16_t* Oo = reinterpret_cast<const bf16_t*>(p.o) + (size_t)b * p.NQ * p.ldo + h * 64;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (size_t)b * p.NK * p.ldk + h * 64;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * p.NK * p.ldv + h * 64;
-    bf16x8 qf[2], gf[2];
-    float delta = 0.f;
+    ChunkDma lk, lv;
+    lk.init(K, p.NK, p.ldk, wave, lane);
+    lv.init(V, p.NK, p.ldv, wave, lane);
+    const int nchunks = (p.NK + CHUNK - 1) / CHUNK;
+    // the wave's own operands first (oldest in the vmcnt queue), then the chunk copies; nothing else touches
+    // memory until the epilogue, so "at most DMA_PER_WAVE outstanding" means "chunk ch has landed"
+    bf16x8 qf[2], gf[2], of[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         qf[ks] = frag_global(Q, q, p.NQ, p.ldq, ks, lane);
         gf[ks] = frag_global(G, q, p.NQ, p.lddo, ks, lane);
-        const bf16x8 of = frag_global(Oo, q, p.NQ, p.ldo, ks, lane);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) delta += (float)gf[ks][j] * (float)of[j];
+        of[ks] = frag_global(Oo, q, p.NQ, p.ldo, ks, lane);
     }
-    delta = group_sum(delta);
     const size_t sidx = ((size_t)b * p.H + h) * p.NQ + q;
-    const float lse2 = qv ? p.lse[sidx] * LOG2E : 0.f;
-    if (qv && g == 0) p.delta[sidx] = delta;
-    TileLoad lk, lv;
-    lk.init(K, p.NK, p.ldk, tid);
-    lv.init(V, p.NK, p.ldv, tid);
-    const int ntiles = (p.NK + TILE - 1) / TILE;
+    const float lse_q = qv ? p.lse[sidx] : 0.f;
+    lk.issue(smem, 0, wave);
+    lv.issue(smem + CHUNK_BYTES, 0, wave);
+    if (nchunks > 1) {
+        lk.issue(smem + STAGE_BYTES, 1, wave);
+        lv.issue(smem + STAGE_BYTES + CHUNK_BYTES, 1, wave);
+    }
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += (float)gf[ks][j] * (float)of[ks][j];
+    delta = group_sum(delta);
+    const float lse2 = lse_q * LOG2E;
     const float c = 0.125f * LOG2E;
     FragOffsets fo;
     fo.init(lane);
@@ -273,81 +326,90 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const AttnParams p) {
     f32x4 dq[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) dq[e] = f32x4{0, 0, 0, 0};
-    u32x4 rk[2], rv[2];
-    lk.load(rk, 0);
-    lv.load(rv, 0);
-    lk.store(smem, rk);
-    lv.store(smem + TILE_BYTES, rv);
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const char* sK = smem + (t & 1) * 2 * TILE_BYTES;
-        const char* sV = sK + TILE_BYTES;
-        const bool more = t + 1 < ntiles;
-        if (more) { lk.load(rk, t + 1); lv.load(rv, t + 1); }
-        const int k0 = t * TILE;
-        f32x4 ds[4];
+    const uint64_t drow = (((uint64_t)b * p.H + h) * p.NQ + q) * p.NK;     // dropout index of (q, key 0)
+    for (int ch = 0; ch < nchunks; ++ch) {
+        char* stage = smem + (ch & 1) * STAGE_BYTES;
+        if (ch + 1 < nchunks) wait_vm<DMA_PER_WAVE>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        const int nt = min(CHUNK_TILES, (p.NK - ch * CHUNK + TILE - 1) / TILE);
+        for (int t = 0; t < nt; ++t) {
+            const char* sK = stage + t * TILE_BYTES;
+            const char* sV = stage + CHUNK_BYTES + t * TILE_BYTES;
+            const int k0 = ch * CHUNK + t * TILE;
+            f32x4 ds[4];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+            for (int kb = 0; kb < 4; ++kb) {
+                f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                s = MFMA(fo.row_frag(sK, kb, ks), qf[ks], s);      // S^T[key][q]
-                dp = MFMA(fo.row_frag(sV, kb, ks), gf[ks], dp);    // dP^T[key][q] = V dO^T
+                for (int ks = 0; ks < 2; ++ks) {
+                    s = MFMA(fo.row_frag(sK, kb, ks), qf[ks], s);      // S^T[key][q]
+                    dp = MFMA(fo.row_frag(sV, kb, ks), gf[ks], dp);    // dP^T[key][q] = V dO^T
+                }
+                f32x4 keep = {1.f, 1.f, 1.f, 1.f};
+                if (p.drop.thresh) keep = drop_keep4(p.drop, drow + (uint64_t)(k0 + 16 * kb + 4 * g));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + 16 * kb + 4 * g + r;
+                    const float pr = key < p.NK ? fast_exp2(fmaf(s[r], c, -lse2)) : 0.f;
+                    ds[kb][r] = pr * (dp[r] * keep[r] - delta) * 0.125f;
+                }
             }
+            // dQ^T[e][q] += K^T[e][key] dS^T[key][q]
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + 16 * kb + 4 * g + r;
-                const float pr = key < p.NK ? fast_exp2(fmaf(s[r], c, -lse2)) : 0.f;
-                const float keep = p.drop.thresh ? drop_keep(p.drop, (((uint64_t)b * p.H + h) * p.NQ + q) * p.NK + key) : 1.0f;
-                ds[kb][r] = pr * (dp[r] * keep - delta) * 0.125f;
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 df = pack_acc(ds[2 * kk], ds[2 * kk + 1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dq[e] = MFMA(fo.col_frag(sK, e, kk), df, dq[e]);
             }
         }
-        // dQ^T[e][q] += K^T[e][key] dS^T[key][q]
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const bf16x8 df = pack_acc(ds[2 * kk], ds[2 * kk + 1]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dq[e] = MFMA(fo.col_frag(sK, e, kk), df, dq[e]);
+        if (ch + 2 < nchunks) {
+            __builtin_amdgcn_s_barrier();
+            lk.issue(stage, ch + 2, wave);
+            lv.issue(stage + CHUNK_BYTES, ch + 2, wave);
         }
-        if (more) {
-            char* d = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-            lk.store(d, rk);
-            lv.store(d + TILE_BYTES, rv);
-        }
-        __syncthreads();
     }
     if (qv) {
         bf16_t* D = reinterpret_cast<bf16_t*>(p.dq) + ((size_t)b * p.NQ + q) * p.lddq + h * 64;
 #pragma unroll
         for (int e = 0; e < 4; ++e) store4<bf16_t>(D + 16 * e + 4 * g, dq[e]);
+        if (g == 0) p.delta[sidx] = delta;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: dK, dV.  One wave = 16 key rows; Q / dO tiles (+ lse, delta) streamed.
+// backward: dK, dV.  One wave = 16 key rows; Q / dO chunks (+ lse, delta) streamed.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
-    __shared__ float sL[2][TILE], sD[2][TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_mfma(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, h = blockIdx.y;
-    const int key = blockIdx.x * 64 + wave * 16 + (lane & 15);
+    const int key = blockIdx.x * BLOCK_ROWS + wave * 16 + (lane & 15);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (size_t)b * p.NQ * p.ldq + h * 64;
     const bf16_t* G = reinterpret_cast<const bf16_t*>(p.d_o) + (size_t)b * p.NQ * p.lddo + h * 64;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (size_t)b * p.NK * p.ldk + h * 64;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * p.NK * p.ldv + h * 64;
     const float* L = p.lse + ((size_t)b * p.H + h) * p.NQ;
     const float* Dl = p.delta + ((size_t)b * p.H + h) * p.NQ;
+    ChunkDma lq, lg;
+    lq.init(Q, p.NQ, p.ldq, wave, lane);
+    lg.init(G, p.NQ, p.lddo, wave, lane);
+    // lse / delta of a chunk: 256 floats = one 1-KiB piece each, copied by waves 0 and 1 (zero beyond NQ)
+    const __amdgpu_buffer_rsrc_t rstat = make_rsrc(wave == 0 ? L : Dl, (size_t)p.NQ * 4);
+    const int nchunks = (p.NQ + CHUNK - 1) / CHUNK;
+    auto issue = [&](char* stage, int chunk) {
+        lq.issue(stage, chunk, wave);
+        lg.issue(stage + CHUNK_BYTES, chunk, wave);
+        if (wave < 2) dma16(rstat, lds_addr_of(stage + 2 * CHUNK_BYTES + wave * STAT_BYTES), (uint32_t)(chunk * CHUNK * 4 + lane * 16));
+    };
     bf16x8 kf[2], vf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         kf[ks] = frag_global(K, key, p.NK, p.ldk, ks, lane);
         vf[ks] = frag_global(V, key, p.NK, p.ldv, ks, lane);
     }
-    TileLoad lq, lg;
-    lq.init(Q, p.NQ, p.ldq, tid);
-    lg.init(G, p.NQ, p.lddo, tid);
-    const int ntiles = (p.NQ + TILE - 1) / TILE;
+    issue(smem, 0);
+    if (nchunks > 1) issue(smem + STAGE_BYTES, 1);
     const float c = 0.125f * LOG2E;
     FragOffsets fo;
     fo.init(lane);
@@ -355,65 +417,59 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const AttnParams p) {
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { dk[e] = f32x4{0, 0, 0, 0}; dv[e] = f32x4{0, 0, 0, 0}; }
-    u32x4 rq[2], rg[2];
-    float rl = 0.f, rd = 0.f;
-    auto load_stats = [&](int t) {
-        if (tid < TILE) {
-            const int qq = t * TILE + tid;
-            rl = qq < p.NQ ? L[qq] * LOG2E : INFINITY;    // +inf: exp2(s - inf) = 0 masks padded query rows
-            rd = qq < p.NQ ? Dl[qq] : 0.f;
+    const uint64_t dcol = ((uint64_t)b * p.H + h) * p.NQ * p.NK + key;      // dropout index of (query 0, key)
+    for (int ch = 0; ch < nchunks; ++ch) {
+        char* stage = smem + (ch & 1) * STAGE_BYTES;
+        if (ch + 1 < nchunks) {
+            if (wave < 2) wait_vm<DMA_PER_WAVE + 1>(); else wait_vm<DMA_PER_WAVE>();
+        } else {
+            wait_vm<0>();
         }
-    };
-    lq.load(rq, 0);
-    lg.load(rg, 0);
-    load_stats(0);
-    lq.store(smem, rq);
-    lg.store(smem + TILE_BYTES, rg);
-    if (tid < TILE) { sL[0][tid] = rl; sD[0][tid] = rd; }
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const char* sQ = smem + (t & 1) * 2 * TILE_BYTES;
-        const char* sG = sQ + TILE_BYTES;
-        const float* cl = sL[t & 1];
-        const float* cd = sD[t & 1];
-        const bool more = t + 1 < ntiles;
-        if (more) { lq.load(rq, t + 1); lg.load(rg, t + 1); load_stats(t + 1); }
-        f32x4 pr[4], ds[4];
+        __builtin_amdgcn_s_barrier();
+        const float* cl = reinterpret_cast<const float*>(stage + 2 * CHUNK_BYTES);
+        const float* cd = cl + CHUNK;
+        const int nt = min(CHUNK_TILES, (p.NQ - ch * CHUNK + TILE - 1) / TILE);
+        for (int t = 0; t < nt; ++t) {
+            const char* sQ = stage + t * TILE_BYTES;
+            const char* sG = stage + CHUNK_BYTES + t * TILE_BYTES;
+            const int q0 = ch * CHUNK + t * TILE;
+            f32x4 pr[4], ds[4];
 #pragma unroll
-        for (int qb = 0; qb < 4; ++qb) {
-            f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+            for (int qb = 0; qb < 4; ++qb) {
+                f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                s = MFMA(fo.row_frag(sQ, qb, ks), kf[ks], s);      // S[q][key]
-                dp = MFMA(fo.row_frag(sG, qb, ks), vf[ks], dp);    // dP[q][key] = dO V^T
+                for (int ks = 0; ks < 2; ++ks) {
+                    s = MFMA(fo.row_frag(sQ, qb, ks), kf[ks], s);      // S[q][key]
+                    dp = MFMA(fo.row_frag(sG, qb, ks), vf[ks], dp);    // dP[q][key] = dO V^T
+                }
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(cl + t * TILE + 16 * qb + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(cd + t * TILE + 16 * qb + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qi = q0 + 16 * qb + 4 * g + r;
+                    // padded query rows (qi >= NQ): Q and dO rows are zero-filled, so whatever p is they add nothing
+                    const float pv = fast_exp2(fmaf(s[r], c, -l4[r] * LOG2E));
+                    const float keep = p.drop.thresh ? drop_keep(p.drop, dcol + (uint64_t)(uint32_t)qi * (uint32_t)p.NK) : 1.0f;
+                    ds[qb][r] = pv * (dp[r] * keep - d4[r]) * 0.125f;
+                    pr[qb][r] = pv * keep;
+                }
             }
+            // dV^T[e][key] += dO^T[e][q] P[q][key];   dK^T[e][key] += Q^T[e][q] dS[q][key]
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qi = 16 * qb + 4 * g + r;
-                const float pv = fast_exp2(fmaf(s[r], c, -cl[qi]));
-                const float keep = p.drop.thresh ? drop_keep(p.drop, (((uint64_t)b * p.H + h) * p.NQ + t * TILE + qi) * p.NK + key) : 1.0f;
-                ds[qb][r] = pv * (dp[r] * keep - cd[qi]) * 0.125f;
-                pr[qb][r] = pv * keep;
-            }
-        }
-        // dV^T[e][key] += dO^T[e][q] P[q][key];   dK^T[e][key] += Q^T[e][q] dS[q][key]
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 pf = pack_acc(pr[2 * kk], pr[2 * kk + 1]);
+                const bf16x8 df = pack_acc(ds[2 * kk], ds[2 * kk + 1]);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const bf16x8 pf = pack_acc(pr[2 * kk], pr[2 * kk + 1]);
-            const bf16x8 df = pack_acc(ds[2 * kk], ds[2 * kk + 1]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                dv[e] = MFMA(fo.col_frag(sG, e, kk), pf, dv[e]);
-                dk[e] = MFMA(fo.col_frag(sQ, e, kk), df, dk[e]);
+                for (int e = 0; e < 4; ++e) {
+                    dv[e] = MFMA(fo.col_frag(sG, e, kk), pf, dv[e]);
+                    dk[e] = MFMA(fo.col_frag(sQ, e, kk), df, dk[e]);
+                }
             }
         }
-        if (more) {
-            char* d = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-            lq.store(d, rq);
-            lg.store(d + TILE_BYTES, rg);
-            if (tid < TILE) { sL[(t + 1) & 1][tid] = rl; sD[(t + 1) & 1][tid] = rd; }
+        if (ch + 2 < nchunks) {
+            __builtin_amdgcn_s_barrier();
+            issue(stage, ch + 2);
         }
-        __syncthreads();
     }
     if (key < p.NK) {
         bf16_t* DK = reinterpret_cast<bf16_t*>(p.dk) + ((size_t)b * p.NK + key) * p.lddk + h * 64;
@@ -431,13 +487,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const AttnParams p) {
 static int check_layout(const AttnParams& p) {
     if (p.HD != 64) { mebt_set_error("mfma attention: head size must be 64"); return MEBT_ESHAPE; }
     if ((p.ldq | p.ldk | p.ldv | p.ldo) % 8) { mebt_set_error("mfma attention: row strides must be multiples of 8 elements"); return MEBT_ESHAPE; }
+    static bool inited = false;
+    if (!inited) {
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS));
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS));
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS));
+        inited = true;
+    }
     return MEBT_OK;
 }
+// one stage is enough when the streamed side fits one chunk: two workgroups per CU
+static int lds_bytes(int streamed_rows) { return streamed_rows <= CHUNK ? STAGE_BYTES : ATTN_LDS; }
 
 int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
     if (int rc = check_layout(p)) return rc;
-    const dim3 grid((p.NQ + 63) / 64, p.H, p.B);
-    hipLaunchKernelGGL(attn_fwd_mfma, grid, dim3(256), 0, stream, p);
+    const dim3 grid((p.NQ + BLOCK_ROWS - 1) / BLOCK_ROWS, p.H, p.B);
+    hipLaunchKernelGGL(attn_fwd_mfma, grid, dim3(WAVES * 64), lds_bytes(p.NK), stream, p);
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;
 }
@@ -445,10 +510,10 @@ int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
 int launch_attn_bwd_mfma(const AttnParams& p, hipStream_t stream) {
     if (int rc = check_layout(p)) return rc;
     if ((p.lddo | p.lddq | p.lddk | p.lddv) % 8) { mebt_set_error("mfma attention: row strides must be multiples of 8 elements"); return MEBT_ESHAPE; }
-    const dim3 gq((p.NQ + 63) / 64, p.H, p.B);
-    hipLaunchKernelGGL(attn_bwd_dq_mfma, gq, dim3(256), 0, stream, p);
-    const dim3 gk((p.NK + 63) / 64, p.H, p.B);
-    hipLaunchKernelGGL(attn_bwd_dkv_mfma, gk, dim3(256), 0, stream, p);
+    const dim3 gq((p.NQ + BLOCK_ROWS - 1) / BLOCK_ROWS, p.H, p.B);
+    hipLaunchKernelGGL(attn_bwd_dq_mfma, gq, dim3(WAVES * 64), lds_bytes(p.NK), stream, p);
+    const dim3 gk((p.NK + BLOCK_ROWS - 1) / BLOCK_ROWS, p.H, p.B);
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma, gk, dim3(WAVES * 64), lds_bytes(p.NQ), stream, p);
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;
 }

@@ -40,6 +40,26 @@ __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t o
 }
 
 // ---------------------------------------------------------------------------------------------
+// direct global -> LDS copies (LDS-DMA)
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+// One LDS-DMA instruction as inline asm: hipcc models the builtin form as a store to LDS and then drains
+// the whole DMA queue (s_waitcnt vmcnt(0)) in front of every ds_read_b64_tr_b16, which defeats the ring
+// for the transposed-operand layouts.  In asm the compiler sees no memory operation; completion is
+// tracked by the counted waits of the kernel.  M0 (the LDS base of the DMA) is saved and restored inside
+// the statement because the compiler owns it.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(rsrc)
+                 : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(lds_char_ptr)(char*)p; }
+
+// ---------------------------------------------------------------------------------------------
 // element conversion
 // ---------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f32(T v);
@@ -108,14 +128,18 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
 // counter-based RNG for dropout (Philox-like mixing of a 64-bit counter; one 32-bit draw per call).
 // The mask of element `idx` at site `site` of step `seed` is recomputed in backward, never stored.
 // ---------------------------------------------------------------------------------------------
-// One 32-bit mix (two multiplies) yields two 16-bit draws: elements idx and idx^1 share a hash.
+// One 32-bit mix (two multiplies, the costly part: v_mul_lo_u32 is quarter rate) yields two 16-bit draws:
+// elements idx and idx^1 share a hash.  `pair_hash` takes the pair index (idx >> 1).
+__device__ __forceinline__ uint32_t pair_hash(uint64_t seed, uint32_t site, uint64_t pair) {
+    uint32_t h = ((uint32_t)pair ^ (uint32_t)seed) + ((uint32_t)(pair >> 32) + site) * 0x632BE5ABu + (uint32_t)(seed >> 32);
+    h *= 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    return h;
+}
 __device__ __forceinline__ uint32_t mix_hash(uint64_t seed, uint32_t site, uint64_t idx) {
-    const uint64_t pair = idx >> 1;
-    uint32_t h = (uint32_t)pair * 0x9E3779B1u + (uint32_t)seed;
-    h ^= ((uint32_t)(pair >> 32) + site * 0x632BE5ABu) ^ (uint32_t)(seed >> 32);
-    h ^= h >> 15; h *= 0x85EBCA77u;
-    h ^= h >> 13; h *= 0xC2B2AE3Du;
-    h ^= h >> 16;
+    const uint32_t h = pair_hash(seed, site, idx >> 1);
     return (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
 }
 // Dropout descriptor: element `idx` of site `site` is kept iff its 16-bit draw >= thresh
@@ -129,4 +153,20 @@ struct DropCfg {
 };
 __device__ __forceinline__ float drop_keep(const DropCfg& d, uint64_t idx) {
     return mix_hash(d.seed, d.site, idx) >= d.thresh ? d.inv_keep : 0.0f;
+}
+// keep factors of 4 consecutive elements idx0 .. idx0+3: two hashes when idx0 is even (the usual case:
+// vectors start at multiples of 4), identical values to drop_keep element by element
+__device__ __forceinline__ f32x4 drop_keep4(const DropCfg& d, uint64_t idx0) {
+    f32x4 k;
+    if ((idx0 & 1) == 0) {
+        const uint32_t h0 = pair_hash(d.seed, d.site, idx0 >> 1), h1 = pair_hash(d.seed, d.site, (idx0 >> 1) + 1);
+        k[0] = (h0 & 0xFFFFu) >= d.thresh ? d.inv_keep : 0.0f;
+        k[1] = (h0 >> 16) >= d.thresh ? d.inv_keep : 0.0f;
+        k[2] = (h1 & 0xFFFFu) >= d.thresh ? d.inv_keep : 0.0f;
+        k[3] = (h1 >> 16) >= d.thresh ? d.inv_keep : 0.0f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[j] = drop_keep(d, idx0 + j);
+    }
+    return k;
 }

@@ -54,8 +54,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedParams p) {
         f32x4 v = *reinterpret_cast<const f32x4*>(src0 + e);
         if (src1) v += *reinterpret_cast<const f32x4*>(src1 + e);
         if (dc.thresh) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= drop_keep(dc, ebase + e + j);
+            v *= drop_keep4(dc, ebase + e);
         }
         store4<T>(dst + e, v);
     }
@@ -221,8 +220,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const LnBwdMulti mj) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) m[j] = (float)(T)o[j];
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) m[j] *= drop_keep(p.drop2, (uint64_t)oi + j);
+                m *= drop_keep4(p.drop2, (uint64_t)oi);
                 if (f32out) store4<float>(reinterpret_cast<float*>(p.dx2) + oi, m);
                 else store4<T>(reinterpret_cast<T*>(p.dx2) + oi, m);
             }
@@ -378,7 +376,11 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_fast_kernel(const LnBwdMulti mj
         if (p.dx2) {
             float m[V];
 #pragma unroll
-            for (int j = 0; j < V; ++j) m[j] = (f32out ? o[j] : (float)(T)o[j]) * drop_keep(p.drop2, (uint64_t)oi + j);
+            for (int q4 = 0; q4 < V / 4; ++q4) {
+                const f32x4 k4 = drop_keep4(p.drop2, (uint64_t)oi + 4 * q4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[4 * q4 + j] = (f32out ? o[4 * q4 + j] : (float)(T)o[4 * q4 + j]) * k4[j];
+            }
             if (f32out) storef<V>(reinterpret_cast<float*>(p.dx2) + oi, m);
             else storev<T, V>(reinterpret_cast<T*>(p.dx2) + oi, m);
         }
@@ -616,8 +618,7 @@ template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void apply_dropout_kernel(const TS* src, TD* dst, size_t n, DropCfg d) {
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
         f32x4 v = load4<TS>(src + i);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= drop_keep(d, i + j);
+        v *= drop_keep4(d, i);
         store4<TD>(dst + i, v);
     }
 }

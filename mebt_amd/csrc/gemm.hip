@@ -55,8 +55,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
     } else if (p.epilogue == EPI_RESID) {
         if (p.drop.thresh) {
             const uint64_t e0 = (uint64_t)m * p.N + n;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= drop_keep(p.drop, e0 + j);
+            v *= drop_keep4(p.drop, e0);
         }
         v += load4<TA>(reinterpret_cast<const TA*>(p.aux) + (size_t)m * p.ld_aux + n);
     } else if (p.epilogue == EPI_GELU_BWD) {
@@ -143,8 +142,7 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x
             } else if (p.epilogue == EPI_RESID) {
                 if (p.drop.thresh) {
                     const uint64_t e0 = (uint64_t)m * p.N + n;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= drop_keep(p.drop, e0 + j);
+                    v *= drop_keep4(p.drop, e0);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += (float)auxr[i][r][j];
@@ -330,21 +328,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
 // are counted (`s_waitcnt vmcnt(N)`, never 0 inside the loop) and the barrier is the raw s_barrier
 // (a __syncthreads() would drain the DMA queue).
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-typedef __attribute__((address_space(3))) char* lds_char_ptr;
-// One LDS-DMA instruction as inline asm: hipcc models the builtin form as a store to LDS and then drains
-// the whole DMA queue (s_waitcnt vmcnt(0)) in front of every ds_read_b64_tr_b16, which defeats the ring
-// for the transposed-operand layouts.  In asm the compiler sees no memory operation; completion is
-// tracked by the counted waits of the kernel.  M0 (the LDS base of the DMA) is saved and restored inside
-// the statement because the compiler owns it.
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, unsigned voff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(lds_addr), "s"(rsrc)
-                 : "memory");
-}
-
 template <bool KC, int ROWS>
 struct DmaLoader {
     static constexpr int NP = ROWS / 32;      // 1-KiB pieces per wave per tile (ROWS/8 pieces, 4 waves)
