@@ -690,9 +690,37 @@ static void heuristic_config(const GemmParams& p, int& tbm, int& tbn, int& stagi
     else { tbm = 64; tbn = 64; staging = 4; }
 }
 
+// Candidates are timed with COLD caches: in the train step the weights (676 MB in bf16) never survive in the
+// 256 MB Infinity Cache from one use to the next, and a warm-cache timing favours shallow rings.  Before every
+// timed launch a 384 MB scratch buffer is overwritten (L2 and Infinity Cache hold nothing of the operands).
+static void* g_flush = nullptr;
+static constexpr size_t FLUSH_BYTES = 384ull << 20;
+static int tune_begin() {
+    if (!g_flush) MEBT_HIP_CHECK(hipMalloc(&g_flush, FLUSH_BYTES));
+    return MEBT_OK;
+}
+template <typename F>
+static int time_cold(F&& launch, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, float& best_ms) {
+    float tot = 0.f;
+    launch();                                                                    // code object, TLBs
+    for (int r = 0; r < 2; ++r) {
+        MEBT_HIP_CHECK(hipMemsetAsync(g_flush, r, FLUSH_BYTES, stream));
+        MEBT_HIP_CHECK(hipEventRecord(e0, stream));
+        launch();
+        MEBT_HIP_CHECK(hipEventRecord(e1, stream));
+        MEBT_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        MEBT_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        tot += ms;
+    }
+    best_ms = tot / 2;
+    return MEBT_OK;
+}
+
 static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, int& tbn, int& staging) {
     static hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!e0) { MEBT_HIP_CHECK(hipEventCreate(&e0)); MEBT_HIP_CHECK(hipEventCreate(&e1)); }
+    if (int rc = tune_begin()) return rc;
     static const int tiles[7][2] = {{192, 128}, {128, 128}, {96, 128}, {128, 64}, {64, 128}, {96, 64}, {64, 64}};
     const long out = (long)p.M * p.N;
     float best = 1e30f;
@@ -702,19 +730,14 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
         if (nt < 96 && (long)bm * bn > 64 * 64 && out > 64 * 64) continue;      // would leave most of the chip idle
         for (int st = 2; st <= 4; ++st) {
             if (st * (bm + bn) * BK * 2 > 128 * 1024) continue;
-            launch_bf16_config(p, bm, bn, st, 1, stream);                        // warm-up (code object, L2)
-            MEBT_HIP_CHECK(hipEventRecord(e0, stream));
-            for (int r = 0; r < 3; ++r) launch_bf16_config(p, bm, bn, st, 1, stream);
-            MEBT_HIP_CHECK(hipEventRecord(e1, stream));
-            MEBT_HIP_CHECK(hipEventSynchronize(e1));
             float ms = 0.f;
-            MEBT_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, st, 1, stream); }, stream, e0, e1, ms)) return rc;
             if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = st; }
         }
     }
     if (g_tune_log)
-        fprintf(stderr, "[mebt gemm autotune] M=%d N=%d K=%d a_kc=%d b_kc=%d epi=%d c_f32=%d -> %dx%d ring %d (%.1f us)\n", p.M, p.N, p.K,
-                p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, staging, best * 1e3f / 3);
+        fprintf(stderr, "[mebt gemm autotune] M=%d N=%d K=%d a_kc=%d b_kc=%d epi=%d c_f32=%d -> %dx%d ring %d (%.1f us cold)\n", p.M, p.N, p.K,
+                p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, staging, best * 1e3f);
     return MEBT_OK;
 }
 
@@ -833,23 +856,19 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
         if (it == g_tuned.end()) {
             static hipEvent_t e0 = nullptr, e1 = nullptr;
             if (!e0) { MEBT_HIP_CHECK(hipEventCreate(&e0)); MEBT_HIP_CHECK(hipEventCreate(&e1)); }
+            if (int rc = tune_begin()) return rc;
             static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
             float best = 1e30f;
             for (int t = 0; t < 4; ++t)
                 for (int st = 2; st <= 4; ++st) {
-                    launch_grouped_config(c, tiles[t][0], tiles[t][1], st, stream);
-                    MEBT_HIP_CHECK(hipEventRecord(e0, stream));
-                    for (int r = 0; r < 3; ++r) launch_grouped_config(c, tiles[t][0], tiles[t][1], st, stream);
-                    MEBT_HIP_CHECK(hipEventRecord(e1, stream));
-                    MEBT_HIP_CHECK(hipEventSynchronize(e1));
                     float ms = 0.f;
-                    MEBT_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                    if (int rc = time_cold([&] { launch_grouped_config(c, tiles[t][0], tiles[t][1], st, stream); }, stream, e0, e1, ms)) return rc;
                     if (ms < best) { best = ms; tbm = tiles[t][0]; tbn = tiles[t][1]; stages = st; }
                 }
             if (g_tune_log) {
                 fprintf(stderr, "[mebt gemm autotune] grouped wgrad");
                 for (int i = 0; i < n; ++i) fprintf(stderr, " %dx%dx%d", c.g[i].M, c.g[i].N, c.g[i].K);
-                fprintf(stderr, " -> %dx%d ring %d (%.1f us)\n", tbm, tbn, stages, best * 1e3f / 3);
+                fprintf(stderr, " -> %dx%d ring %d (%.1f us cold)\n", tbm, tbn, stages, best * 1e3f);
             }
             it = g_tuned.emplace(key, (tbm << 16) | (tbn << 8) | stages).first;
         }
