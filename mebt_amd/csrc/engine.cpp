@@ -127,6 +127,24 @@ static int gemm(const mebt_model* m, GemmParams p, hipStream_t st) {
     return rc;
 }
 
+static int gemm_pair(const mebt_model* m, const GemmParams& p0, const GemmParams& p1, hipStream_t st) {
+    if (m->d.dtype != MEBT_BF16 || p0.K <= 0 || p1.K <= 0 || p0.M <= 0 || p1.M <= 0) {
+        if (int rc = gemm(m, p0, st)) return rc;
+        return gemm(m, p1, st);
+    }
+    ProfRec r;
+    if (g_prof_on) {
+        r.a = get_event(); r.b = get_event(); r.flops = 2.0 * p0.M * p0.N * p0.K + 2.0 * p1.M * p1.N * p1.K;
+        r.bytes = 0;
+        for (const GemmParams* q : {&p0, &p1})
+            r.bytes += ((double)q->M * q->K + (double)q->N * q->K) * 2.0 + (double)q->M * q->N * (2.0 * (q->C ? 1 : 0) + (q->aux ? 2.0 : 0));
+        (void)hipEventRecord(r.a, st);
+    }
+    const int rc = launch_gemm_pair(p0, p1, m->d.dtype, st);
+    if (g_prof_on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
+    return rc;
+}
+
 extern "C" int mebt_profile_enable(int32_t on) {
     g_prof_on = on != 0;
     for (auto& r : g_prof) { g_ev_pool.push_back(r.a); g_ev_pool.push_back(r.b); }
@@ -423,9 +441,7 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         a.q_in = (mode == MEBT_MODE_LATENT_DEC) ? Tv : Sv;
         // LN1 on query and key with the SAME parameters (gpt.py:180-181), then the projections
         // (gpt.py:126-128); the three [d,d] weights are adjacent in W so QKV / KV fuse.  The key side
-        // (LN + KV projection) is independent of the query side: it runs on the side stream.
-        const bool side = m->use_side && mode != MEBT_MODE_LATENT_SELF && Mk > 0;
-        hipStream_t sk = side ? m->side : st;
+        // is independent of the query side: both LayerNorms are one launch, both projections are one launch.
         {
             LnFwdParams lj[MEBT_LN_MAXJ];
             int nj = 0;
@@ -450,7 +466,6 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
             }
             RC(launch_ln_fwd_multi(lj, nj, dt, st));
         }
-        if (side) RC(fork_side(m, st));
         if (mode == MEBT_MODE_LATENT_SELF) {
             GemmParams p = gp(a.qn, m->Wop(o.wq), a.q, Mq, 3 * d, d, d, d, 3 * d, 1, 1);
             p.bias = m->P + o.bq;
@@ -458,12 +473,10 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         } else {
             GemmParams pk = gp(a.kn, m->Wop(o.wk), a.k, Mk, 2 * d, d, d, d, 2 * d, 1, 1);
             pk.bias = m->P + o.bk;
-            RC(gemm(m, pk, sk));
             GemmParams p = gp(a.qn, m->Wop(o.wq), a.q, Mq, d, d, d, d, d, 1, 1);
             p.bias = m->P + o.bq;
-            RC(gemm(m, p, st));
+            RC(gemm_pair(m, pk, p, st));         // key/value and query projections in one launch
         }
-        if (side) { MEBT_HIP_CHECK(hipEventRecord(m->ev_join, m->side)); MEBT_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join, 0)); }
         // softmax(q k^T / sqrt(hd)) v  (gpt.py:131-137)
         AttnParams ap;
         memset(&ap, 0, sizeof(ap));
@@ -761,8 +774,12 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         lv.wgrad(sc.dqkv_q, d, a.qn, d, m->gW + o.wq, d, d, Mq);
         lv.colsum(sc.dqkv_k, Mk, 2 * d, 2 * d, m->gP + o.bk);
         lv.wgrad(sc.dqkv_k, 2 * d, a.kn, d, m->gW + o.wk, 2 * d, d, Mk);
-        RC(dgrad(m, sc.dqkv_q, d, o.wq, sc.dqn, Mq, d, d, EPI_RESID, sc.dx, d, st));
-        if (Mk > 0) RC(dgrad(m, sc.dqkv_k, 2 * d, o.wk, sc.dkn, Mk, 2 * d, d, EPI_NONE, nullptr, 0, st));
+        {
+            GemmParams pq = gp(sc.dqkv_q, m->Wop(o.wq), sc.dqn, Mq, d, d, d, d, d, 1, 0);
+            pq.epilogue = EPI_RESID; pq.aux = sc.dx; pq.ld_aux = d;
+            GemmParams pk = gp(sc.dqkv_k, m->Wop(o.wk), sc.dkn, Mk, d, 2 * d, 2 * d, d, d, 1, 0);
+            if (Mk > 0) RC(gemm_pair(m, pk, pq, st)); else RC(gemm(m, pq, st));
+        }
         if (side) RC(fork_side(m, st));
         RC(flush_leaves(m, lv, sd));
         if (mode == MEBT_MODE_LATENT_ENC) {

@@ -455,6 +455,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams p) 
     gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE>(p, m0, n0, kt0, kt1, smem, gridDim.z > 1, blockIdx.z == 0);
 }
 
+struct GemmPair { GemmParams p[2]; int tiles0; int ntx[2]; };
+template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmPair g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int which = (int)blockIdx.x >= g.tiles0 ? 1 : 0;
+    const GemmParams& p = g.p[which];
+    const int t = blockIdx.x - (which ? g.tiles0 : 0);
+    const int m0 = (t / g.ntx[which]) * TBM, n0 = (t % g.ntx[which]) * TBN;
+    gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE>(p, m0, n0, 0, (p.K + BK - 1) / BK, smem, false, true);
+}
+
 // grouped weight gradients: blockIdx.x enumerates the tiles of all groups (RC x RC, fp32 result)
 template <int TBM, int TBN, int NSTAGE>
 __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w) {
@@ -806,6 +817,90 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     return MEBT_OK;
 }
 
+static void launch_pair_config(GemmPair& g, int tbm, int tbn, int staging, hipStream_t stream) {
+    int tiles[2];
+    for (int i = 0; i < 2; ++i) {
+        g.ntx[i] = (g.p[i].N + tbn - 1) / tbn;
+        tiles[i] = ((g.p[i].M + tbm - 1) / tbm) * g.ntx[i];
+    }
+    g.tiles0 = tiles[0];
+    const dim3 grid(tiles[0] + tiles[1]);
+#define PAIR_T(AK, BKC, TM_, TN_)                                                                                                                          \
+    do {                                                                                                                                                  \
+        if (staging >= 4 && 4 * (TM_ + TN_) * BK * 2 <= 128 * 1024) hipLaunchKernelGGL((gemm_pair_kernel<AK, BKC, TM_, TN_, (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024 ? 4 : 2)>), grid, dim3(256), 4 * (TM_ + TN_) * BK * 2, stream, g); \
+        else if (staging >= 3) hipLaunchKernelGGL((gemm_pair_kernel<AK, BKC, TM_, TN_, 3>), grid, dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, g);          \
+        else hipLaunchKernelGGL((gemm_pair_kernel<AK, BKC, TM_, TN_, 2>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, g);                           \
+    } while (0)
+#define PAIR_L(AK, BKC)                                                  \
+    do {                                                                 \
+        if (tbm == 128 && tbn == 128) PAIR_T(AK, BKC, 128, 128);         \
+        else if (tbm == 192 && tbn == 128) PAIR_T(AK, BKC, 192, 128);    \
+        else if (tbm == 96 && tbn == 128) PAIR_T(AK, BKC, 96, 128);      \
+        else if (tbm == 96 && tbn == 64) PAIR_T(AK, BKC, 96, 64);        \
+        else if (tbm == 128 && tbn == 64) PAIR_T(AK, BKC, 128, 64);      \
+        else if (tbm == 64 && tbn == 128) PAIR_T(AK, BKC, 64, 128);      \
+        else PAIR_T(AK, BKC, 64, 64);                                    \
+    } while (0)
+    if (g.p[0].b_kc) PAIR_L(true, true);
+    else PAIR_L(true, false);
+#undef PAIR_L
+#undef PAIR_T
+}
+
+int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipStream_t stream) {
+    const bool ok = dtype == MEBT_BF16 && p0.a_kc && p1.a_kc && p0.b_kc == p1.b_kc && p0.M > 0 && p0.N > 0 && p1.M > 0 && p1.N > 0 &&
+                    p0.K > 0 && p1.K > 0 && !p0.beta && !p1.beta && !p0.c_f32 && !p1.c_f32 && !g_gemm_force_tile && g_gemm_dma < 0 &&
+                    p0.K % BK == 0 && p1.K % BK == 0 && p0.N % 8 == 0 && p1.N % 8 == 0 && !g_gemm_nostore;
+    if (!ok) {                       // anything unusual: two ordinary launches (with their own validation)
+        if (int rc = launch_gemm(p0, dtype, stream)) return rc;
+        return launch_gemm(p1, dtype, stream);
+    }
+    if (g_autotune < 0) {
+        const char* e = getenv("MEBT_GEMM_AUTOTUNE");
+        g_autotune = (e && e[0] == '0') ? 0 : 1;
+        const char* l = getenv("MEBT_GEMM_TUNE_LOG");
+        g_tune_log = (l && l[0] == '1') ? 1 : 0;
+    }
+    GemmPair g;
+    g.p[0] = p0; g.p[1] = p1;
+    int tbm = 96, tbn = 128, staging = 3;
+    if (g_autotune) {
+        const TuneKey key{p0.M * 131 + p1.M, p0.N * 131 + p1.N, p0.K * 131 + p1.K,
+                          0x20000000 | p0.b_kc | (p0.epilogue << 2) | (p1.epilogue << 5) | ((p0.drop.thresh != 0) << 8)};
+        auto it = g_tuned.find(key);
+        if (it == g_tuned.end()) {
+            static hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (!e0) { MEBT_HIP_CHECK(hipEventCreate(&e0)); MEBT_HIP_CHECK(hipEventCreate(&e1)); }
+            if (int rc = tune_begin()) return rc;
+            static const int tiles[7][2] = {{192, 128}, {128, 128}, {96, 128}, {128, 64}, {64, 128}, {96, 64}, {64, 64}};
+            float best = 1e30f;
+            for (int t = 0; t < 7; ++t)
+                for (int st = 2; st <= 4; ++st) {
+                    if (st * (tiles[t][0] + tiles[t][1]) * BK * 2 > 128 * 1024) continue;
+                    float ms = 0.f;
+                    if (int rc = time_cold([&] { launch_pair_config(g, tiles[t][0], tiles[t][1], st, stream); }, stream, e0, e1, ms)) return rc;
+                    if (ms < best) { best = ms; tbm = tiles[t][0]; tbn = tiles[t][1]; staging = st; }
+                }
+            // ... against the two products launched one after the other with their own tuned configurations
+            float sep = 0.f;
+            if (int rc = time_cold([&] { launch_gemm(p0, MEBT_BF16, stream); launch_gemm(p1, MEBT_BF16, stream); }, stream, e0, e1, sep)) return rc;
+            if (int rc = time_cold([&] { launch_gemm(p0, MEBT_BF16, stream); launch_gemm(p1, MEBT_BF16, stream); }, stream, e0, e1, sep)) return rc;
+            if (g_tune_log)
+                fprintf(stderr, "[mebt gemm autotune] pair %dx%dx%d + %dx%dx%d b_kc=%d -> %dx%d ring %d (%.1f us cold; separate launches %.1f us)\n",
+                        p0.M, p0.N, p0.K, p1.M, p1.N, p1.K, p0.b_kc, tbm, tbn, staging, best * 1e3f, sep * 1e3f);
+            it = g_tuned.emplace(key, sep <= best ? 0 : ((tbm << 16) | (tbn << 8) | staging)).first;
+        }
+        if (it->second == 0) {       // the pair did not win on this shape
+            if (int rc = launch_gemm(p0, dtype, stream)) return rc;
+            return launch_gemm(p1, dtype, stream);
+        }
+        tbm = it->second >> 16; tbn = (it->second >> 8) & 255; staging = it->second & 255;
+    }
+    launch_pair_config(g, tbm, tbn, staging, stream);
+    MEBT_HIP_CHECK(hipGetLastError());
+    return MEBT_OK;
+}
+
 // grouped weight gradients of one block.  Items are ordered by reduction length, longest first (the key
 // projection reduces over twice as many tokens as the rest: started last, its tiles were the tail of the
 // launch), and the block tile / ring depth are autotuned per group signature like the single GEMMs.
@@ -888,6 +983,17 @@ int gemm_init_attributes() {
     } while (0)
     SET_G(128, 128); SET_G(128, 64); SET_G(64, 128); SET_G(64, 64);
 #undef SET_G
+#define SET_P(AK, BKC, TM_, TN_)                                                                                                                           \
+    do {                                                                                                                                                  \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pair_kernel<AK, BKC, TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2)); \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pair_kernel<AK, BKC, TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM_ + TN_) * BK * 2)); \
+        if (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pair_kernel<AK, BKC, TM_, TN_, (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024 ? 4 : 2)>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (TM_ + TN_) * BK * 2)); \
+    } while (0)
+#define SET_PAIR(AK, BKC) do { SET_P(AK, BKC, 192, 128); SET_P(AK, BKC, 128, 128); SET_P(AK, BKC, 96, 128); SET_P(AK, BKC, 128, 64); SET_P(AK, BKC, 64, 128); SET_P(AK, BKC, 96, 64); SET_P(AK, BKC, 64, 64); } while (0)
+    SET_PAIR(true, true);
+    SET_PAIR(true, false);
+#undef SET_PAIR
+#undef SET_P
     // dynamic LDS up to 64 KiB
 #define SET_T(AK, BKC, TM_, TN_)                                                                                                  \
     do {                                                                                                                         \
