@@ -178,6 +178,40 @@ template <> __device__ __forceinline__ int rc_swizzle<96>(int krow) { return ((k
 // 384-B rows: rows q and q+2 coincide mod 256 B, and so do r and r+8
 template <> __device__ __forceinline__ int rc_swizzle<192>(int krow) { return (((krow >> 1) & 1) << 1) | (((krow >> 3) & 1) << 2); }
 
+// XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs (consecutive linear ids on
+// consecutive XCDs) and each XCD has its own 4 MB L2, so the tiles an XCD works on at the same time should
+// share operand rows: XCD x gets a COMPACT xr x xc sub-grid of the tile grid (xr * xc = 8), the shape chosen
+// to minimise the bytes all XCDs fetch together, xc * |A| + xr * |B| with |A| ~ M and |B| ~ N (both x K).
+// Measured with rocprofv3 FETCH_SIZE before this mapping: 3-6x the algorithmic operand bytes (the grouped
+// weight-gradient launch streamed 357 MB for 62 MB of operands at 4.3 TB/s — bandwidth-bound on re-reads).
+// `t` = linear workgroup index within the product; any t with equal t % 8 share an XCD.
+__device__ __forceinline__ void xcd_tile(int t, int ntx, int nty, int M, int N, int& tr, int& tc) {
+    const int T = ntx * nty;
+    if (T & 7) {                              // no whole sub-grids: contiguous runs along N (bijective for any T)
+        const int q = T >> 3, r = T & 7, xcd = t & 7, idx = t >> 3;
+        const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tr = b / ntx; tc = b % ntx;
+        return;
+    }
+    int xr = 0, xc = 0;
+    long best = 0x7FFFFFFFFFFFFFFFl;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int r = 8 >> s, c = 1 << s;     // (8,1) (4,2) (2,4) (1,8)
+        if (nty % r || ntx % c) continue;
+        const long cost = (long)c * M + (long)r * N;
+        if (cost < best) { best = cost; xr = r; xc = c; }
+    }
+    if (!xr) {                                // T % 8 == 0 but neither dimension splits (e.g. 3 x 8 ... handled above); fall back
+        tr = t / ntx; tc = t % ntx;
+        return;
+    }
+    const int xcd = t & 7, idx = t >> 3;
+    const int lr = nty / xr, lc = ntx / xc;
+    tr = (xcd / xc) * lr + idx / lc;
+    tc = (xcd % xc) * lc + idx % lc;
+}
+
 template <bool KC, int ROWS>
 struct TileLoader {
     // per-thread 16-byte chunks of a [ROWS x 64] (KC) or [64 x ROWS] (RC) bf16 tile
@@ -303,15 +337,10 @@ __device__ __forceinline__ void gemm_tile_regstaged(const GemmParams& p, int m0,
 template <bool A_KC, bool B_KC, int TBM, int TBN>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD
-    // a contiguous run of tiles along N (they share the same A rows -> L2 hits).
-    const int ntx = gridDim.x, nty = gridDim.y, ntiles = ntx * nty;
-    int bid = blockIdx.y * ntx + blockIdx.x;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int m0 = (bid / ntx) * TBM, n0 = (bid % ntx) * TBN;
+    const int ntx = gridDim.x, nty = gridDim.y;
+    int tr, tc;
+    xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
+    const int m0 = tr * TBM, n0 = tc * TBN;
     const int nkt = (p.K + BK - 1) / BK;
     const int per = (nkt + gridDim.z - 1) / gridDim.z;
     const int kt0 = blockIdx.z * per;
@@ -440,13 +469,10 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
 template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ntx = gridDim.x, nty = gridDim.y, ntiles = ntx * nty;
-    int bid = blockIdx.y * ntx + blockIdx.x;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int m0 = (bid / ntx) * TBM, n0 = (bid % ntx) * TBN;
+    const int ntx = gridDim.x, nty = gridDim.y;
+    int tr, tc;
+    xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
+    const int m0 = tr * TBM, n0 = tc * TBN;
     const int nkt = (p.K + BK - 1) / BK;
     const int per = (nkt + gridDim.z - 1) / gridDim.z;
     const int kt0 = blockIdx.z * per;
@@ -462,7 +488,9 @@ __global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmPair g) {
     const int which = (int)blockIdx.x >= g.tiles0 ? 1 : 0;
     const GemmParams& p = g.p[which];
     const int t = blockIdx.x - (which ? g.tiles0 : 0);
-    const int m0 = (t / g.ntx[which]) * TBM, n0 = (t % g.ntx[which]) * TBN;
+    int tr, tc;
+    xcd_tile(t, g.ntx[which], (p.M + TBM - 1) / TBM, p.M, p.N, tr, tc);
+    const int m0 = tr * TBM, n0 = tc * TBN;
     gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE>(p, m0, n0, 0, (p.K + BK - 1) / BK, smem, false, true);
 }
 
@@ -480,7 +508,9 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w
     p.A = it.A; p.B = it.B; p.C = it.C; p.C2 = nullptr; p.bias = nullptr; p.aux = nullptr;
     p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb; p.ldc = it.ldc; p.ld_aux = 0;
     p.a_kc = 0; p.b_kc = 0; p.epilogue = EPI_NONE; p.c_f32 = 1; p.beta = 0; p.split_k = 1; p.drop.thresh = 0;
-    const int m0 = (t / it.ntx) * TBM, n0 = (t % it.ntx) * TBN;
+    int tr, tc;
+    xcd_tile(t, it.ntx, (it.M + TBM - 1) / TBM, it.M, it.N, tr, tc);
+    const int m0 = tr * TBM, n0 = tc * TBN;
     gemm_tile_dma<false, false, TBM, TBN, NSTAGE>(p, m0, n0, 0, (it.K + BK - 1) / BK, smem, false, false);
 }
 
@@ -689,6 +719,31 @@ struct TuneHash {
 };
 static std::unordered_map<TuneKey, int, TuneHash> g_tuned;      // -> (tbm << 16) | (tbn << 8) | staging
 static int g_autotune = -1, g_tune_log = 0;
+static const char* g_tune_cache = nullptr;                       // MEBT_GEMM_TUNE_CACHE: text file of tuned choices
+
+// environment: MEBT_GEMM_AUTOTUNE=0 disables tuning, MEBT_GEMM_TUNE_LOG=1 prints choices, MEBT_GEMM_TUNE_CACHE=<file>
+// loads earlier choices at start-up and appends new ones (a later process then launches no tuning candidates)
+static void tune_init() {
+    if (g_autotune >= 0) return;
+    const char* e = getenv("MEBT_GEMM_AUTOTUNE");
+    g_autotune = (e && e[0] == '0') ? 0 : 1;
+    const char* l = getenv("MEBT_GEMM_TUNE_LOG");
+    g_tune_log = (l && l[0] == '1') ? 1 : 0;
+    g_tune_cache = getenv("MEBT_GEMM_TUNE_CACHE");
+    if (g_tune_cache && g_tune_cache[0]) {
+        if (FILE* f = fopen(g_tune_cache, "r")) {
+            TuneKey k; int v;
+            while (fscanf(f, "%d %d %d %d %d", &k.M, &k.N, &k.K, &k.flags, &v) == 5) g_tuned[k] = v;
+            fclose(f);
+        }
+    } else {
+        g_tune_cache = nullptr;
+    }
+}
+static void tune_remember(const TuneKey& k, int v) {
+    if (!g_tune_cache) return;
+    if (FILE* f = fopen(g_tune_cache, "a")) { fprintf(f, "%d %d %d %d %d\n", k.M, k.N, k.K, k.flags, v); fclose(f); }
+}
 
 static void heuristic_config(const GemmParams& p, int& tbm, int& tbn, int& staging) {
     // cold-operand measurements (profiles/r01_gemm_variants_cold.txt), all three layouts alike:
@@ -777,12 +832,7 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         MEBT_HIP_CHECK(hipMemset2DAsync(p.C, (size_t)p.ldc * 4, 0, (size_t)p.N * 4, p.M, stream));
     }
     if (dtype == MEBT_BF16) {
-        if (g_autotune < 0) {
-            const char* e = getenv("MEBT_GEMM_AUTOTUNE");
-            g_autotune = (e && e[0] == '0') ? 0 : 1;
-            const char* l = getenv("MEBT_GEMM_TUNE_LOG");
-            g_tune_log = (l && l[0] == '1') ? 1 : 0;
-        }
+        tune_init();
         int tbm = 128, tbn = 128, staging = 2;
         const bool forced = g_gemm_force_tile || g_gemm_dma >= 0;
         const bool idempotent = !p.beta && split == 1 && p.C != p.aux;
@@ -793,6 +843,7 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
                 heuristic_config(p, tbm, tbn, staging);
                 if (int rc = autotune_config(p, stream, tbm, tbn, staging)) return rc;
                 it = g_tuned.emplace(key, (tbm << 16) | (tbn << 8) | staging).first;
+                tune_remember(key, it->second);
             }
             tbm = it->second >> 16; tbn = (it->second >> 8) & 255; staging = it->second & 255;
         } else {
@@ -855,12 +906,7 @@ int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipS
         if (int rc = launch_gemm(p0, dtype, stream)) return rc;
         return launch_gemm(p1, dtype, stream);
     }
-    if (g_autotune < 0) {
-        const char* e = getenv("MEBT_GEMM_AUTOTUNE");
-        g_autotune = (e && e[0] == '0') ? 0 : 1;
-        const char* l = getenv("MEBT_GEMM_TUNE_LOG");
-        g_tune_log = (l && l[0] == '1') ? 1 : 0;
-    }
+    tune_init();
     GemmPair g;
     g.p[0] = p0; g.p[1] = p1;
     int tbm = 96, tbn = 128, staging = 3;
@@ -889,6 +935,7 @@ int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipS
                 fprintf(stderr, "[mebt gemm autotune] pair %dx%dx%d + %dx%dx%d b_kc=%d -> %dx%d ring %d (%.1f us cold; separate launches %.1f us)\n",
                         p0.M, p0.N, p0.K, p1.M, p1.N, p1.K, p0.b_kc, tbm, tbn, staging, best * 1e3f, sep * 1e3f);
             it = g_tuned.emplace(key, sep <= best ? 0 : ((tbm << 16) | (tbn << 8) | staging)).first;
+            tune_remember(key, it->second);
         }
         if (it->second == 0) {       // the pair did not win on this shape
             if (int rc = launch_gemm(p0, dtype, stream)) return rc;
@@ -937,12 +984,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
     if (!n) return MEBT_OK;
     for (int i = 1; i < n; ++i)              // insertion sort, K descending
         for (int j = i; j > 0 && c.g[j].K > c.g[j - 1].K; --j) { const GroupedWgrad::Item t = c.g[j]; c.g[j] = c.g[j - 1]; c.g[j - 1] = t; }
-    if (g_autotune < 0) {
-        const char* e = getenv("MEBT_GEMM_AUTOTUNE");
-        g_autotune = (e && e[0] == '0') ? 0 : 1;
-        const char* l = getenv("MEBT_GEMM_TUNE_LOG");
-        g_tune_log = (l && l[0] == '1') ? 1 : 0;
-    }
+    tune_init();
     int tbm = 128, tbn = 128, stages = g_grouped_stages == 3 ? 3 : 2;
     if (g_autotune) {
         TuneKey key{0, 0, 0, 0x40000000 | n};
@@ -966,6 +1008,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
                 fprintf(stderr, " -> %dx%d ring %d (%.1f us cold)\n", tbm, tbn, stages, best * 1e3f);
             }
             it = g_tuned.emplace(key, (tbm << 16) | (tbn << 8) | stages).first;
+            tune_remember(key, it->second);
         }
         tbm = it->second >> 16; tbn = (it->second >> 8) & 255; stages = it->second & 255;
     }

@@ -16,7 +16,7 @@ def per_kernel(d, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        k = "gemm_bf16" if ("gemm_bf16" in name or "wgrad_grouped" in name) else name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
+        k = "gemm_bf16" if ("gemm_bf16" in name or "wgrad_grouped" in name or "gemm_pair" in name) else name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
         tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"])
         n[k] = n.get(k, 0) + 1
     return tot, n
