@@ -95,12 +95,23 @@ int mebt_adamw_step(mebt_model* m, float* mW, float* vW, float* mP, float* vP, f
                     float eps, float weight_decay, int32_t step, float grad_scale, mebt_stream_t stream);
 
 /* The same update restricted to one gradient bucket — kind 0: head weight; 1: blocks layer_lo..layer_hi;
- * 2: the P tail (ln_f + embeddings); 3: everything.  Buckets are disjoint: a caller may issue each on its
+ * 2: the P tail (ln_f + embeddings); 3: everything; 4: everything except the blocks' Linear weights (after a
+ * backward with the fused optimizer armed).  Buckets are disjoint: a caller may issue each on its
  * own stream as soon as that bucket's gradients are final (after its all-reduce), overlapping the HBM-bound
  * optimizer with the rest of backward. */
 int mebt_adamw_range(mebt_model* m, float* mW, float* vW, float* mP, float* vP, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int32_t step, float grad_scale, int32_t kind, int32_t layer_hi,
                      int32_t layer_lo, mebt_stream_t stream);
+
+/* Optimizer-in-backward (single-process training): armed with step >= 1, the next mebt_backward_layers applies
+ * AdamW to every block's Linear weights INSIDE the weight-gradient launch (the gradient tile is consumed from
+ * registers; it is not stored in gW, and W / the bf16 mirror / mW / vW are updated in place), which removes
+ * 8 of the 34 bytes per parameter the separate optimizer pass moves and hides the rest behind the MFMA work.
+ * The remaining parameters are then updated with mebt_adamw_range(kind = 4).  step <= 0 disarms.  Same math as
+ * mebt_adamw_step (torch.optim.AdamW, transformer.py:790-797); not usable when gradients must be all-reduced
+ * or inspected first. */
+int mebt_model_set_fused_adamw(mebt_model* m, float* mW, float* vW, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int32_t step, float grad_scale);
 
 /* ---- operator entry points (building blocks; also what the parity tests call) ---------------------- */
 /* C[M,N] = sum_k A(m,k) B(n,k) + bias, epilogue 0 none / 1 GELU (C=pre, C2=gelu) / 2 +aux residual /

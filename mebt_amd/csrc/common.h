@@ -125,6 +125,25 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// AdamW (decoupled weight decay, torch.optim.AdamW semantics): one definition for the streaming kernel and
+// for the weight-gradient epilogue that applies the update in place (optimizer-in-backward)
+// ---------------------------------------------------------------------------------------------
+struct AdamWHyper { float lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale; };
+__device__ __forceinline__ void adamw_update4(f32x4& p, const f32x4& g, f32x4& m, f32x4& v, const AdamWHyper& a) {
+    const float step_size = a.lr / a.bc1;
+    const float inv_sqrt_bc2 = rsqrtf(a.bc2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float gj = g[j] * a.grad_scale;
+        p[j] *= 1.0f - a.lr * a.weight_decay;
+        m[j] = a.beta1 * m[j] + (1.0f - a.beta1) * gj;
+        v[j] = a.beta2 * v[j] + (1.0f - a.beta2) * gj * gj;
+        const float denom = sqrtf(v[j]) * inv_sqrt_bc2 + a.eps;
+        p[j] -= step_size * (m[j] / denom);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // counter-based RNG for dropout (Philox-like mixing of a 64-bit counter; one 32-bit draw per call).
 // The mask of element `idx` at site `site` of step `seed` is recomputed in backward, never stored.
 // ---------------------------------------------------------------------------------------------

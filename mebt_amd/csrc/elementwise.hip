@@ -591,22 +591,13 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const CeBwdParams p) {
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
     // (nontemporal loads/stores and grids of 2048..16384 workgroups were tried: all within noise, 4.5-5.4 TB/s
     //  depending on the box, of the ~6.3 TB/s a float4 copy reaches)
-    const float step_size = a.lr / a.bc1;
-    const float inv_sqrt_bc2 = rsqrtf(a.bc2);
+    const AdamWHyper h = {a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.bc1, a.bc2, a.grad_scale};
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (size_t)gridDim.x * 1024) {
         f32x4 p = *reinterpret_cast<const f32x4*>(a.p + i);
-        f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i);
         f32x4 m = *reinterpret_cast<const f32x4*>(a.m + i);
         f32x4 v = *reinterpret_cast<const f32x4*>(a.v + i);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float gj = g[j] * a.grad_scale;
-            p[j] *= 1.0f - a.lr * a.weight_decay;
-            m[j] = a.beta1 * m[j] + (1.0f - a.beta1) * gj;
-            v[j] = a.beta2 * v[j] + (1.0f - a.beta2) * gj * gj;
-            const float denom = sqrtf(v[j]) * inv_sqrt_bc2 + a.eps;
-            p[j] -= step_size * (m[j] / denom);
-        }
+        adamw_update4(p, g, m, v, h);
         *reinterpret_cast<f32x4*>(a.p + i) = p;
         *reinterpret_cast<f32x4*>(a.m + i) = m;
         *reinterpret_cast<f32x4*>(a.v + i) = v;

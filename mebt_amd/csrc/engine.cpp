@@ -80,6 +80,11 @@ struct mebt_model {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_e1 = nullptr, ev_layer[2] = {nullptr, nullptr}, ev_join = nullptr;
     bool use_side = true;
+    // optimizer-in-backward (mebt_model_set_fused_adamw): when armed, the weight gradients of the blocks are applied
+    // to W (AdamW) inside the weight-gradient launch instead of being stored in gW
+    bool fused_on = false;
+    float *fused_mW = nullptr, *fused_vW = nullptr;
+    AdamWHyper fused_h = {0, 0, 0, 0, 0, 1, 1, 1};
     int esz() const { return d.dtype == MEBT_BF16 ? 2 : 4; }
     // weight operand for GEMMs (bf16 mirror in bf16 mode)
     const void* Wop(int64_t off) const {
@@ -656,6 +661,17 @@ struct Leaves {
     }
 };
 
+// AdamW (armed fused hyper-parameters) on the weight whose gradient starts at `g` (a contiguous [n_out,k_in] block of gW)
+static int fused_adamw_slice(mebt_model* m, const float* g, int64_t n, hipStream_t st) {
+    const int64_t off = g - m->gW;
+    AdamWParams a;
+    a.p = m->W + off; a.g = g; a.m = m->fused_mW + off; a.v = m->fused_vW + off; a.n = (size_t)n;
+    a.p_bf16 = m->Wlp ? (void*)((char*)m->Wlp + off * 2) : nullptr;
+    a.lr = m->fused_h.lr; a.beta1 = m->fused_h.beta1; a.beta2 = m->fused_h.beta2; a.eps = m->fused_h.eps;
+    a.weight_decay = m->fused_h.weight_decay; a.bc1 = m->fused_h.bc1; a.bc2 = m->fused_h.bc2; a.grad_scale = m->fused_h.grad_scale;
+    return launch_adamw(a, st);
+}
+
 static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd) {
     const int dt = m->d.dtype;
     RC(launch_colsum_grouped(lv.c, dt, sd));
@@ -676,16 +692,27 @@ static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd) {
             }
             (void)hipEventRecord(r.a, sd);
         }
+        if (m->fused_on) {
+            lv.w.fused = 1; lv.w.W = m->W; lv.w.gW = m->gW; lv.w.mW = m->fused_mW; lv.w.vW = m->fused_vW; lv.w.Wlp = m->Wlp;
+            lv.w.opt = m->fused_h;
+            for (int i = 0; i < lv.w.n; ++i) {      // an empty reduction still decays / advances the moments: its gradient is the zero just written
+                const GroupedWgrad::Item& it = lv.w.g[i];
+                if (it.K <= 0 && it.M > 0 && it.N > 0) RC(fused_adamw_slice(m, it.C, (int64_t)it.M * it.N, sd));
+            }
+        }
         const int rc = launch_wgrad_grouped(lv.w, dt, sd);
         if (prof) { (void)hipEventRecord(r.b, sd); g_prof.push_back(r); }
         return rc;
     }
     for (int i = 0; i < lv.w.n; ++i) {
         const GroupedWgrad::Item& it = lv.w.g[i];
-        if (it.K <= 0) continue;
-        GemmParams p = gp(it.A, it.B, it.C, it.M, it.N, it.K, it.lda, it.ldb, it.ldc, 0, 0);
-        p.c_f32 = 1;
-        RC(gemm(m, p, sd));
+        if (it.K > 0) {
+            GemmParams p = gp(it.A, it.B, it.C, it.M, it.N, it.K, it.lda, it.ldb, it.ldc, 0, 0);
+            p.c_f32 = 1;
+            RC(gemm(m, p, sd));
+        }
+        // fp32 parity mode has no fused epilogue: same semantics with the streaming kernel on this weight
+        if (m->fused_on && it.M > 0 && it.N > 0) RC(fused_adamw_slice(m, it.C, (int64_t)it.M * it.N, sd));
     }
     return MEBT_OK;
 }
@@ -837,8 +864,9 @@ extern "C" int mebt_backward_embed(mebt_model* m, void* ws, mebt_stream_t stream
 // optimiser
 // ---------------------------------------------------------------------------------------------------
 // AdamW over one gradient bucket: kind 0 = head weight, 1 = blocks layer_lo..layer_hi (their W and P
-// slices), 2 = the P tail (ln_f, mask/sos/pos/tok embeddings), 3 = everything.  Buckets are disjoint,
-// so the caller may run each one on its own stream as soon as that bucket's gradients are final.
+// slices), 2 = the P tail (ln_f, mask/sos/pos/tok embeddings), 3 = everything, 4 = everything EXCEPT the
+// blocks' Linear weights (what is left after a backward with the fused optimizer armed).  Buckets are
+// disjoint, so the caller may run each one on its own stream as soon as that bucket's gradients are final.
 extern "C" int mebt_adamw_range(mebt_model* m, float* mW, float* vW, float* mP, float* vP, float lr, float beta1, float beta2,
                                 float eps, float weight_decay, int32_t step, float grad_scale, int32_t kind, int32_t layer_hi,
                                 int32_t layer_lo, mebt_stream_t stream) {
@@ -855,23 +883,34 @@ extern "C" int mebt_adamw_range(mebt_model* m, float* mW, float* vW, float* mP, 
         a.p_bf16 = lp ? (void*)((char*)lp + off * 2) : nullptr;
         return launch_adamw(a, st);
     };
-    if (kind == 1 || kind == 3) {   // contiguous runs of live layers (torch skips parameters whose grad is None)
-        const int lo = kind == 3 ? 0 : layer_lo, hi = kind == 3 ? m->d.n_layer - 1 : layer_hi;
+    if (kind == 1 || kind == 3 || kind == 4) {   // contiguous runs of live layers (torch skips parameters whose grad is None)
+        const int lo = kind != 1 ? 0 : layer_lo, hi = kind != 1 ? m->d.n_layer - 1 : layer_hi;
         int i = lo;
         while (i <= hi) {
             if (!m->live[i]) { ++i; continue; }
             int j = i;
             while (j + 1 <= hi && m->live[j + 1]) ++j;
-            RC(run(m->W, m->gW, mW, vW, m->Wlp, m->lo[i].wq, (int64_t)(j - i + 1) * 12 * d * d, weight_decay));
+            if (kind != 4) RC(run(m->W, m->gW, mW, vW, m->Wlp, m->lo[i].wq, (int64_t)(j - i + 1) * 12 * d * d, weight_decay));
             RC(run(m->P, m->gP, mP, vP, nullptr, m->lo[i].ln1w, (int64_t)(j - i + 1) * 13 * d, 0.f));
             i = j + 1;
         }
     }
-    if (kind == 0 || kind == 3) RC(run(m->W, m->gW, mW, vW, m->Wlp, m->head_w, (int64_t)m->d.vocab * d, weight_decay));
-    if (kind == 2 || kind == 3) {   // ln_f, mask_emb, sos_emb, pos_emb (always reached) and tok_emb (only through a live latent_enc)
+    if (kind == 0 || kind == 3 || kind == 4) RC(run(m->W, m->gW, mW, vW, m->Wlp, m->head_w, (int64_t)m->d.vocab * d, weight_decay));
+    if (kind == 2 || kind == 3 || kind == 4) {   // ln_f, mask_emb, sos_emb, pos_emb (always reached) and tok_emb (only through a live latent_enc)
         const int64_t tail_n = (m->tok_live ? m->n_p : m->tok_emb) - m->lnf_w;
         RC(run(m->P, m->gP, mP, vP, nullptr, m->lnf_w, tail_n, 0.f));
     }
+    return MEBT_OK;
+}
+
+// Arm (step >= 1) or disarm (step <= 0) the optimizer-in-backward for the blocks' Linear weights.
+extern "C" int mebt_model_set_fused_adamw(mebt_model* m, float* mW, float* vW, float lr, float beta1, float beta2, float eps,
+                                          float weight_decay, int32_t step, float grad_scale) {
+    if (!m) { mebt_set_error("set_fused_adamw: null model"); return MEBT_EINVAL; }
+    if (step <= 0) { m->fused_on = false; return MEBT_OK; }
+    if (!mW || !vW || !m->W || !m->gW) { mebt_set_error("set_fused_adamw: optimizer state / model not bound"); return MEBT_EINVAL; }
+    m->fused_on = true; m->fused_mW = mW; m->fused_vW = vW;
+    m->fused_h = {lr, beta1, beta2, eps, weight_decay, (float)(1.0 - pow((double)beta1, step)), (float)(1.0 - pow((double)beta2, step)), grad_scale};
     return MEBT_OK;
 }
 

@@ -84,10 +84,55 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
 // vector per row pass) is fetched BEFORE the accumulators are staged, all loads back to back at clamped
 // (always valid) addresses: a load under a per-row bounds/epilogue branch makes hipcc wait for it inside
 // the branch, which turned the 16 row passes of a wave into 16-32 dependent L2/HBM round trips.
+// EPI_ADAMW: the tile is a weight gradient; apply AdamW to the parameter tile in place (p, m, v fp32 + bf16 mirror)
+// instead of storing it.  Straight-line per 16-row slab: all 12 loads of the slab's 4 row passes first.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_adamw(const GemmParams& p, const f32x4 (&acc)[TM][TN], char* smem, int wave, int lane,
+                                               int mbase, int nbase) {
+    constexpr int COLS = TN * 16, LD = COLS + 4;
+    float* st = reinterpret_cast<float*>(smem) + wave * (16 * LD);
+    constexpr int LPR = COLS / 4, RPI = 64 / LPR, NPASS = 16 / RPI;
+    const int r0 = lane / LPR, c4 = (lane % LPR) * 4;
+    const int n = nbase + c4;
+    const bool n_ok = n < p.N;
+    const int nc = n_ok ? n : 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        f32x4 pp[NPASS], mm[NPASS], vv[NPASS];
+        size_t ci[NPASS];
+#pragma unroll
+        for (int r = 0; r < NPASS; ++r) {
+            const int m = min(mbase + i * 16 + r * RPI + r0, p.M - 1);
+            ci[r] = (size_t)m * p.ldc + nc;
+            pp[r] = *reinterpret_cast<const f32x4*>(p.opt_p + ci[r]);
+            mm[r] = *reinterpret_cast<const f32x4*>(p.opt_m + ci[r]);
+            vv[r] = *reinterpret_cast<const f32x4*>(p.opt_v + ci[r]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            *reinterpret_cast<f32x4*>(st + (lane & 15) * LD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < NPASS; ++r) {
+            const int row = r * RPI + r0;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(st + row * LD + c4);
+            adamw_update4(pp[r], g, mm[r], vv[r], p.opt);
+            if (mbase + i * 16 + row < p.M && n_ok) {
+                *reinterpret_cast<f32x4*>(p.opt_p + ci[r]) = pp[r];
+                *reinterpret_cast<f32x4*>(p.opt_m + ci[r]) = mm[r];
+                *reinterpret_cast<f32x4*>(p.opt_v + ci[r]) = vv[r];
+                if (p.opt_lp) store4<bf16_t>(reinterpret_cast<bf16_t*>(p.opt_lp) + ci[r], pp[r]);
+            }
+        }
+    }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x4 (&acc)[TM][TN], char* smem, int wave, int lane,
                                                  int mbase, int nbase, bool add_bias, bool atomic) {
     typedef bf16_t TA;
+    if (p.epilogue == EPI_ADAMW) { epilogue_adamw<TM, TN>(p, acc, smem, wave, lane, mbase, nbase); return; }
     constexpr int COLS = TN * 16, LD = COLS + 4;          // fp32 elements per staged row
     float* st = reinterpret_cast<float*>(smem) + wave * (16 * LD);   // one 16-row slab per wave (<= 4.3 KiB)
     constexpr int LPR = COLS / 4;                         // lanes per row
@@ -508,6 +553,12 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w
     p.A = it.A; p.B = it.B; p.C = it.C; p.C2 = nullptr; p.bias = nullptr; p.aux = nullptr;
     p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb; p.ldc = it.ldc; p.ld_aux = 0;
     p.a_kc = 0; p.b_kc = 0; p.epilogue = EPI_NONE; p.c_f32 = 1; p.beta = 0; p.split_k = 1; p.drop.thresh = 0;
+    if (w.fused) {
+        const ptrdiff_t off = it.C - w.gW;
+        p.epilogue = EPI_ADAMW; p.opt = w.opt;
+        p.opt_p = w.W + off; p.opt_m = w.mW + off; p.opt_v = w.vW + off;
+        p.opt_lp = w.Wlp ? (void*)(reinterpret_cast<bf16_t*>(w.Wlp) + off) : nullptr;
+    }
     int tr, tc;
     xcd_tile(t, it.ntx, (it.M + TBM - 1) / TBM, it.M, it.N, tr, tc);
     const int m0 = tr * TBM, n0 = tc * TBN;
@@ -982,12 +1033,13 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
     }
     c.n = n;
     if (!n) return MEBT_OK;
+    c.fused = w.fused; c.W = w.W; c.gW = w.gW; c.mW = w.mW; c.vW = w.vW; c.Wlp = w.Wlp; c.opt = w.opt;
     for (int i = 1; i < n; ++i)              // insertion sort, K descending
         for (int j = i; j > 0 && c.g[j].K > c.g[j - 1].K; --j) { const GroupedWgrad::Item t = c.g[j]; c.g[j] = c.g[j - 1]; c.g[j - 1] = t; }
     tune_init();
     int tbm = 128, tbn = 128, stages = g_grouped_stages == 3 ? 3 : 2;
     if (g_autotune) {
-        TuneKey key{0, 0, 0, 0x40000000 | n};
+        TuneKey key{0, 0, 0, 0x40000000 | n | (c.fused ? 0x100 : 0)};
         for (int i = 0; i < n; ++i) { key.M = key.M * 31 + c.g[i].M; key.N = key.N * 31 + c.g[i].N; key.K = key.K * 31 + c.g[i].K; }
         auto it = g_tuned.find(key);
         if (it == g_tuned.end()) {
@@ -996,10 +1048,14 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
             if (int rc = tune_begin()) return rc;
             static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
             float best = 1e30f;
+            // candidates are timed in the mode that will run; a fused launch is not idempotent, so its candidates
+            // run with a zero learning rate, zero decay and beta1 = beta2 = 1 (p, m, v are rewritten unchanged)
+            GroupedWgrad tc = c;
+            if (tc.fused) { tc.opt.lr = 0.f; tc.opt.weight_decay = 0.f; tc.opt.beta1 = 1.f; tc.opt.beta2 = 1.f; }
             for (int t = 0; t < 4; ++t)
                 for (int st = 2; st <= 4; ++st) {
                     float ms = 0.f;
-                    if (int rc = time_cold([&] { launch_grouped_config(c, tiles[t][0], tiles[t][1], st, stream); }, stream, e0, e1, ms)) return rc;
+                    if (int rc = time_cold([&] { launch_grouped_config(tc, tiles[t][0], tiles[t][1], st, stream); }, stream, e0, e1, ms)) return rc;
                     if (ms < best) { best = ms; tbm = tiles[t][0]; tbn = tiles[t][1]; stages = st; }
                 }
             if (g_tune_log) {

@@ -14,7 +14,7 @@ static inline DropCfg make_drop(uint64_t seed, uint32_t site, float p) {
     d.inv_keep = d.thresh ? (float)(65536.0 / (65536.0 - d.thresh)) : 1.0f;
     return d;
 }
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_GELU_BWD = 3 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_GELU_BWD = 3, EPI_ADAMW = 4 /* internal: grouped weight gradients only */ };
 
 // C[M,N] = sum_k A(m,k) B(n,k) (+bias) (+epilogue).  *_kc = 1: operand stored [rows][K];
 // *_kc = 0: stored [K][rows].  ld* are element strides of the slow dimension.
@@ -33,6 +33,9 @@ struct GemmParams {
     int beta;            // fp32 C only: C += result
     int split_k;         // 0 = heuristic, 1 = never, >1 = forced (fp32 C, EPI_NONE only)
     DropCfg drop;        // EPI_RESID: C = dropout(acc + bias) + aux   (resid_pdrop, reference gpt.py:140,154)
+    // EPI_ADAMW: the result is a weight gradient; it is not stored, the parameter is updated in place
+    float* opt_p = nullptr; float* opt_m = nullptr; float* opt_v = nullptr; void* opt_lp = nullptr;   // [M,ldc] like C
+    AdamWHyper opt = {0, 0, 0, 0, 0, 1, 1, 1};
 };
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 // two independent products with the same operand layouts in ONE launch (query- and key-side projections of a
@@ -45,6 +48,10 @@ struct GroupedWgrad {
     int n;
     int tile_start[MEBT_MAX_GROUP + 1];
     struct Item { const void* A; const void* B; float* C; int M, N, K, lda, ldb, ldc, ntx; } g[MEBT_MAX_GROUP];
+    // optimizer-in-backward: when `fused`, item i's gradient is applied to W + (C - gW) etc. instead of stored
+    int fused = 0;
+    float* W = nullptr; float* gW = nullptr; float* mW = nullptr; float* vW = nullptr; void* Wlp = nullptr;
+    AdamWHyper opt = {0, 0, 0, 0, 0, 1, 1, 1};
 };
 int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream);   // fills tile_start / ntx
 struct GroupedColsum {

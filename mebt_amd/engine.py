@@ -205,10 +205,17 @@ class NativeModel:
     def adamw_range(self, kind, hi, lo, lr, weight_decay, step, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0, stream=None):
         """AdamW on one gradient bucket ('head' | 'layers' | 'embed'), on `stream` (default: current)."""
         mW, vW, mP, vP = self._adam_state()
-        k = {"head": 0, "layers": 1, "embed": 2, "all": 3}[kind]
+        k = {"head": 0, "layers": 1, "embed": 2, "all": 3, "rest": 4}[kind]
         check(self.lib.mebt_adamw_range(self.h, ptr(mW), ptr(vW), ptr(mP), ptr(vP), float(lr), float(betas[0]), float(betas[1]),
                                         float(eps), float(weight_decay), int(step), float(grad_scale), k, int(hi or 0), int(lo or 0),
                                         stream if stream is not None else cur_stream()))
+
+    def set_fused_adamw(self, lr=0.0, weight_decay=0.0, step=0, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0):
+        """Arm (step >= 1) / disarm (step = 0) the optimizer-in-backward for the blocks' Linear weights; after the
+        backward call adamw_range('rest', ...) for everything else."""
+        mW, vW, _, _ = self._adam_state()
+        check(self.lib.mebt_model_set_fused_adamw(self.h, ptr(mW), ptr(vW), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                                  float(weight_decay), int(step), float(grad_scale)))
 
     def adamw_step(self, lr, weight_decay, step, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0):
         self._adam_state()

@@ -12,7 +12,7 @@ from .parallel import GradReducer
 
 
 class TrainLoop:
-    def __init__(self, model, reducer=None, max_steps=0, overlap_optimizer=None):
+    def __init__(self, model, reducer=None, max_steps=0, overlap_optimizer=None, fused_optimizer=None):
         if overlap_optimizer is None:   # pays when there is an all-reduce to hide behind; on one GPU both contend for HBM
             world = reducer.world_size if reducer is not None else 1
             overlap_optimizer = os.environ.get("MEBT_OVERLAP_OPT", "1" if world > 1 else "0") != "0"
@@ -30,6 +30,12 @@ class TrainLoop:
         # (after its all-reduce when data-parallel): AdamW streams 30 B/parameter through HBM while the rest
         # of backward is latency/compute-bound, so the two overlap almost perfectly
         self.opt_stream = torch.cuda.Stream(device=self.native.device) if overlap_optimizer else None
+        # one process, bf16: AdamW of the blocks' Linear weights is applied inside the weight-gradient launches of
+        # backward (the gradient never goes to HBM and the optimizer traffic hides behind MFMA work); the all-reduce of a
+        # data-parallel job needs the gradients first, so this is the single-GPU path only
+        if fused_optimizer is None:   # the fp32 parity mode has no fused epilogue (the engine would fall back to one AdamW launch per weight)
+            fused_optimizer = os.environ.get("MEBT_FUSED_ADAMW", "1") != "0" and model.compute_dtype == "bf16"
+        self.fused_optimizer = bool(fused_optimizer) and self.reducer.world_size == 1
 
     def step(self, x, indices, t=None):
         """x [B,T,H,W] int64 tokens, indices [B,N] permutations.  Returns a device tensor
@@ -48,7 +54,12 @@ class TrainLoop:
         self.step_count += 1
         logits = nm.forward(x_ids, ci, ti, training=True, dropout_seed=m._next_seed())
         stats = nm.loss_stats(logits)
-        if self.opt_stream is None:
+        if self.fused_optimizer:
+            nm.set_fused_adamw(lr, m.weight_decay, self.step_count)
+            nm.backward(logits, scale)
+            nm.set_fused_adamw(step=0)
+            nm.adamw_range("rest", None, None, lr, m.weight_decay, self.step_count)
+        elif self.opt_stream is None:
             nm.backward(logits, scale, between=lambda s, hi, lo: red.bucket_ready(nm, s, hi, lo))
             red.wait()
             nm.adamw_step(lr, m.weight_decay, self.step_count, grad_scale=red.grad_scale)

@@ -209,3 +209,37 @@ def test_trainloop_steps_vs_golden(name, overlap):
         for k in finals[0]:
             d = (finals[0][k] - finals[1][k]).abs().max().item()
             assert d < 1e-6, (k, d)
+
+
+@pytest.mark.parametrize("name", ["micro", "micro_budget"])
+def test_trainloop_fused_optimizer(name):
+    """Optimizer-in-backward (`mebt_model_set_fused_adamw`): in fp32 the three steps still match the reference's
+    golden losses / parameter norms; in bf16 the fused epilogue gives the same parameters, moments and bf16 mirror
+    as the separate AdamW pass (same math on the same fp32 gradient values)."""
+    from mebt_amd.trainer import TrainLoop
+    g = load_golden("train_" + name)
+    names = [str(n) for n in g["names"]]
+    model = build_product(name, "f32").train()
+    model.learning_rate, model.weight_decay, model.warmup_steps, model.cosine_lr = float(g["lr"]), float(g["wd"]), 0, False
+    loop = TrainLoop(model, fused_optimizer=True)
+    assert loop.fused_optimizer
+    for s, t in enumerate(g["ts"]):
+        x, idx = torch.from_numpy(g[f"s{s}_x"]).to(DEV), torch.from_numpy(g[f"s{s}_indices"]).to(DEV)
+        stats = loop.step(x, idx, t=float(t)).cpu().numpy()
+        assert abs(stats[4] - g[f"s{s}_meta"][0]) < 5e-5 * abs(g[f"s{s}_meta"][0])
+        sd = model.state_dict()
+        np.testing.assert_allclose(np.array([float(sd[n].double().norm()) for n in names]), g[f"s{s}_pnorm"], rtol=2e-5)
+    finals = []
+    for fused in (False, True):
+        model = build_product(name, "bf16").train()
+        model.learning_rate, model.weight_decay, model.warmup_steps, model.cosine_lr = float(g["lr"]), float(g["wd"]), 0, False
+        loop = TrainLoop(model, fused_optimizer=fused)
+        assert loop.fused_optimizer == fused
+        for s, t in enumerate(g["ts"]):
+            x, idx = torch.from_numpy(g[f"s{s}_x"]).to(DEV), torch.from_numpy(g[f"s{s}_indices"]).to(DEV)
+            loop.step(x, idx, t=float(t))
+        nm = loop.native
+        finals.append([nm.W.clone(), nm.P.clone(), nm.Wlp.clone().float(), nm.adam[0].clone(), nm.adam[1].clone()])
+    for a, b, what in zip(finals[0], finals[1], ("W", "P", "bf16 mirror", "exp_avg", "exp_avg_sq")):
+        d = (a - b).abs().max().item()
+        assert d <= 1e-6 * max(1.0, a.abs().max().item()), (what, d)
