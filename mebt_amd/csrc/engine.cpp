@@ -688,7 +688,8 @@ static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd) {
                 const GroupedWgrad::Item& it = lv.w.g[i];
                 if (it.K <= 0) continue;
                 r.flops += 2.0 * it.M * it.N * it.K;
-                r.bytes += ((double)it.M * it.K + (double)it.N * it.K) * 2.0 + (double)it.M * it.N * 4.0;
+                // fp32 gradient store, or (optimizer-in-backward) read p,m,v + write p,m,v and the bf16 mirror
+                r.bytes += ((double)it.M * it.K + (double)it.N * it.K) * 2.0 + (double)it.M * it.N * (m->fused_on ? 26.0 : 4.0);
             }
             (void)hipEventRecord(r.a, sd);
         }
