@@ -128,7 +128,7 @@ __device__ __forceinline__ void epilogue_adamw(const GemmParams& p, const f32x4 
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool SYNC = true>
 __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x4 (&acc)[TM][TN], char* smem, int wave, int lane,
                                                  int mbase, int nbase, bool add_bias, bool atomic) {
     typedef bf16_t TA;
@@ -156,7 +156,7 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x
                 auxr[i][r] = *reinterpret_cast<const bf16x4*>(aux + (size_t)m * p.ld_aux);
             }
     }
-    __syncthreads();                                      // every wave is done reading the last k-tile
+    if (SYNC) __syncthreads();                            // every wave is done reading the last k-tile
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -447,15 +447,24 @@ struct DmaLoader {
 };
 
 // one output tile (m0, n0), k-tiles [kt0, kt1): LDS-DMA ring main loop + epilogue
-template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
+// KS = 2: an 8-wave workgroup runs TWO of these 4-wave pipelines on the same output tile, one on the even and one on
+// the odd k-tiles (each with its own LDS ring), and adds the two accumulator sets through LDS before the epilogue.
+// For outputs of a chip's worth of tiles or less and a deep reduction (the MLP down-projection and its dgrad:
+// 256 tiles x 64 k-tiles) a single 4-wave workgroup per CU is bound by the latency of one k-step (barrier, LDS
+// read, 12-24 dependent MFMAs); the second pipeline fills exactly those bubbles.
+template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE, int KS = 1>
 __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n0, int kt0, int kt1, char* smem, bool atomic, bool add_bias) {
     constexpr int STAGE = (TBM + TBN) * BK * 2;
     constexpr int TM = TBM / 32, TN = TBN / 32;
     constexpr int LPT = (TBM + TBN) / 32;              // DMA instructions per wave per tile
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = KS == 2 ? wave8 >> 2 : 0;          // pipeline of this wave
+    const int wave = wave8 & 3;
     const int wm = wave >> 1, wn = wave & 1;
-    const int nk = kt1 - kt0;
+    const int nk = (kt1 - kt0) / KS;                    // k-tiles per pipeline (the launcher guarantees divisibility)
+    char* ring = smem + grp * (NSTAGE * STAGE);
+    const int ktb = kt0 + grp;                          // pipeline tile t is k-tile ktb + KS * t
 
     DmaLoader<A_KC, TBM> la;
     DmaLoader<B_KC, TBN> lb;
@@ -472,8 +481,8 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
 #pragma unroll
     for (int a = 0; a < AHEAD; ++a)
         if (a < nk) {
-            la.issue(smem + a * STAGE, kt0 + a, wave);
-            lb.issue(smem + a * STAGE + TBM * BK * 2, kt0 + a, wave);
+            la.issue(ring + a * STAGE, ktb + KS * a, wave);
+            lb.issue(ring + a * STAGE + TBM * BK * 2, ktb + KS * a, wave);
         }
     int st = 0;                                          // ring slot of tile t
     for (int t = 0; t < nk; ++t) {
@@ -488,10 +497,10 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
         __builtin_amdgcn_s_barrier();
         if (t + AHEAD < nk) {                            // slot of tile t-1: every wave is past its reads
             int s2 = st + AHEAD; if (s2 >= NSTAGE) s2 -= NSTAGE;
-            la.issue(smem + s2 * STAGE, kt0 + t + AHEAD, wave);
-            lb.issue(smem + s2 * STAGE + TBM * BK * 2, kt0 + t + AHEAD, wave);
+            la.issue(ring + s2 * STAGE, ktb + KS * (t + AHEAD), wave);
+            lb.issue(ring + s2 * STAGE + TBM * BK * 2, ktb + KS * (t + AHEAD), wave);
         }
-        const char* sA = smem + st * STAGE;
+        const char* sA = ring + st * STAGE;
         const char* sB = sA + TBM * BK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -508,7 +517,38 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
         }
         if (++st == NSTAGE) st = 0;
     }
-    epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
+    if (KS == 2) {
+        // odd pipeline -> LDS -> even pipeline.  The exchange area starts above the epilogue's staging slabs
+        // (4 waves x 16 rows x <= 132 floats = 33 KiB) and fits the two rings (checked by the launcher).
+        constexpr int RED_OFF = 34 * 1024;
+        f32x4* red = reinterpret_cast<f32x4*>(smem + RED_OFF) + (size_t)(wave * TM * TN) * 64 + lane;
+        __syncthreads();                                 // both pipelines are done with the rings
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) red[(i * TN + j) * 64] = acc[i][j];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += red[(i * TN + j) * 64];
+        epilogue_via_lds<TM, TN, false>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
+    } else {
+        epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
+    }
+}
+
+// two pipelines per workgroup (KS = 2): whole reduction in one workgroup, K a multiple of 128
+template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
+__global__ __launch_bounds__(512) void gemm_bf16_dma_ks2_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntx = gridDim.x, nty = gridDim.y;
+    int tr, tc;
+    xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
+    gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE, 2>(p, tr * TBM, tc * TBN, 0, p.K / BK, smem, false, true);
 }
 
 template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
@@ -712,7 +752,43 @@ extern "C" void mebt_debug_gemm_tile(int bm, int bn) { g_gemm_force_tile = (bm &
 
 // one bf16 launch with an explicit (block tile, staging) choice; staging 0 = register-staged 2 stages,
 // 2..5 = LDS-DMA ring with that many stages (clamped to what the tile's LDS footprint admits)
+// LDS bytes of a two-pipeline (KS = 2) configuration; 0 = not available for this tile / ring depth
+static int ks2_lds(int tbm, int tbn, int ring) {
+    const bool tile_ok = (tbm == 96 && tbn == 64) || (tbm == 64 && tbn == 64) || (tbm == 96 && tbn == 128) || (tbm == 64 && tbn == 128) || (tbm == 128 && tbn == 64);
+    if (!tile_ok || ring < 2 || ring > 3) return 0;
+    const int bytes = 2 * ring * (tbm + tbn) * BK * 2;
+    const int need = 34 * 1024 + 4 * (tbm / 32) * (tbn / 32) * 1024;
+    return (bytes <= 160 * 1024 && bytes >= need) ? bytes : 0;
+}
+static void launch_bf16_ks2(const GemmParams& p, int tbm, int tbn, int ring, hipStream_t stream) {
+    const dim3 grid((p.N + tbn - 1) / tbn, (p.M + tbm - 1) / tbm, 1);
+    const int lds = ks2_lds(tbm, tbn, ring);
+#define KS2_T(AK, BKC, TM_, TN_)                                                                                                        \
+    do {                                                                                                                               \
+        if (ring == 3) hipLaunchKernelGGL((gemm_bf16_dma_ks2_kernel<AK, BKC, TM_, TN_, 3>), grid, dim3(512), lds, stream, p);            \
+        else hipLaunchKernelGGL((gemm_bf16_dma_ks2_kernel<AK, BKC, TM_, TN_, 2>), grid, dim3(512), lds, stream, p);                      \
+    } while (0)
+#define KS2_L(AK, BKC)                                              \
+    do {                                                            \
+        if (tbm == 96 && tbn == 64) KS2_T(AK, BKC, 96, 64);         \
+        else if (tbm == 64 && tbn == 64) KS2_T(AK, BKC, 64, 64);    \
+        else if (tbm == 96 && tbn == 128) KS2_T(AK, BKC, 96, 128);  \
+        else if (tbm == 64 && tbn == 128) KS2_T(AK, BKC, 64, 128);  \
+        else KS2_T(AK, BKC, 128, 64);                               \
+    } while (0)
+    if (p.a_kc && p.b_kc) KS2_L(true, true);
+    else if (p.a_kc && !p.b_kc) KS2_L(true, false);
+    else if (!p.a_kc && !p.b_kc) KS2_L(false, false);
+    else KS2_L(false, true);
+#undef KS2_L
+#undef KS2_T
+}
+
 static void launch_bf16_config(const GemmParams& p, int tbm, int tbn, int staging, int split, hipStream_t stream) {
+    if (staging >= 16) {          // two pipelines: whole reduction in the workgroup, an even number of k-tiles
+        if (split == 1 && p.K % (2 * BK) == 0 && ks2_lds(tbm, tbn, staging - 16)) { launch_bf16_ks2(p, tbm, tbn, staging - 16, stream); return; }
+        staging -= 16;
+    }
     const dim3 grid((p.N + tbn - 1) / tbn, (p.M + tbm - 1) / tbm, split);
 #define LAUNCH_T(AK, BKC, TM_, TN_)                                                                                   \
         do {                                                                                                         \
@@ -851,10 +927,17 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
             if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, st, 1, stream); }, stream, e0, e1, ms)) return rc;
             if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = st; }
         }
+        if (p.K % (2 * BK) == 0 && p.K >= 8 * BK && nt <= 640)                 // two pipelines per workgroup (staging 16 + ring depth)
+            for (int st = 2; st <= 3; ++st) {
+                if (!ks2_lds(bm, bn, st)) continue;
+                float ms = 0.f;
+                if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, 16 + st, 1, stream); }, stream, e0, e1, ms)) return rc;
+                if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = 16 + st; }
+            }
     }
     if (g_tune_log)
-        fprintf(stderr, "[mebt gemm autotune] M=%d N=%d K=%d a_kc=%d b_kc=%d epi=%d c_f32=%d -> %dx%d ring %d (%.1f us cold)\n", p.M, p.N, p.K,
-                p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, staging, best * 1e3f);
+        fprintf(stderr, "[mebt gemm autotune] M=%d N=%d K=%d a_kc=%d b_kc=%d epi=%d c_f32=%d -> %dx%d ring %d%s (%.1f us cold)\n", p.M, p.N, p.K,
+                p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, staging & 15, staging >= 16 ? " x2 pipelines" : "", best * 1e3f);
     return MEBT_OK;
 }
 
@@ -1088,6 +1171,15 @@ int gemm_init_attributes() {
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pair_kernel<AK, BKC, TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM_ + TN_) * BK * 2)); \
         if (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pair_kernel<AK, BKC, TM_, TN_, (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024 ? 4 : 2)>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (TM_ + TN_) * BK * 2)); \
     } while (0)
+#define SET_K(AK, BKC, TM_, TN_)                                                                                                                           \
+    do {                                                                                                                                                  \
+        if (ks2_lds(TM_, TN_, 2)) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_ks2_kernel<AK, BKC, TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ks2_lds(TM_, TN_, 2))); \
+        if (ks2_lds(TM_, TN_, 3)) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_ks2_kernel<AK, BKC, TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ks2_lds(TM_, TN_, 3))); \
+    } while (0)
+#define SET_KS2(AK, BKC) do { SET_K(AK, BKC, 96, 64); SET_K(AK, BKC, 64, 64); SET_K(AK, BKC, 96, 128); SET_K(AK, BKC, 64, 128); SET_K(AK, BKC, 128, 64); } while (0)
+    SET_KS2(true, true); SET_KS2(true, false); SET_KS2(false, false); SET_KS2(false, true);
+#undef SET_KS2
+#undef SET_K
 #define SET_PAIR(AK, BKC) do { SET_P(AK, BKC, 192, 128); SET_P(AK, BKC, 128, 128); SET_P(AK, BKC, 96, 128); SET_P(AK, BKC, 128, 64); SET_P(AK, BKC, 64, 128); SET_P(AK, BKC, 96, 64); SET_P(AK, BKC, 64, 64); } while (0)
     SET_PAIR(true, true);
     SET_PAIR(true, false);

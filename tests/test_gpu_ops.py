@@ -87,6 +87,26 @@ def test_gemm_every_tile_variant(tile, a_kc, b_kc, staging):
     assert torch.equal(out.double(), ref), (out.double() - ref).abs().max()
 
 
+@pytest.mark.parametrize("ring", [2, 3])
+@pytest.mark.parametrize("tile", [(96, 64), (64, 64), (96, 128), (64, 128), (128, 64)])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0), (0, 1)])
+def test_gemm_two_pipeline_variants(tile, a_kc, b_kc, ring):
+    """8-wave workgroups running two 4-wave pipelines on alternate k-tiles (variant 16 + ring depth), ragged M / N"""
+    M, N, K = 328, 200, 512
+    Am, Bm = rnd(M, K, seed=21, ints=True), rnd(N, K, seed=22, ints=True)
+    ref = Am.double() @ Bm.double().t()
+    A = Am if a_kc else Am.t().contiguous()
+    B = Bm if b_kc else Bm.t().contiguous()
+    lib().mebt_debug_gemm_tile(*tile)
+    lib().mebt_debug_gemm_variant(16 + ring)
+    try:
+        out, _ = run_gemm(_lib.BF16, A, B, M, N, K, a_kc, b_kc, c_f32=1)
+    finally:
+        lib().mebt_debug_gemm_tile(0, 0)
+        lib().mebt_debug_gemm_variant(-1)
+    assert torch.equal(out.double(), ref), (out.double() - ref).abs().max()
+
+
 @pytest.mark.parametrize("dtype", [_lib.BF16, _lib.F32])
 def test_gemm_ragged_reduction_and_splitk(dtype):
     """wgrad shape: reduction over an arbitrary token count (not a tile multiple), split-K atomics."""
