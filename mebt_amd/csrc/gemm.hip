@@ -563,7 +563,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams p) 
     const int kt0 = blockIdx.z * per;
     const int kt1 = min(nkt, kt0 + per);
     if (kt0 >= kt1) return;
+    if (p.slab) {                 // partial product of this k-range into its own fp32 slab (reduced by splitk_reduce_kernel)
+        GemmParams q = p;
+        q.C = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.z * p.slab;
+        gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE>(q, m0, n0, kt0, kt1, smem, false, false);
+        return;
+    }
     gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE>(p, m0, n0, kt0, kt1, smem, gridDim.z > 1, blockIdx.z == 0);
+}
+
+// Split-K for small outputs with a deep reduction: S workgroups per LARGE tile each reduce K/S and store fp32
+// partials (slab mode above); this kernel adds the S slabs and applies the product's real epilogue.  Why: the
+// global->LDS fill rate caps a tile shape at ~13 TB/s / (1/bm + 1/bn) B per flop; a 1536 x 1024 output only
+// fills the chip with 96 x 64 tiles (~500 TFLOP/s cap), split 4 ways it can use 192 x 128 tiles (~1000).
+template <int S>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* part, long slab) {
+    const long n4 = p.N / 4;
+    const long total = (long)p.M * n4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+        f32x4 v[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) v[s] = *reinterpret_cast<const f32x4*>(part + (size_t)s * slab + (size_t)m * p.N + n);
+#pragma unroll
+        for (int s = 1; s < S; ++s) v[0] += v[s];
+        epilogue_store<bf16_t>(p, m, n, v[0], true, false);
+    }
 }
 
 struct GemmPair { GemmParams p[2]; int tiles0; int ntx[2]; };
@@ -784,6 +809,29 @@ static void launch_bf16_ks2(const GemmParams& p, int tbm, int tbn, int ring, hip
 #undef KS2_T
 }
 
+// scratch for split-K partials (library-owned, grown on demand; launches that use it are ordered on ONE stream: the
+// autotuner only offers split configurations for bf16-output products, i.e. the forward / dgrad chain)
+static float* g_sk_buf = nullptr;
+static size_t g_sk_bytes = 0;
+static void launch_bf16_config(const GemmParams& p, int tbm, int tbn, int staging, int split, hipStream_t stream);
+static int launch_bf16_splitk(const GemmParams& p, int tbm, int tbn, int ring, int S, hipStream_t stream) {
+    const size_t need = (size_t)S * p.M * p.N * 4;
+    if (need > g_sk_bytes) {
+        if (g_sk_buf) { MEBT_HIP_CHECK(hipStreamSynchronize(stream)); MEBT_HIP_CHECK(hipFree(g_sk_buf)); g_sk_buf = nullptr; g_sk_bytes = 0; }
+        MEBT_HIP_CHECK(hipMalloc(&g_sk_buf, need));
+        g_sk_bytes = need;
+    }
+    GemmParams q = p;
+    q.C = g_sk_buf; q.C2 = nullptr; q.c_f32 = 1; q.ldc = p.N; q.epilogue = EPI_NONE; q.bias = nullptr; q.aux = nullptr; q.beta = 0;
+    q.drop.thresh = 0; q.slab = (long)p.M * p.N;
+    launch_bf16_config(q, tbm, tbn, ring, S, stream);
+    const long total = (long)p.M * (p.N / 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (S == 2) hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3(blocks), dim3(256), 0, stream, p, g_sk_buf, q.slab);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, stream, p, g_sk_buf, q.slab);
+    return MEBT_OK;
+}
+
 static void launch_bf16_config(const GemmParams& p, int tbm, int tbn, int staging, int split, hipStream_t stream) {
     if (staging >= 16) {          // two pipelines: whole reduction in the workgroup, an even number of k-tiles
         if (split == 1 && p.K % (2 * BK) == 0 && ks2_lds(tbm, tbn, staging - 16)) { launch_bf16_ks2(p, tbm, tbn, staging - 16, stream); return; }
@@ -920,14 +968,26 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
     for (int t = 0; t < 7; ++t) {
         const int bm = tiles[t][0], bn = tiles[t][1];
         const long nt = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-        if (nt < 96 && (long)bm * bn > 64 * 64 && out > 64 * 64) continue;      // would leave most of the chip idle
-        for (int st = 2; st <= 4; ++st) {
+        const bool few = nt < 96 && (long)bm * bn > 64 * 64 && out > 64 * 64;    // unsplit, this tile would leave most of the chip idle
+        for (int st = 2; st <= 4 && !few; ++st) {
             if (st * (bm + bn) * BK * 2 > 128 * 1024) continue;
             float ms = 0.f;
             if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, st, 1, stream); }, stream, e0, e1, ms)) return rc;
             if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = st; }
         }
-        if (p.K % (2 * BK) == 0 && p.K >= 8 * BK && nt <= 640)                 // two pipelines per workgroup (staging 16 + ring depth)
+        if (!p.c_f32 && p.C && nt <= 256 && (long)bm * bn >= 128 * 128)          // split-K into fp32 slabs + reduce/epilogue kernel (staging 32 * log2(S) + ring)
+            for (int S = 2; S <= 4; S *= 2) {
+                if (p.K % (S * BK) || p.K / S < 8 * BK) continue;
+                for (int st = 2; st <= 3; ++st) {
+                    if (st * (bm + bn) * BK * 2 > 128 * 1024) continue;
+                    float ms = 0.f;
+                    int rc2 = MEBT_OK;
+                    if (int rc = time_cold([&] { rc2 |= launch_bf16_splitk(p, bm, bn, st, S, stream); }, stream, e0, e1, ms)) return rc;
+                    if (rc2) return rc2;
+                    if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = (S == 2 ? 32 : 64) + st; }
+                }
+            }
+        if (p.K % (2 * BK) == 0 && p.K >= 8 * BK && nt <= 640 && !few)         // two pipelines per workgroup (staging 16 + ring depth)
             for (int st = 2; st <= 3; ++st) {
                 if (!ks2_lds(bm, bn, st)) continue;
                 float ms = 0.f;
@@ -937,7 +997,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
     }
     if (g_tune_log)
         fprintf(stderr, "[mebt gemm autotune] M=%d N=%d K=%d a_kc=%d b_kc=%d epi=%d c_f32=%d -> %dx%d ring %d%s (%.1f us cold)\n", p.M, p.N, p.K,
-                p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, staging & 15, staging >= 16 ? " x2 pipelines" : "", best * 1e3f);
+                p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, staging & 15, staging >= 64 ? " split-K 4" : staging >= 32 ? " split-K 2" : staging >= 16 ? " x2 pipelines" : "", best * 1e3f);
     return MEBT_OK;
 }
 
@@ -985,7 +1045,13 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
             if (g_gemm_force_tile) { tbm = g_gemm_force_tile >> 8; tbn = g_gemm_force_tile & 255; }
             if (g_gemm_dma >= 0) staging = g_gemm_dma == 1 ? 3 : g_gemm_dma;       // forced: 0 reg, 2..5 LDS-DMA stages (1 = 3)
         }
-        launch_bf16_config(p, tbm, tbn, staging, split, stream);
+        if (staging >= 32) {
+            const int S = staging >= 64 ? 4 : 2;
+            if (!p.c_f32 && p.C && split == 1 && p.K % (S * BK) == 0 && !p.beta) { if (int rc = launch_bf16_splitk(p, tbm, tbn, staging & 15, S, stream)) return rc; }
+            else launch_bf16_config(p, tbm, tbn, staging & 15, split, stream);
+        } else {
+            launch_bf16_config(p, tbm, tbn, staging, split, stream);
+        }
     } else if (dtype == MEBT_F32) {
         dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, split);
 #define LAUNCH_F32(AK, BKC) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC>), grid, dim3(256), 0, stream, p)

@@ -32,6 +32,7 @@ struct GemmParams {
     int c_f32;           // bf16 kernel: write fp32 C (weight gradients, logits)
     int beta;            // fp32 C only: C += result
     int split_k;         // 0 = heuristic, 1 = never, >1 = forced (fp32 C, EPI_NONE only)
+    long slab = 0;       // internal: split-K without atomics — grid.z slice z stores its partial product at C + z * slab
     DropCfg drop;        // EPI_RESID: C = dropout(acc + bias) + aux   (resid_pdrop, reference gpt.py:140,154)
     // EPI_ADAMW: the result is a weight gradient; it is not stored, the parameter is updated in place
     float* opt_p = nullptr; float* opt_m = nullptr; float* opt_v = nullptr; void* opt_lp = nullptr;   // [M,ldc] like C

@@ -143,6 +143,34 @@ def test_gemm_epilogues(dtype, tol):
     assert (out.double() - nob * x.grad).abs().max() < tol * max(1, nob.abs().max())
 
 
+@pytest.mark.parametrize("variant", [34, 67])
+@pytest.mark.parametrize("tile", [(128, 128), (192, 128)])
+@pytest.mark.parametrize("b_kc", [1, 0])
+def test_gemm_splitk_slabs_with_epilogues(tile, variant, b_kc):
+    """split-K into fp32 slabs + reduce/epilogue kernel (variant 32 + ring: 2 ways, 64 + ring: 4 ways), forced"""
+    M, N, K = 200, 264, 1024
+    tol = 2e-2
+    A = q(rnd(M, K, seed=6), _lib.BF16)
+    Bm = q(rnd(N, K, seed=7, scale=0.1), _lib.BF16)
+    B = Bm if b_kc else Bm.t().contiguous()
+    bias = rnd(N, seed=8)
+    aux = q(rnd(M, N, seed=9), _lib.BF16)
+    lin = A.double() @ Bm.double().t() + bias.double()
+    lib().mebt_debug_gemm_tile(*tile)
+    lib().mebt_debug_gemm_variant(variant)
+    try:
+        out, _ = run_gemm(_lib.BF16, A, B, M, N, K, 1, b_kc, bias=bias)
+        assert (out.double() - lin).abs().max() < tol * max(1, lin.abs().max())
+        out, g = run_gemm(_lib.BF16, A, B, M, N, K, 1, b_kc, bias=bias, epilogue=_lib.EPI_GELU)
+        assert (out.double() - lin).abs().max() < tol * max(1, lin.abs().max())
+        assert (g.double() - F.gelu(lin)).abs().max() < tol * max(1, lin.abs().max())
+        out, _ = run_gemm(_lib.BF16, A, B, M, N, K, 1, b_kc, bias=bias, aux=aux, epilogue=_lib.EPI_RESID)
+        assert (out.double() - (lin + aux.double())).abs().max() < tol * max(1, lin.abs().max())
+    finally:
+        lib().mebt_debug_gemm_tile(0, 0)
+        lib().mebt_debug_gemm_variant(-1)
+
+
 @pytest.mark.parametrize("dtype,tol", [(_lib.BF16, 2e-2), (_lib.F32, 1e-5)])
 @pytest.mark.parametrize("rows,d", [(37, 64), (130, 256), (64, 1024), (5, 320)])
 def test_layernorm_fwd_bwd(dtype, tol, rows, d):
