@@ -160,15 +160,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdMulti mj) {
 //      when hundreds of workgroups meet on the same 2*d addresses — a fused variant with one adder per
 //      16 rows ran 4x slower than both kernels together).
 template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const LnBwdMulti mj) {
+__device__ __forceinline__ void ln_bwd_dx_body(const LnBwdMulti& mj, int bid) {
     int job = 0;
 #pragma unroll
     for (int i = 1; i < MEBT_LN_MAXJ; ++i)
-        if (i < mj.n && (int)blockIdx.x >= mj.blk_start[i]) job = i;
+        if (i < mj.n && bid >= mj.blk_start[i]) job = i;
     const LnBwdParams& p = mj.j[job];
     const int lane = threadIdx.x & 63;
     const int d = p.d;
-    const long row = (long)(blockIdx.x - mj.blk_start[job]) * 4 + (threadIdx.x >> 6);
+    const long row = (long)(bid - mj.blk_start[job]) * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const long mrow = map_row(row, p.seg, p.seg_stride, p.seg_off);
     const T* x = reinterpret_cast<const T*>(p.x) + (size_t)row * d;
@@ -312,15 +312,15 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const LnFwdMulti mj) {
 }
 
 template <typename T, int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_dx_fast_kernel(const LnBwdMulti mj) {
+__device__ __forceinline__ void ln_bwd_dx_fast_body(const LnBwdMulti& mj, int bid) {
     constexpr int V = LaneVec<T>::V, D = NCH * 64 * V;
     int job = 0;
 #pragma unroll
     for (int i = 1; i < MEBT_LN_MAXJ; ++i)
-        if (i < mj.n && (int)blockIdx.x >= mj.blk_start[i]) job = i;
+        if (i < mj.n && bid >= mj.blk_start[i]) job = i;
     const LnBwdParams& p = mj.j[job];
     const int lane = threadIdx.x & 63;
-    const long row = (long)(blockIdx.x - mj.blk_start[job]) * 4 + (threadIdx.x >> 6);
+    const long row = (long)(bid - mj.blk_start[job]) * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const long mrow = map_row(row, p.seg, p.seg_stride, p.seg_off);
     const size_t ro = (size_t)row * D + lane * V, mo = (size_t)mrow * D + lane * V;
@@ -389,16 +389,16 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_fast_kernel(const LnBwdMulti mj
 
 // blocks of job j: gx = ceil(d/64) column groups x ceil(rows/rpw) row chunks (rpw = rows per workgroup here)
 template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_param_kernel(const LnBwdMulti mj) {
+__device__ __forceinline__ void ln_bwd_param_body(const LnBwdMulti& mj, int bid) {
     __shared__ float red[2][16][64 + 4];
     int job = 0;
 #pragma unroll
     for (int i = 1; i < MEBT_LN_MAXJ; ++i)
-        if (i < mj.n && (int)blockIdx.x >= mj.blk_start[i]) job = i;
+        if (i < mj.n && bid >= mj.blk_start[i]) job = i;
     const LnBwdParams& p = mj.j[job];
     const int rows_per_block = mj.rpw[job];
     const int gx = (p.d + 63) / 64;
-    const int lb = blockIdx.x - mj.blk_start[job];
+    const int lb = bid - mj.blk_start[job];
     const int bx = lb % gx, by = lb / gx;
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int n = bx * 64 + cg * 4;
@@ -426,6 +426,19 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const LnBwdMulti mj) 
         for (int r = 0; r < 16; ++r) t += red[which][r][col];
         const int c = bx * 64 + col;
         if (c < p.d) atomicAdd((which ? p.dbeta : p.dgamma) + c, t);
+    }
+}
+
+// ONE launch for both parts: workgroups [0, dx_blocks) compute dx rows, the rest the dgamma/dbeta column chunks.
+// They read the same x / dy at the same time (the second reader hits L2) and a kernel boundary disappears.
+// NCH = 0 selects the generic-d row kernel.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdMulti mj, const LnBwdMulti mp, int dx_blocks) {
+    if ((int)blockIdx.x < dx_blocks) {
+        if constexpr (NCH > 0) ln_bwd_dx_fast_body<T, NCH>(mj, blockIdx.x);
+        else ln_bwd_dx_body<T>(mj, blockIdx.x);
+    } else {
+        ln_bwd_param_body<T>(mp, blockIdx.x - dx_blocks);
     }
 }
 
@@ -710,21 +723,20 @@ int launch_ln_bwd_multi(const LnBwdParams* jobs, int n, int dtype, hipStream_t s
     if (!k) return MEBT_OK;
     mj.n = mp.n = k;
     for (int i = k; i <= MEBT_LN_MAXJ; ++i) { mj.blk_start[i] = blocks; mp.blk_start[i] = pblocks; }
-    hipStream_t ps = param_stream ? param_stream : stream;
+    (void)param_stream;                      // both parts are one launch on `stream` now
     bool same_d = true;
     for (int i = 1; i < k; ++i) same_d = same_d && mj.j[i].d == mj.j[0].d;
     const int d0 = mj.j[0].d;
+    const dim3 grid(blocks + pblocks);
     if (dtype == MEBT_BF16) {
-        if (same_d && d0 == 1024) hipLaunchKernelGGL((ln_bwd_dx_fast_kernel<bf16_t, 2>), dim3(blocks), dim3(256), 0, stream, mj);
-        else if (same_d && d0 == 512) hipLaunchKernelGGL((ln_bwd_dx_fast_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, stream, mj);
-        else if (same_d && d0 == 2048) hipLaunchKernelGGL((ln_bwd_dx_fast_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 0, stream, mj);
-        else hipLaunchKernelGGL(ln_bwd_dx_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, mj);
-        hipLaunchKernelGGL(ln_bwd_param_kernel<bf16_t>, dim3(pblocks), dim3(256), 0, ps, mp);
+        if (same_d && d0 == 1024) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 2>), grid, dim3(256), 0, stream, mj, mp, blocks);
+        else if (same_d && d0 == 512) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 1>), grid, dim3(256), 0, stream, mj, mp, blocks);
+        else if (same_d && d0 == 2048) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, stream, mj, mp, blocks);
+        else hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 0>), grid, dim3(256), 0, stream, mj, mp, blocks);
     } else {
-        if (same_d && d0 == 1024) hipLaunchKernelGGL((ln_bwd_dx_fast_kernel<float, 4>), dim3(blocks), dim3(256), 0, stream, mj);
-        else if (same_d && d0 == 256) hipLaunchKernelGGL((ln_bwd_dx_fast_kernel<float, 1>), dim3(blocks), dim3(256), 0, stream, mj);
-        else hipLaunchKernelGGL(ln_bwd_dx_kernel<float>, dim3(blocks), dim3(256), 0, stream, mj);
-        hipLaunchKernelGGL(ln_bwd_param_kernel<float>, dim3(pblocks), dim3(256), 0, ps, mp);
+        if (same_d && d0 == 1024) hipLaunchKernelGGL((ln_bwd_kernel<float, 4>), grid, dim3(256), 0, stream, mj, mp, blocks);
+        else if (same_d && d0 == 256) hipLaunchKernelGGL((ln_bwd_kernel<float, 1>), grid, dim3(256), 0, stream, mj, mp, blocks);
+        else hipLaunchKernelGGL((ln_bwd_kernel<float, 0>), grid, dim3(256), 0, stream, mj, mp, blocks);
     }
     CHECK_LAUNCH();
     return MEBT_OK;

@@ -74,9 +74,9 @@ struct mebt_model {
     std::vector<char> live;   // per layer: does the loss depend on this block?
     bool tok_live = false;
     FwdCtx ctx;
-    // side stream for work that nothing on the critical path waits for (weight / bias / LN-affine
-    // gradients, the key-side projection in forward): the per-layer kernels at batch 6 are too small
-    // to fill 256 CUs one at a time.  Fork/join with events only (graph-capturable).
+    // side stream for work that nothing on the critical path waits for in backward (weight / bias / LN-affine
+    // gradients).  It bought +14 % while the per-layer kernels were too small to fill 256 CUs; with the tuned,
+    // paired and grouped launches of today it is neutral (measured), and kept.  Fork/join with events only.
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_e1 = nullptr, ev_layer[2] = {nullptr, nullptr}, ev_join = nullptr;
     bool use_side = true;

@@ -12,11 +12,15 @@
 //   dgrad    dX = dY W   : A = dY (KC)  B = W  (RC, stored [n_out][k_in] = [K][rows])
 //   wgrad    dW = dY^T X : A = dY (RC)  B = X  (RC)      (reduction over tokens)
 //
-// bf16 kernel: 128x128x64 block tile, 4 waves (2x2) of 64x64, v_mfma_f32_16x16x32_bf16 with the
-// operands swapped (D^T = B A^T) so that each lane owns 4 consecutive output columns (vector
-// epilogue loads/stores).  Global->LDS staging goes through registers with the next tile's loads
-// issued before the current tile's MFMAs (issue-early / write-late), one barrier per k-tile,
-// two LDS stages.  Ragged edges are handled by buffer-resource bounds (OOB loads return 0).
+// bf16 kernels: block tiles 192x128 ... 64x64 x 64 (k), 4 waves (2x2), v_mfma_f32_16x16x32_bf16 with the
+// operands swapped (D^T = B A^T) so that each lane owns 4 consecutive output columns (vector epilogue
+// loads/stores).  Global->LDS staging is LDS-DMA into a ring of 2-4 k-tiles with counted waits and a raw
+// s_barrier (gemm_tile_dma); a register-staged two-stage variant (gemm_tile_regstaged) is kept as the
+// reference implementation of the same LDS images.  Variants on top: two pipelines per workgroup on
+// alternate k-tiles, two independent products per launch (pair), the grouped weight gradients of a block
+// (optionally with AdamW in the epilogue), split-K into fp32 slabs + a reduce/epilogue kernel.  The host
+// picks tile / ring depth / variant per GEMM signature by timing them in situ (autotune_config).
+// Ragged edges are handled by buffer-resource bounds (OOB loads return 0).
 //
 // f32 kernel (parity mode): same tiling on v_mfma_f32_32x32x2_f32, which is an exact fp32 FMA
 // chain (no TF32-like truncation exists on gfx950).
@@ -769,7 +773,7 @@ static int g_gemm_force_split = 0;
 static int g_gemm_force_tile = 0;     // (BM << 8) | BN, benchmarking only
 static int g_grouped_stages = 2;
 extern "C" void mebt_debug_grouped_stages(int n) { g_grouped_stages = n; }
-static int g_gemm_dma = -1;           // -1 heuristic; forced: 0 register-staged, 2 LDS-DMA 2 stages, 1 LDS-DMA 3 stages
+static int g_gemm_dma = -1;           // -1 autotune / heuristic; forced (tests, tools): 0 register-staged, 2..5 LDS-DMA ring depth, 16+r two pipelines, 32+r / 64+r split-K 2 / 4
 static int g_gemm_nostore = 0;        // experiments only (variant >= 100): skip the C store of plain epilogues
 extern "C" void mebt_debug_gemm_variant(int dma) { g_gemm_nostore = dma >= 100; g_gemm_dma = dma >= 100 ? (dma == 199 ? -1 : dma - 100) : dma; }
 void mebt_gemm_force_split(int s) { g_gemm_force_split = s; }

@@ -114,7 +114,7 @@ struct LnBwdParams {
     void* dx2 = nullptr;          // optional second output: dx * dropout mask `drop2` (element index row*d + e), type of dx
     DropCfg drop2 = {0, 0, 0, 1.0f};
 };
-// dx on `stream`, the dgamma/dbeta column reduction on `param_stream` (null: the same stream); `n` jobs per launch
+// dx rows and the dgamma/dbeta column reduction of `n` jobs in ONE launch on `stream` (param_stream is ignored: kept for callers)
 int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream, hipStream_t param_stream = nullptr);
 int launch_ln_bwd_multi(const LnBwdParams* jobs, int n, int dtype, hipStream_t stream, hipStream_t param_stream = nullptr);
 
