@@ -881,8 +881,10 @@ static void launch_bf16_config(const GemmParams& p, int tbm, int tbn, int stagin
 // tile is the one whose tile count lands on a whole number of workgroup slots of the 256 CUs
 // (profiles/r01_gemm_variants_cold.txt: up to 1.35x between neighbouring tiles, no closed-form rule
 // survives all shapes).  The first launch of a signature times every (tile, ring depth) candidate on the
-// caller's stream with the caller's operands and keeps the fastest; every candidate computes the same
-// bits (same k order per output element), so results do not depend on the choice.  Only idempotent
+// caller's stream with the caller's operands and keeps the fastest.  The plain candidates accumulate every
+// output element in the same k order (identical bits); the two-pipeline and split-K candidates add two or four
+// partial sums at the end, i.e. differ in the last fp32 bits before the bf16 rounding of the output — inside
+// the bf16 tolerance of the parity tests, and the fp32 parity mode is never tuned.  Only idempotent
 // launches are tuned (no beta accumulation, no split-K atomics).  MEBT_GEMM_AUTOTUNE=0 disables it
 // (heuristic below), MEBT_GEMM_TUNE_LOG=1 prints the choices.
 // ------------------------------------------------------------------------------------------------
