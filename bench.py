@@ -149,8 +149,7 @@ def main():
         nb, tb, by = C.c_double(), C.c_double(), C.c_double()
         _lib.check(lib.mebt_profile_read(1, C.byref(nb), C.byref(tb), C.byref(by)))
         lib.mebt_profile_enable(0)
-    # the same two steps with every launch on one stream: per-kernel durations without the overlap of
-    # the side stream (gradient leaves run concurrently with the dgrad chain in the shipped path)
+    # the same two steps with every launch on one stream (identical to the above unless MEBT_SIDE_STREAM=1)
     ser = None
     lib.mebt_debug_side_stream(loop.native.h, 0)
     if rank == 0:
@@ -163,7 +162,7 @@ def main():
         _lib.check(lib.mebt_profile_read(0, C.byref(n2), C.byref(t2), C.byref(f2)))
         lib.mebt_profile_enable(0)
         ser = round(f2.value / (t2.value * 1e-3) / 1e12, 2) if t2.value > 0 else None
-    lib.mebt_debug_side_stream(loop.native.h, 1)
+    lib.mebt_debug_side_stream(loop.native.h, 1 if loop.native.side_stream else 0)
     if rank == 0:
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         # HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command

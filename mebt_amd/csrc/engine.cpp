@@ -76,7 +76,8 @@ struct mebt_model {
     FwdCtx ctx;
     // side stream for work that nothing on the critical path waits for in backward (weight / bias / LN-affine
     // gradients).  It bought +14 % while the per-layer kernels were too small to fill 256 CUs; with the tuned,
-    // paired and grouped launches of today it is neutral (measured), and kept.  Fork/join with events only.
+    // paired and grouped launches of today it is neutral to slightly slower (measured), so the Python side
+    // switches it off unless MEBT_SIDE_STREAM=1.  Fork/join with events only.
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_e1 = nullptr, ev_layer[2] = {nullptr, nullptr}, ev_join = nullptr;
     bool use_side = true;

@@ -68,8 +68,10 @@ class NativeModel:
         self.n_w, self.n_p = nw.value, np_.value
         if os.environ.get("MEBT_GROUPED_STAGES"):
             self.lib.mebt_debug_grouped_stages(int(os.environ["MEBT_GROUPED_STAGES"]))
-        if os.environ.get("MEBT_SIDE_STREAM", "1") == "0":
-            self.lib.mebt_debug_side_stream(self.h, 0)
+        # second stream for the gradient leaves of backward: off by default (neutral-to-slower since every launch fills
+        # the chip: 11.3 vs 11.6 ms per Sky-16f step), MEBT_SIDE_STREAM=1 turns it on
+        self.side_stream = os.environ.get("MEBT_SIDE_STREAM", "0") == "1"
+        self.lib.mebt_debug_side_stream(self.h, 1 if self.side_stream else 0)
         self.n_layer, self.n_embd, self.vocab, self.n_latent = n_layer, n_embd, vocab, n_latent
         self.W = self.P = self.gW = self.gP = self.Wlp = None
         self.ws = None

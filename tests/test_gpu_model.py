@@ -62,11 +62,14 @@ def test_edges_nc0_nt1(dtype):
     np.testing.assert_allclose(l1[..., e["cols"]].numpy(), e["nt1_cols"], atol=tol, rtol=0)
 
 
-@pytest.mark.parametrize("name,dtype", [("micro", "f32"), ("c1", "f32"), ("micro", "bf16"), ("c1", "bf16")])
-def test_gradients_vs_oracle_autograd(name, dtype):
+@pytest.mark.parametrize("name,dtype,side", [("micro", "f32", 0), ("c1", "f32", 0), ("micro", "bf16", 0), ("c1", "bf16", 0),
+                                             ("c1", "f32", 1), ("c1", "bf16", 1)])
+def test_gradients_vs_oracle_autograd(name, dtype, side):
+    """side = 1: gradient leaves on the second stream (MEBT_SIDE_STREAM=1 path)"""
     cfg = mg.oracle_cfg(name)
     P = {k: v.clone().requires_grad_(True) for k, v in params_for(name).items()}
     nm = build_native(cfg, dtype)
+    nm.lib.mebt_debug_side_stream(nm.h, side)
     B = 3
     x, idx = mg.inputs(name, B, "grad")
     for t in (0.5, 0.2, 0.0):      # t = 0 -> NC = 0
