@@ -177,7 +177,7 @@ def main():
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(by.value / max(1.0, nb.value)),
-                "kernel": "gemm_bf16_kernel (all layouts/tiles)" if args.dtype == "bf16" else "gemm_f32_kernel",
+                "kernel": "bf16 MFMA GEMM family (gemm_bf16_dma[_ks2] / gemm_pair / wgrad_grouped incl. its fused AdamW epilogue)" if args.dtype == "bf16" else "gemm_f32_kernel",
                 "launches_per_step": n.value / 2, "gemm_ms_per_step": round(tms.value / 2, 3),
                 "gemm_gflop_per_step": round(fl.value / 2 / 1e9, 1), "achieved_single_stream": ser}
 
