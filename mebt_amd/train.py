@@ -7,8 +7,9 @@
 Same config handling as the reference (YAML list + dot-list overrides, train_transformer.py:25-27;
 exp.{exact_lr,warmup_steps,weight_decay,cosine_lr}, :45-66), seed 42 on every rank (:11) so all ranks
 draw the same `t`; one process per GPU with RCCL all-reduce (DDP, :39-41).  Data: token grids from a
-`.npy` file ([num,T,H,W] int64, `--tokens`) or synthetic grids; every item carries
-`indices = randperm(T*H*W)` like the reference datasets (mebt/data.py:85,233,413,471).
+`.npz` / `.h5` token file with the reference's `{train,test}_data` / `_idx` keys (`--tokens` or `data.data_path`,
+mebt_amd/data.py) or synthetic grids; every item carries `indices = randperm(T*H*W)` like the reference datasets
+(mebt/data.py:85,233,413,471); ranks read disjoint shards (DistributedSampler semantics).
 Checkpoints use the Lightning layout {'state_dict','hyper_parameters','global_step'}.
 """
 import argparse
@@ -24,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--base", nargs="*", default=[], metavar="base_config.yaml")
     ap.add_argument("--preset", default=None, help="sky_16f | ucf_128f | tiny (instead of --base)")
-    ap.add_argument("--tokens", default=None, help=".npy with [num,T,H,W] int64 token grids")
+    ap.add_argument("--tokens", default=None, help=".npz / .h5 token file (train_data [frames,H,W], train_idx), see mebt_amd/data.py")
     ap.add_argument("--max_steps", type=int, default=100)
     ap.add_argument("--log_every", type=int, default=10)
     ap.add_argument("--ckpt_every", type=int, default=0)
@@ -59,18 +60,33 @@ def main():
     loop = TrainLoop(model, GradReducer(world_size=world), max_steps=args.max_steps)
 
     shape = list(cfg.model.mask.params.shape)
-    N = int(np.prod(shape))
-    B = cfg.data.batch_size
-    g = torch.Generator().manual_seed(1234 + rank)
-    data = torch.from_numpy(np.load(args.tokens)).long() if args.tokens else None
+    # data: the reference's `vtokens` contract (mebt/data.py:236-305,330-414) — token clips from an .npz / .h5 file with
+    # {train,test}_data / _idx, or synthetic grids; every item carries indices = randperm(T*H*W); ranks read disjoint shards
+    from .config import AttrDict
+    from .data import TokenData
+    dargs = AttrDict(dict(cfg.data)) if "data" in cfg else AttrDict()
+    if args.tokens:
+        dargs["data_path"] = args.tokens
+    # token files are in latent units: clip length / crop come from the mask grid (the config's data node of the shipped
+    # YAMLs is in pixel units, e.g. sequence_length 16 frames -> 4 latent frames), the file's own grid is its resolution
+    dargs["latent_shape"] = shape
+    dargs["sequence_length"] = shape[0] * int(dargs.get("sample_every_n_frames", 1))
+    dargs["resolution"] = None
+    dargs["spatial_length"] = shape[1]
+    dargs.setdefault("batch_size", 6)
+    loader = TokenData(dargs, world_size=world, rank=rank).train_dataloader()
+    epoch, it = 0, iter(loader)
     t0 = time.perf_counter()
     for step in range(args.max_steps):
-        if data is not None:
-            sel = torch.randint(0, data.shape[0], (B,), generator=g)
-            x = data[sel]
-        else:
-            x = torch.randint(0, 16384, (B, *shape), generator=g)
-        idx = torch.stack([torch.randperm(N, generator=g) for _ in range(B)])
+        try:
+            batch = next(it)
+        except StopIteration:
+            epoch += 1
+            if hasattr(loader.sampler, "set_epoch"):
+                loader.sampler.set_epoch(epoch)
+            it = iter(loader)
+            batch = next(it)
+        x, idx = batch["video"], batch["indices"]
         stats = loop.step(x.to(dev, non_blocking=True), idx.to(dev, non_blocking=True))
         if (step + 1) % args.log_every == 0:
             s = loop.reducer.mean_scalars(torch.stack([stats[4], 100 * stats[1] / stats[3], 100 * stats[2] / stats[3]])).cpu()

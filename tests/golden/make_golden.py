@@ -479,6 +479,51 @@ def gen_script_drivers():
     save("script_drivers", **out)
 
 
+def gen_data_contract():
+    """Items of the reference's HDF5Dataset_vtokens (mebt/data.py:330-414) on a small synthetic token file.  h5py is not
+    installed here: `h5py.File` is stubbed by an npz reader (a container stub, the dataset logic is the reference's)."""
+    import importlib
+    tmp = os.path.join(HERE, "_tokens_tmp.npz")
+    rs = np.random.RandomState(7)
+    lens = [9, 3, 12, 5, 20, 4, 7]                       # frames per video; sequence_length 4 -> videos 1 and 5 are too short
+    idx = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    tokens = rs.randint(0, 16384, size=(int(idx[-1]), 6, 6)).astype(np.int64)
+    test_lens = [6, 8]
+    tidx = np.concatenate([[0], np.cumsum(test_lens)]).astype(np.int64)
+    ttokens = rs.randint(0, 16384, size=(int(tidx[-1]), 6, 6)).astype(np.int64)
+    np.savez(tmp, train_data=tokens, train_idx=idx, test_data=ttokens, test_idx=tidx)
+    h5 = types.ModuleType("h5py")
+    h5.File = lambda path, mode="r": dict(np.load(path))
+    sys.modules["h5py"] = h5
+    for name in ("torchvision", "torchvision.transforms", "torchvision.datasets", "torchvision.datasets.video_utils", "PIL", "PIL.Image", "av"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision.datasets.video_utils"].VideoClips = object
+    if not hasattr(sys.modules["pytorch_lightning"], "LightningDataModule"):
+        sys.modules["pytorch_lightning"].LightningDataModule = object
+    try:
+        data_mod = importlib.import_module("mebt.data")
+    except Exception as e:                                 # heavy optional imports of the module: stub what is missing, once more
+        missing = str(e)
+        raise RuntimeError("could not import reference mebt.data: " + missing)
+    out = {"train_data": tokens, "train_idx": idx, "test_data": ttokens, "test_idx": tidx}
+    cases = [("full", dict(sequence_length=4, resolution=6, spatial_length=6, sample_every_n_frames=1, latent_shape=[4, 6, 6])),
+             ("crop", dict(sequence_length=4, resolution=6, spatial_length=4, sample_every_n_frames=1, latent_shape=[4, 4, 4])),
+             ("skip", dict(sequence_length=6, resolution=6, spatial_length=6, sample_every_n_frames=2, latent_shape=[3, 6, 6]))]
+    for tag, kw in cases:
+        for train in (True, False):
+            ds = data_mod.HDF5Dataset_vtokens(tmp, train=train, **kw)
+            torch.manual_seed(123)
+            vids, boxes, perms = [], [], []
+            for i in range(len(ds)):
+                it = ds[i]
+                vids.append(it["video"].numpy()); perms.append(it["indices"].numpy())
+                boxes.append(np.asarray(it["cbox"]).reshape(-1) if not np.isscalar(it["cbox"]) else np.zeros(4, np.int64))
+            pre = f"{tag}_{'train' if train else 'test'}"
+            out[pre + "_video"], out[pre + "_cbox"], out[pre + "_indices"] = np.stack(vids), np.stack(boxes), np.stack(perms)
+    os.remove(tmp)
+    save("data_contract", **out)
+
+
 def _shared_step_with_t(model, x, idx, t):
     """shared_step (:717-732) with the python RNG draw `t` (:228) forced."""
     orig = random.random
@@ -499,6 +544,7 @@ def main():
     gen_sample_loops()
     gen_train()
     gen_script_drivers()
+    gen_data_contract()
 
 
 if __name__ == "__main__":

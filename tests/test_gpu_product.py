@@ -243,3 +243,26 @@ def test_trainloop_fused_optimizer(name):
     for a, b, what in zip(finals[0], finals[1], ("W", "P", "bf16 mirror", "exp_avg", "exp_avg_sq")):
         d = (a - b).abs().max().item()
         assert d <= 1e-6 * max(1.0, a.abs().max().item()), (what, d)
+
+
+def test_launcher_trains_from_token_file(tmp_path):
+    """`python -m mebt_amd.train` (counterpart of train_transformer.py) on a token file in the reference's vtokens
+    container layout: runs, logs finite losses, writes a Lightning-layout checkpoint that loads back."""
+    import subprocess, sys, os, re
+    rs = np.random.RandomState(3)
+    lens = [5, 9, 4, 7, 12, 6]
+    idx = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    f = str(tmp_path / "tok.npz")
+    np.savez(f, train_data=rs.randint(0, 16384, size=(int(idx[-1]), 8, 8)).astype(np.int64), train_idx=idx,
+             test_data=rs.randint(0, 16384, size=(6, 8, 8)).astype(np.int64), test_idx=np.array([0, 6], np.int64))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "mebt_amd.train", "--preset", "tiny", "--tokens", f, "--max_steps", "6", "--log_every", "2",
+                          "--ckpt_every", "6", "--default_root_dir", str(tmp_path / "runs")], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    losses = [float(v) for v in re.findall(r"train/loss ([0-9.]+)", out.stdout)]
+    assert len(losses) == 3 and all(np.isfinite(losses)) and losses[0] < 12.0, out.stdout
+    ck = torch.load(str(tmp_path / "runs" / "step=6.ckpt"), map_location="cpu", weights_only=False)
+    assert set(ck) >= {"state_dict", "hyper_parameters", "global_step"} and ck["global_step"] == 6
+    from mebt.transformer import Net2NetTransformer
+    m = Net2NetTransformer.load_from_checkpoint(str(tmp_path / "runs" / "step=6.ckpt"))
+    assert torch.equal(m.state_dict()["transformer.head.weight"].cpu(), ck["state_dict"]["transformer.head.weight"])

@@ -188,3 +188,55 @@ def test_data_parallel_reducer_gloo_world2():
     assert abs(r["loss"] - loss2) < 1e-5 * abs(r["loss"])        # mean of per-rank mean losses == full-batch loss (equal shards)
     for k, v in st.P.items():
         assert np.allclose(v.detach().numpy(), P2[k], rtol=2e-4, atol=2e-6), k
+
+
+def test_token_dataset_matches_reference_items(tmp_path):
+    """mebt_amd.data.TokenClipDataset == reference HDF5Dataset_vtokens (mebt/data.py:330-414) item by item for the same
+    torch seed: clip start, resampling of too-short videos, spatial crop box, frame skipping, `indices` permutation."""
+    import torch
+    from mebt_amd.data import TokenClipDataset
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_contract.npz"))
+    f = str(tmp_path / "tokens.npz")
+    np.savez(f, train_data=g["train_data"], train_idx=g["train_idx"], test_data=g["test_data"], test_idx=g["test_idx"])
+    cases = [("full", dict(sequence_length=4, resolution=6, spatial_length=6, sample_every_n_frames=1, latent_shape=[4, 6, 6])),
+             ("crop", dict(sequence_length=4, resolution=6, spatial_length=4, sample_every_n_frames=1, latent_shape=[4, 4, 4])),
+             ("skip", dict(sequence_length=6, resolution=6, spatial_length=6, sample_every_n_frames=2, latent_shape=[3, 6, 6]))]
+    for tag, kw in cases:
+        for train in (True, False):
+            ds = TokenClipDataset(f, train=train, **kw)
+            pre = f"{tag}_{'train' if train else 'test'}"
+            assert len(ds) == g[pre + "_video"].shape[0]
+            torch.manual_seed(123)
+            for i in range(len(ds)):
+                it = ds[i]
+                assert it["video"].dtype == torch.int64
+                assert np.array_equal(it["video"].numpy(), g[pre + "_video"][i]), (pre, i)
+                assert np.array_equal(it["indices"].numpy(), g[pre + "_indices"][i]), (pre, i)
+                box = np.asarray(it["cbox"]).reshape(-1) if not np.isscalar(it["cbox"]) else np.zeros(4, np.int64)
+                assert np.array_equal(box, g[pre + "_cbox"][i]), (pre, i)
+
+
+def test_sharded_sampler_equals_distributed_sampler():
+    """ShardedSampler == torch DistributedSampler (what the reference's VideoData uses, data.py:271-275) for every rank,
+    several world sizes / epochs, with and without shuffle / drop_last."""
+    import torch
+    from torch.utils.data.distributed import DistributedSampler
+    from mebt_amd.data import ShardedSampler, TokenData, SyntheticTokenDataset
+    for n in (1, 7, 16, 37):
+        ds = list(range(n))
+        for world in (1, 2, 3, 8):
+            for shuffle in (True, False):
+                for drop_last in (False, True):
+                    for epoch in (0, 3):
+                        for rank in range(world):
+                            ref = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle, seed=5, drop_last=drop_last)
+                            ref.set_epoch(epoch)
+                            mine = ShardedSampler(n, world, rank, shuffle=shuffle, seed=5, drop_last=drop_last)
+                            mine.set_epoch(epoch)
+                            assert list(ref) == list(mine) and len(ref) == len(mine), (n, world, shuffle, drop_last, epoch, rank)
+    # the data module yields the {'video','indices'} batches the training step consumes
+    from mebt_amd.config import AttrDict
+    dl = TokenData(AttrDict(latent_shape=[2, 4, 4], batch_size=3, num_workers=0), world_size=2, rank=1).train_dataloader()
+    b = next(iter(dl))
+    assert b["video"].shape == (3, 2, 4, 4) and b["indices"].shape == (3, 32) and b["video"].dtype == torch.int64
+    assert sorted(b["indices"][0].tolist()) == list(range(32))
