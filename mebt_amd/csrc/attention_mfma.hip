@@ -33,33 +33,6 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) & 3) << 1; }
 
-// 4 x 16-byte chunks per thread cover half a tile: a [64 x 64] bf16 tile = 512 chunks = 2 per thread
-struct TileLoad {
-    uint32_t goff[2];
-    uint32_t loff[2];
-    __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t step;
-    // base: first row of this (batch) slice at column h*64; rows: valid rows in the slice
-    __device__ __forceinline__ void init(const bf16_t* base, int rows, int ld, int tid) {
-        rsrc = make_rsrc(base, rows > 0 ? ((size_t)(rows - 1) * ld + 64) * 2 : 0);
-        step = (uint32_t)TILE * ld * 2;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-            goff[i] = ((uint32_t)row * ld + 8 * c) * 2;
-            loff[i] = row * 128 + ((c ^ swz(row)) << 4);
-        }
-    }
-    __device__ __forceinline__ void load(u32x4 (&r)[2], int tile) const {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) r[i] = buf_load16(rsrc, goff[i] + (uint32_t)tile * step);
-    }
-    __device__ __forceinline__ void store(char* lds, const u32x4 (&r)[2]) const {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(lds + loff[i]) = r[i];
-    }
-};
-
 // row-wise fragment: 16 rows (blk16) x 32 k (ks): lane l holds row l&15, k = 32ks + 8(l>>4) + j
 __device__ __forceinline__ bf16x8 frag_rows(const char* tile, int blk16, int ks, int lane) {
     const int row = blk16 * 16 + (lane & 15);
