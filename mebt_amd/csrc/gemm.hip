@@ -1,770 +1,36 @@
-// MFMA GEMM kernels for gfx950:  C[M,N] = sum_k A(m,k) * B(n,k)  (+ fused epilogue)
-//
-// Replaces the implicit ATen dispatches behind nn.Linear forward/backward on the MeBT hot path
-// (reference mebt/modules/gpt.py:126-128,140,150-155,248 and their autograd backward).
-//
-// Operand layouts.  Each operand is either
-//   KC  "k-contiguous":   stored [rows][K]  (K fastest)  -> LDS image [row][64 k], ds_read_b128
-//   RC  "row-contiguous": stored [K][rows]  (row fastest)-> LDS image [k][128 rows],
-//                                                           ds_read_b64_tr_b16 (hardware transpose)
-// so the three products of a Linear layer need no transposed copies in HBM:
-//   forward  Y  = X  W^T : A = X  (KC)  B = W  (KC)
-//   dgrad    dX = dY W   : A = dY (KC)  B = W  (RC, stored [n_out][k_in] = [K][rows])
-//   wgrad    dW = dY^T X : A = dY (RC)  B = X  (RC)      (reduction over tokens)
-//
-// bf16 kernels: block tiles 192x128 ... 64x64 x 64 (k), 4 waves (2x2), v_mfma_f32_16x16x32_bf16 with the
-// operands swapped (D^T = B A^T) so that each lane owns 4 consecutive output columns (vector epilogue
-// loads/stores).  Global->LDS staging is LDS-DMA into a ring of 2-4 k-tiles with counted waits and a raw
-// s_barrier (gemm_tile_dma); a register-staged two-stage variant (gemm_tile_regstaged) is kept as the
-// reference implementation of the same LDS images.  Variants on top: two pipelines per workgroup on
-// alternate k-tiles, two independent products per launch (pair), the grouped weight gradients of a block
-// (optionally with AdamW in the epilogue), split-K into fp32 slabs + a reduce/epilogue kernel.  The host
-// picks tile / ring depth / variant per GEMM signature by timing them in situ (autotune_config).
-// Ragged edges are handled by buffer-resource bounds (OOB loads return 0).
-//
-// f32 kernel (parity mode): same tiling on v_mfma_f32_32x32x2_f32, which is an exact fp32 FMA
-// chain (no TF32-like truncation exists on gfx950).
-#include "common.h"
-#include "kernels.h"
+// Host side of the bf16 / f32 GEMM family: validation, in-situ autotuning, split-K scratch, and dispatch to the four
+// per-layout translation units (gemm_kk/kr/rr/rk.hip, which hold the bf16 kernel instantiations; the device code and
+// the design notes are in gemm_kernels.h).  The fp32 parity kernel and the split-K reduce kernel are instantiated here.
+#include "gemm_kernels.h"
 #include <cstdio>
 #include <cstdlib>
 #include <unordered_map>
 
-namespace {
+void mebt_gemm_cfg_kk(const GemmParams&, int, int, int, int, hipStream_t);
+void mebt_gemm_cfg_kr(const GemmParams&, int, int, int, int, hipStream_t);
+void mebt_gemm_cfg_rr(const GemmParams&, int, int, int, int, hipStream_t);
+void mebt_gemm_cfg_rk(const GemmParams&, int, int, int, int, hipStream_t);
+void mebt_gemm_ks2_kk(const GemmParams&, int, int, int, hipStream_t);
+void mebt_gemm_ks2_kr(const GemmParams&, int, int, int, hipStream_t);
+void mebt_gemm_ks2_rr(const GemmParams&, int, int, int, hipStream_t);
+void mebt_gemm_ks2_rk(const GemmParams&, int, int, int, hipStream_t);
+int mebt_gemm_attrs_kk(); int mebt_gemm_attrs_kr(); int mebt_gemm_attrs_rr(); int mebt_gemm_attrs_rk();
+void mebt_gemm_pair_kk(GemmPair&, int, int, int, hipStream_t);
+void mebt_gemm_pair_kr(GemmPair&, int, int, int, hipStream_t);
+void mebt_gemm_grouped(GroupedWgrad&, int, int, int, hipStream_t);
 
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-
-// ------------------------------------------------------------------------------------------------
-// epilogue shared by both kernels.  v = 4 consecutive output columns n..n+3 of row m.
-// ------------------------------------------------------------------------------------------------
-template <typename TA /*activation dtype of aux / C2*/>
-__device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, f32x4 v, bool add_bias, bool atomic) {
-    if (add_bias && p.bias) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-        v += b;
-    }
-    const size_t ci = (size_t)m * p.ldc + n;
-    if (atomic) {
-        float* c = reinterpret_cast<float*>(p.C) + ci;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(c + j, v[j]);
-        return;
-    }
-    constexpr bool fast = sizeof(TA) == 2;       // bf16 kernel: cheap erf (1.5e-7 abs error)
-    if (p.epilogue == EPI_GELU) {
-        f32x4 g;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = fast ? gelu_fast(v[j]) : gelu_f(v[j]);
-        store4<TA>(reinterpret_cast<TA*>(p.C2) + ci, g);
-    } else if (p.epilogue == EPI_RESID) {
-        if (p.drop.thresh) {
-            const uint64_t e0 = (uint64_t)m * p.N + n;
-            v *= drop_keep4(p.drop, e0);
-        }
-        v += load4<TA>(reinterpret_cast<const TA*>(p.aux) + (size_t)m * p.ld_aux + n);
-    } else if (p.epilogue == EPI_GELU_BWD) {
-        const f32x4 x = load4<TA>(reinterpret_cast<const TA*>(p.aux) + (size_t)m * p.ld_aux + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= fast ? gelu_grad_fast(x[j]) : gelu_grad_f(x[j]);
-    }
-    if (!p.C) return;                   // EPI_GELU in inference: only gelu(C) is needed
-    if (p.c_f32) {
-        float* c = reinterpret_cast<float*>(p.C) + ci;
-        if (p.beta) v += *reinterpret_cast<const f32x4*>(c);
-        *reinterpret_cast<f32x4*>(c) = v;
-    } else {
-        store4<TA>(reinterpret_cast<TA*>(p.C) + ci, v);
-    }
+static void launch_bf16_ks2(const GemmParams& p, int tbm, int tbn, int ring, hipStream_t stream) {
+    if (p.a_kc && p.b_kc) mebt_gemm_ks2_kk(p, tbm, tbn, ring, stream);
+    else if (p.a_kc && !p.b_kc) mebt_gemm_ks2_kr(p, tbm, tbn, ring, stream);
+    else if (!p.a_kc && !p.b_kc) mebt_gemm_ks2_rr(p, tbm, tbn, ring, stream);
+    else mebt_gemm_ks2_rk(p, tbm, tbn, ring, stream);
 }
-
-// Epilogue through LDS.  The MFMA accumulators hold, per lane, 4 consecutive columns of ONE row of each
-// 16x16 fragment, so a direct store instruction touches 16 rows x 32 bytes — a quarter of every 128-byte
-// line for the C store and for the aux / residual loads.  After the k-loop the LDS ring is idle: each
-// wave parks its (TM*16) x (TN*16) fp32 tile there (padded rows: conflict-free ds_write_b128), then walks
-// it row-contiguously, 4 columns per lane, so every global access of the epilogue covers whole rows of the
-// wave's tile (TN*32 bytes of bf16 per row).
-//
-// Every operand the epilogue reads (bias: one f32x4 per lane, the same for all rows; aux: one 8-byte
-// vector per row pass) is fetched BEFORE the accumulators are staged, all loads back to back at clamped
-// (always valid) addresses: a load under a per-row bounds/epilogue branch makes hipcc wait for it inside
-// the branch, which turned the 16 row passes of a wave into 16-32 dependent L2/HBM round trips.
-// EPI_ADAMW: the tile is a weight gradient; apply AdamW to the parameter tile in place (p, m, v fp32 + bf16 mirror)
-// instead of storing it.  Straight-line per 16-row slab: all 12 loads of the slab's 4 row passes first.
-template <int TM, int TN>
-__device__ __forceinline__ void epilogue_adamw(const GemmParams& p, const f32x4 (&acc)[TM][TN], char* smem, int wave, int lane,
-                                               int mbase, int nbase) {
-    constexpr int COLS = TN * 16, LD = COLS + 4;
-    float* st = reinterpret_cast<float*>(smem) + wave * (16 * LD);
-    constexpr int LPR = COLS / 4, RPI = 64 / LPR, NPASS = 16 / RPI;
-    const int r0 = lane / LPR, c4 = (lane % LPR) * 4;
-    const int n = nbase + c4;
-    const bool n_ok = n < p.N;
-    const int nc = n_ok ? n : 0;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        f32x4 pp[NPASS], mm[NPASS], vv[NPASS];
-        size_t ci[NPASS];
-#pragma unroll
-        for (int r = 0; r < NPASS; ++r) {
-            const int m = min(mbase + i * 16 + r * RPI + r0, p.M - 1);
-            ci[r] = (size_t)m * p.ldc + nc;
-            pp[r] = *reinterpret_cast<const f32x4*>(p.opt_p + ci[r]);
-            mm[r] = *reinterpret_cast<const f32x4*>(p.opt_m + ci[r]);
-            vv[r] = *reinterpret_cast<const f32x4*>(p.opt_v + ci[r]);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            *reinterpret_cast<f32x4*>(st + (lane & 15) * LD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < NPASS; ++r) {
-            const int row = r * RPI + r0;
-            const f32x4 g = *reinterpret_cast<const f32x4*>(st + row * LD + c4);
-            adamw_update4(pp[r], g, mm[r], vv[r], p.opt);
-            if (mbase + i * 16 + row < p.M && n_ok) {
-                *reinterpret_cast<f32x4*>(p.opt_p + ci[r]) = pp[r];
-                *reinterpret_cast<f32x4*>(p.opt_m + ci[r]) = mm[r];
-                *reinterpret_cast<f32x4*>(p.opt_v + ci[r]) = vv[r];
-                if (p.opt_lp) store4<bf16_t>(reinterpret_cast<bf16_t*>(p.opt_lp) + ci[r], pp[r]);
-            }
-        }
-    }
+static void launch_pair_config(GemmPair& g, int tbm, int tbn, int staging, hipStream_t stream) {
+    if (g.p[0].b_kc) mebt_gemm_pair_kk(g, tbm, tbn, staging, stream);
+    else mebt_gemm_pair_kr(g, tbm, tbn, staging, stream);
 }
+static void launch_grouped_config(GroupedWgrad& c, int tbm, int tbn, int stages, hipStream_t stream) { mebt_gemm_grouped(c, tbm, tbn, stages, stream); }
 
-template <int TM, int TN, bool SYNC = true>
-__device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x4 (&acc)[TM][TN], char* smem, int wave, int lane,
-                                                 int mbase, int nbase, bool add_bias, bool atomic) {
-    typedef bf16_t TA;
-    if (p.epilogue == EPI_ADAMW) { epilogue_adamw<TM, TN>(p, acc, smem, wave, lane, mbase, nbase); return; }
-    constexpr int COLS = TN * 16, LD = COLS + 4;          // fp32 elements per staged row
-    float* st = reinterpret_cast<float*>(smem) + wave * (16 * LD);   // one 16-row slab per wave (<= 4.3 KiB)
-    constexpr int LPR = COLS / 4;                         // lanes per row
-    constexpr int RPI = 64 / LPR;                         // rows per pass
-    constexpr int NPASS = 16 / RPI;
-    const int r0 = lane / LPR, c4 = (lane % LPR) * 4;
-    const int n = nbase + c4;
-    const bool n_ok = n < p.N;
-    const int nc = n_ok ? n : 0;
-    const bool need_aux = p.epilogue == EPI_RESID || p.epilogue == EPI_GELU_BWD;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (add_bias && p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + nc);
-    bf16x4 auxr[TM][NPASS];
-    if (need_aux) {
-        const TA* aux = reinterpret_cast<const TA*>(p.aux) + nc;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < NPASS; ++r) {
-                const int m = min(mbase + i * 16 + r * RPI + r0, p.M - 1);
-                auxr[i][r] = *reinterpret_cast<const bf16x4*>(aux + (size_t)m * p.ld_aux);
-            }
-    }
-    if (SYNC) __syncthreads();                            // every wave is done reading the last k-tile
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            *reinterpret_cast<f32x4*>(st + (lane & 15) * LD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
-        // the same wave reads back what it wrote (LDS operations of a wave execute in order): only its LDS
-        // queue has to drain, no workgroup barrier
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < NPASS; ++r) {
-            const int row = r * RPI + r0;
-            f32x4 v = *reinterpret_cast<const f32x4*>(st + row * LD + c4);
-            const int m = mbase + i * 16 + row;
-            if (!(m < p.M && n_ok)) continue;
-            v += bias;
-            const size_t ci = (size_t)m * p.ldc + n;
-            if (atomic) {
-                float* c = reinterpret_cast<float*>(p.C) + ci;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) atomicAdd(c + j, v[j]);
-                continue;
-            }
-            if (p.epilogue == EPI_GELU) {
-                f32x4 g;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = gelu_fast(v[j]);
-                store4<TA>(reinterpret_cast<TA*>(p.C2) + ci, g);
-            } else if (p.epilogue == EPI_RESID) {
-                if (p.drop.thresh) {
-                    const uint64_t e0 = (uint64_t)m * p.N + n;
-                    v *= drop_keep4(p.drop, e0);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += (float)auxr[i][r][j];
-            } else if (p.epilogue == EPI_GELU_BWD) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_fast((float)auxr[i][r][j]);
-            }
-            if (!p.C) continue;                 // EPI_GELU in inference: only gelu(C) is needed
-            if (p.c_f32) {
-                float* c = reinterpret_cast<float*>(p.C) + ci;
-                if (p.beta) v += *reinterpret_cast<const f32x4*>(c);
-                *reinterpret_cast<f32x4*>(c) = v;
-            } else {
-                store4<TA>(reinterpret_cast<TA*>(p.C) + ci, v);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// bf16 kernel, templated on the block tile (TBM x TBN in {128,64}) so that small outputs still fill
-// 256 CUs: 4 waves as 2x2, each wave (TBM/2) x (TBN/2) = (TBM/32) x (TBN/32) MFMA tiles of 16x16.
-// ------------------------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, BK = 64;
-
-// swizzle of the 16-byte chunk index of an RC image row (k-row `krow`): conflict-free transposed reads
-template <int ROWS> __device__ __forceinline__ int rc_swizzle(int krow);
-template <> __device__ __forceinline__ int rc_swizzle<128>(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }          // 256-B rows
-template <> __device__ __forceinline__ int rc_swizzle<64>(int krow) { return (((krow >> 1) & 1) << 1) | (((krow >> 3) & 1) << 2); }   // 128-B rows
-// 192-B rows: k-rows q = 0..3 of a 16-lane group already land 64 B apart; rows r and r+8 (the two groups of a
-// 32-lane half) coincide mod 256 B -> move the second group to the neighbouring 32-B pair
-template <> __device__ __forceinline__ int rc_swizzle<96>(int krow) { return ((krow >> 3) & 1) << 1; }
-// 384-B rows: rows q and q+2 coincide mod 256 B, and so do r and r+8
-template <> __device__ __forceinline__ int rc_swizzle<192>(int krow) { return (((krow >> 1) & 1) << 1) | (((krow >> 3) & 1) << 2); }
-
-// XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs (consecutive linear ids on
-// consecutive XCDs) and each XCD has its own 4 MB L2, so the tiles an XCD works on at the same time should
-// share operand rows: XCD x gets a COMPACT xr x xc sub-grid of the tile grid (xr * xc = 8), the shape chosen
-// to minimise the bytes all XCDs fetch together, xc * |A| + xr * |B| with |A| ~ M and |B| ~ N (both x K).
-// Measured with rocprofv3 FETCH_SIZE before this mapping: 3-6x the algorithmic operand bytes (the grouped
-// weight-gradient launch streamed 357 MB for 62 MB of operands at 4.3 TB/s — bandwidth-bound on re-reads).
-// `t` = linear workgroup index within the product; any t with equal t % 8 share an XCD.
-__device__ __forceinline__ void xcd_tile(int t, int ntx, int nty, int M, int N, int& tr, int& tc) {
-    const int T = ntx * nty;
-    if (T & 7) {                              // no whole sub-grids: contiguous runs along N (bijective for any T)
-        const int q = T >> 3, r = T & 7, xcd = t & 7, idx = t >> 3;
-        const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        tr = b / ntx; tc = b % ntx;
-        return;
-    }
-    int xr = 0, xc = 0;
-    long best = 0x7FFFFFFFFFFFFFFFl;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int r = 8 >> s, c = 1 << s;     // (8,1) (4,2) (2,4) (1,8)
-        if (nty % r || ntx % c) continue;
-        const long cost = (long)c * M + (long)r * N;
-        if (cost < best) { best = cost; xr = r; xc = c; }
-    }
-    if (!xr) {                                // T % 8 == 0 but neither dimension splits (e.g. 3 x 8 ... handled above); fall back
-        tr = t / ntx; tc = t % ntx;
-        return;
-    }
-    const int xcd = t & 7, idx = t >> 3;
-    const int lr = nty / xr, lc = ntx / xc;
-    tr = (xcd / xc) * lr + idx / lc;
-    tc = (xcd % xc) * lc + idx % lc;
-}
-
-template <bool KC, int ROWS>
-struct TileLoader {
-    // per-thread 16-byte chunks of a [ROWS x 64] (KC) or [64 x ROWS] (RC) bf16 tile
-    static constexpr int NCH = ROWS / 32;
-    uint32_t goff[NCH];
-    uint32_t loff[NCH];
-    bool ok[NCH];
-    uint32_t step;   // byte advance per k-tile
-    __amdgpu_buffer_rsrc_t rsrc;
-
-    __device__ __forceinline__ void init(const void* base, int rows, int K, int ld, int r0, int tid) {
-        const bf16_t* b = reinterpret_cast<const bf16_t*>(base);
-        if (KC) {
-            rsrc = make_rsrc(b + (size_t)r0 * ld, (size_t)(rows - r0) * ld * 2);
-            step = BK * 2;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-                goff[i] = ((uint32_t)row * ld + 8 * c) * 2;
-                loff[i] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
-                ok[i] = true;
-            }
-        } else {
-            constexpr int CPR = ROWS / 8;          // chunks per k-row
-            rsrc = make_rsrc(b, (size_t)K * ld * 2);
-            step = (uint32_t)BK * ld * 2;
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int id = tid + 256 * i, krow = id / CPR, c = id % CPR;
-                const int col = r0 + 8 * c;
-                ok[i] = col < rows;
-                goff[i] = ((uint32_t)krow * ld + col) * 2;
-                loff[i] = krow * (ROWS * 2) + ((c ^ rc_swizzle<ROWS>(krow)) << 4);
-            }
-        }
-    }
-    __device__ __forceinline__ void load(u32x4 (&r)[NCH], int kt) const {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) r[i] = buf_load16(rsrc, ok[i] ? goff[i] + (uint32_t)kt * step : (uint32_t)MEBT_OOB);
-    }
-    __device__ __forceinline__ void store(char* lds, const u32x4 (&r)[NCH]) const {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(lds + loff[i]) = r[i];
-    }
-};
-
-// fragment of 16 rows x 32 k for v_mfma_f32_16x16x32_bf16: lane l holds row (l&15), k = 8*(l>>4)+j
-template <bool KC, int ROWS>
-__device__ __forceinline__ bf16x8 read_frag(const char* tile, int blk16 /*16-row block in tile*/, int ks, int lane) {
-    if (KC) {
-        const int row = blk16 * 16 + (lane & 15);
-        const int c = 4 * ks + (lane >> 4);
-        return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-    } else {
-        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-        const int ch = 2 * blk16 + (pp >> 1);
-        const int k0 = 32 * ks + 8 * g + q, k1 = k0 + 4;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + k0 * (ROWS * 2) + ((ch ^ rc_swizzle<ROWS>(k0)) << 4) + 8 * (pp & 1)));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + k1 * (ROWS * 2) + ((ch ^ rc_swizzle<ROWS>(k1)) << 4) + 8 * (pp & 1)));
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
-        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8, v);
-    }
-}
-
-// one output tile (m0, n0), k-tiles [kt0, kt1): register-staged 2-stage main loop + epilogue
-template <bool A_KC, bool B_KC, int TBM, int TBN>
-__device__ __forceinline__ void gemm_tile_regstaged(const GemmParams& p, int m0, int n0, int kt0, int kt1, char* smem, bool atomic, bool add_bias) {
-    constexpr int STAGE = (TBM + TBN) * BK * 2;
-    constexpr int TM = TBM / 32, TN = TBN / 32;         // MFMA tiles per wave
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    TileLoader<A_KC, TBM> la;
-    TileLoader<B_KC, TBN> lb;
-    la.init(p.A, p.M, p.K, p.lda, m0, tid);
-    lb.init(p.B, p.N, p.K, p.ldb, n0, tid);
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    u32x4 ra[TBM / 32], rb[TBN / 32];
-    la.load(ra, kt0);
-    lb.load(rb, kt0);
-    la.store(smem, ra);
-    lb.store(smem + TBM * BK * 2, rb);
-    __syncthreads();
-
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int s = (kt - kt0) & 1;
-        const char* sA = smem + s * STAGE;
-        const char* sB = sA + TBM * BK * 2;
-        const bool more = kt + 1 < kt1;
-        if (more) {
-            la.load(ra, kt + 1);
-            lb.load(rb, kt + 1);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = read_frag<A_KC, TBM>(sA, wm * TM + i, ks, lane);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = read_frag<B_KC, TBN>(sB, wn * TN + j, ks, lane);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            char* dA = smem + (s ^ 1) * STAGE;
-            la.store(dA, ra);
-            lb.store(dA + TBM * BK * 2, rb);
-        }
-        __syncthreads();
-    }
-    epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
-}
-
-template <bool A_KC, bool B_KC, int TBM, int TBN>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ntx = gridDim.x, nty = gridDim.y;
-    int tr, tc;
-    xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
-    const int m0 = tr * TBM, n0 = tc * TBN;
-    const int nkt = (p.K + BK - 1) / BK;
-    const int per = (nkt + gridDim.z - 1) / gridDim.z;
-    const int kt0 = blockIdx.z * per;
-    const int kt1 = min(nkt, kt0 + per);
-    if (kt0 >= kt1) return;
-    gemm_tile_regstaged<A_KC, B_KC, TBM, TBN>(p, m0, n0, kt0, kt1, smem, gridDim.z > 1, blockIdx.z == 0);
-}
-
-// ------------------------------------------------------------------------------------------------
-// bf16 kernel, direct-to-LDS variant: the same LDS images and fragment reads, but the tiles are
-// written by `buffer_load_dwordx4 ... lds` (no VGPR round trip, no ds_write) into a 3-stage ring, so
-// two k-tiles are in flight behind the one being multiplied.  An LDS-DMA wave-instruction writes 1 KiB
-// at a wave-uniform base + lane*16, so the XOR swizzle moves to the per-lane SOURCE address.  Waits
-// are counted (`s_waitcnt vmcnt(N)`, never 0 inside the loop) and the barrier is the raw s_barrier
-// (a __syncthreads() would drain the DMA queue).
-// ------------------------------------------------------------------------------------------------
-template <bool KC, int ROWS>
-struct DmaLoader {
-    static constexpr int NP = ROWS / 32;      // 1-KiB pieces per wave per tile (ROWS/8 pieces, 4 waves)
-    uint32_t goff[NP];
-    bool ok[NP];
-    uint32_t step;
-    __amdgpu_buffer_rsrc_t rsrc;
-    __device__ __forceinline__ void init(const void* base, int rows, int K, int ld, int r0, int wave, int lane) {
-        const bf16_t* b = reinterpret_cast<const bf16_t*>(base);
-        if (KC) {                             // piece = 8 rows x 128 B
-            rsrc = make_rsrc(b + (size_t)r0 * ld, (size_t)(rows - r0) * ld * 2);
-            step = BK * 2;
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                const int row = 8 * (4 * i + wave) + (lane >> 3), slot = lane & 7;
-                const int c = slot ^ ((row >> 1) & 7);
-                goff[i] = ((uint32_t)row * ld + 8 * c) * 2;
-                ok[i] = true;
-            }
-        } else {
-            constexpr int CPR = ROWS / 8;     // 16-byte slots per k-row; a 1-KiB piece = 64 consecutive slots of the image
-            rsrc = make_rsrc(b, (size_t)K * ld * 2);
-            step = (uint32_t)BK * ld * 2;
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                const int id = 64 * (4 * i + wave) + lane;
-                const int krow = id / CPR, slot = id % CPR;
-                const int c = slot ^ rc_swizzle<ROWS>(krow);
-                const int col = r0 + 8 * c;
-                ok[i] = col < rows;
-                goff[i] = ((uint32_t)krow * ld + col) * 2;
-            }
-        }
-    }
-    // tile kt -> LDS image at `tile` (wave-uniform pointer)
-    __device__ __forceinline__ void issue(char* tile, int kt, int wave) const {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const uint32_t off = ok[i] ? goff[i] + (uint32_t)kt * step : (uint32_t)MEBT_OOB;
-            dma16(rsrc, (unsigned)(size_t)(lds_char_ptr)(tile + (4 * i + wave) * 1024), off);
-        }
-    }
-};
-
-// one output tile (m0, n0), k-tiles [kt0, kt1): LDS-DMA ring main loop + epilogue
-// KS = 2: an 8-wave workgroup runs TWO of these 4-wave pipelines on the same output tile, one on the even and one on
-// the odd k-tiles (each with its own LDS ring), and adds the two accumulator sets through LDS before the epilogue.
-// For outputs of a chip's worth of tiles or less and a deep reduction (the MLP down-projection and its dgrad:
-// 256 tiles x 64 k-tiles) a single 4-wave workgroup per CU is bound by the latency of one k-step (barrier, LDS
-// read, 12-24 dependent MFMAs); the second pipeline fills exactly those bubbles.
-template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE, int KS = 1>
-__device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n0, int kt0, int kt1, char* smem, bool atomic, bool add_bias) {
-    constexpr int STAGE = (TBM + TBN) * BK * 2;
-    constexpr int TM = TBM / 32, TN = TBN / 32;
-    constexpr int LPT = (TBM + TBN) / 32;              // DMA instructions per wave per tile
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = KS == 2 ? wave8 >> 2 : 0;          // pipeline of this wave
-    const int wave = wave8 & 3;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nk = (kt1 - kt0) / KS;                    // k-tiles per pipeline (the launcher guarantees divisibility)
-    char* ring = smem + grp * (NSTAGE * STAGE);
-    const int ktb = kt0 + grp;                          // pipeline tile t is k-tile ktb + KS * t
-
-    DmaLoader<A_KC, TBM> la;
-    DmaLoader<B_KC, TBN> lb;
-    la.init(p.A, p.M, p.K, p.lda, m0, wave, lane);
-    lb.init(p.B, p.N, p.K, p.ldb, n0, wave, lane);
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    constexpr int AHEAD = NSTAGE - 1;                   // tiles in flight behind the one being multiplied
-#pragma unroll
-    for (int a = 0; a < AHEAD; ++a)
-        if (a < nk) {
-            la.issue(ring + a * STAGE, ktb + KS * a, wave);
-            lb.issue(ring + a * STAGE + TBM * BK * 2, ktb + KS * a, wave);
-        }
-    int st = 0;                                          // ring slot of tile t
-    for (int t = 0; t < nk; ++t) {
-        // tile t must have landed; the (up to AHEAD-1) younger tiles may stay in flight.  vmcnt takes an
-        // immediate, so the tail (fewer younger tiles than AHEAD-1) selects the count by a uniform switch.
-        const int younger = min(AHEAD - 1, nk - 1 - t);
-        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-        else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT) : "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + AHEAD < nk) {                            // slot of tile t-1: every wave is past its reads
-            int s2 = st + AHEAD; if (s2 >= NSTAGE) s2 -= NSTAGE;
-            la.issue(ring + s2 * STAGE, ktb + KS * (t + AHEAD), wave);
-            lb.issue(ring + s2 * STAGE + TBM * BK * 2, ktb + KS * (t + AHEAD), wave);
-        }
-        const char* sA = ring + st * STAGE;
-        const char* sB = sA + TBM * BK * 2;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = read_frag<A_KC, TBM>(sA, wm * TM + i, ks, lane);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = read_frag<B_KC, TBN>(sB, wn * TN + j, ks, lane);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        if (++st == NSTAGE) st = 0;
-    }
-    if (KS == 2) {
-        // odd pipeline -> LDS -> even pipeline.  The exchange area starts above the epilogue's staging slabs
-        // (4 waves x 16 rows x <= 132 floats = 33 KiB) and fits the two rings (checked by the launcher).
-        constexpr int RED_OFF = 34 * 1024;
-        f32x4* red = reinterpret_cast<f32x4*>(smem + RED_OFF) + (size_t)(wave * TM * TN) * 64 + lane;
-        __syncthreads();                                 // both pipelines are done with the rings
-        if (grp == 1) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) red[(i * TN + j) * 64] = acc[i][j];
-        }
-        __syncthreads();
-        if (grp == 1) return;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] += red[(i * TN + j) * 64];
-        epilogue_via_lds<TM, TN, false>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
-    } else {
-        epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
-    }
-}
-
-// two pipelines per workgroup (KS = 2): whole reduction in one workgroup, K a multiple of 128
-template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
-__global__ __launch_bounds__(512) void gemm_bf16_dma_ks2_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ntx = gridDim.x, nty = gridDim.y;
-    int tr, tc;
-    xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
-    gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE, 2>(p, tr * TBM, tc * TBN, 0, p.K / BK, smem, false, true);
-}
-
-template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ntx = gridDim.x, nty = gridDim.y;
-    int tr, tc;
-    xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
-    const int m0 = tr * TBM, n0 = tc * TBN;
-    const int nkt = (p.K + BK - 1) / BK;
-    const int per = (nkt + gridDim.z - 1) / gridDim.z;
-    const int kt0 = blockIdx.z * per;
-    const int kt1 = min(nkt, kt0 + per);
-    if (kt0 >= kt1) return;
-    if (p.slab) {                 // partial product of this k-range into its own fp32 slab (reduced by splitk_reduce_kernel)
-        GemmParams q = p;
-        q.C = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.z * p.slab;
-        gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE>(q, m0, n0, kt0, kt1, smem, false, false);
-        return;
-    }
-    gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE>(p, m0, n0, kt0, kt1, smem, gridDim.z > 1, blockIdx.z == 0);
-}
-
-// Split-K for small outputs with a deep reduction: S workgroups per LARGE tile each reduce K/S and store fp32
-// partials (slab mode above); this kernel adds the S slabs and applies the product's real epilogue.  Why: the
-// global->LDS fill rate caps a tile shape at ~13 TB/s / (1/bm + 1/bn) B per flop; a 1536 x 1024 output only
-// fills the chip with 96 x 64 tiles (~500 TFLOP/s cap), split 4 ways it can use 192 x 128 tiles (~1000).
-template <int S>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* part, long slab) {
-    const long n4 = p.N / 4;
-    const long total = (long)p.M * n4;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int m = (int)(i / n4), n = (int)(i % n4) * 4;
-        f32x4 v[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) v[s] = *reinterpret_cast<const f32x4*>(part + (size_t)s * slab + (size_t)m * p.N + n);
-#pragma unroll
-        for (int s = 1; s < S; ++s) v[0] += v[s];
-        epilogue_store<bf16_t>(p, m, n, v[0], true, false);
-    }
-}
-
-struct GemmPair { GemmParams p[2]; int tiles0; int ntx[2]; };
-template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmPair g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int which = (int)blockIdx.x >= g.tiles0 ? 1 : 0;
-    const GemmParams& p = g.p[which];
-    const int t = blockIdx.x - (which ? g.tiles0 : 0);
-    int tr, tc;
-    xcd_tile(t, g.ntx[which], (p.M + TBM - 1) / TBM, p.M, p.N, tr, tc);
-    const int m0 = tr * TBM, n0 = tc * TBN;
-    gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE>(p, m0, n0, 0, (p.K + BK - 1) / BK, smem, false, true);
-}
-
-// grouped weight gradients: blockIdx.x enumerates the tiles of all groups (RC x RC, fp32 result)
-template <int TBM, int TBN, int NSTAGE>
-__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int g = 0;
-#pragma unroll
-    for (int i = 1; i < MEBT_MAX_GROUP; ++i)
-        if (i < w.n && (int)blockIdx.x >= w.tile_start[i]) g = i;
-    const GroupedWgrad::Item& it = w.g[g];
-    const int t = blockIdx.x - w.tile_start[g];
-    GemmParams p;
-    p.A = it.A; p.B = it.B; p.C = it.C; p.C2 = nullptr; p.bias = nullptr; p.aux = nullptr;
-    p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb; p.ldc = it.ldc; p.ld_aux = 0;
-    p.a_kc = 0; p.b_kc = 0; p.epilogue = EPI_NONE; p.c_f32 = 1; p.beta = 0; p.split_k = 1; p.drop.thresh = 0;
-    if (w.fused) {
-        const ptrdiff_t off = it.C - w.gW;
-        p.epilogue = EPI_ADAMW; p.opt = w.opt;
-        p.opt_p = w.W + off; p.opt_m = w.mW + off; p.opt_v = w.vW + off;
-        p.opt_lp = w.Wlp ? (void*)(reinterpret_cast<bf16_t*>(w.Wlp) + off) : nullptr;
-    }
-    int tr, tc;
-    xcd_tile(t, it.ntx, (it.M + TBM - 1) / TBM, it.M, it.N, tr, tc);
-    const int m0 = tr * TBM, n0 = tc * TBN;
-    gemm_tile_dma<false, false, TBM, TBN, NSTAGE>(p, m0, n0, 0, (it.K + BK - 1) / BK, smem, false, false);
-}
-
-// ------------------------------------------------------------------------------------------------
-// f32 kernel (parity mode).  LDS image is always [k][row] (row fastest); KC operands are
-// transposed by the staging write, RC operands are copied.  BK = 16.
-// ------------------------------------------------------------------------------------------------
-constexpr int FBK = 16, FLD = 132;   // padded row length (floats)
-
-template <bool KC>
-struct TileLoaderF32 {
-    uint32_t goff[2];
-    bool ok[2];
-    int l0[2], l1[2];
-    uint32_t step;
-    __amdgpu_buffer_rsrc_t rsrc;
-    __device__ __forceinline__ void init(const void* base, int rows, int K, int ld, int r0, int tid) {
-        const float* b = reinterpret_cast<const float*>(base);
-        if (KC) {   // tile [128 rows][16 k] : 512 float4 chunks
-            rsrc = make_rsrc(b + (size_t)r0 * ld, (size_t)(rows - r0) * ld * 4);
-            step = FBK * 4;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int id = tid + 256 * i, row = id >> 2, c = id & 3;
-                goff[i] = ((uint32_t)row * ld + 4 * c) * 4;
-                ok[i] = true;
-                l0[i] = 4 * c;   // k
-                l1[i] = row;
-            }
-        } else {    // tile [16 k][128 rows] : 512 float4 chunks
-            rsrc = make_rsrc(b, (size_t)K * ld * 4);
-            step = (uint32_t)FBK * ld * 4;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int id = tid + 256 * i, krow = id >> 5, c = id & 31;
-                const int col = r0 + 4 * c;
-                ok[i] = col < rows;
-                goff[i] = ((uint32_t)krow * ld + col) * 4;
-                l0[i] = krow;
-                l1[i] = 4 * c;
-            }
-        }
-    }
-    __device__ __forceinline__ void load(f32x4 (&r)[2], int kt) const {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            r[i] = __builtin_bit_cast(f32x4, buf_load16(rsrc, ok[i] ? goff[i] + (uint32_t)kt * step : (uint32_t)MEBT_OOB));
-    }
-    __device__ __forceinline__ void store(float* lds, const f32x4 (&r)[2]) const {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (KC) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) lds[(l0[i] + j) * FLD + l1[i]] = r[i][j];
-            } else {
-                *reinterpret_cast<f32x4*>(lds + l0[i] * FLD + l1[i]) = r[i];
-            }
-        }
-    }
-};
-
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float sA[FBK * FLD];
-    __shared__ __attribute__((aligned(16))) float sB[FBK * FLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int nkt = (p.K + FBK - 1) / FBK;
-    const int per = (nkt + gridDim.z - 1) / gridDim.z;
-    const int kt0 = blockIdx.z * per;
-    const int kt1 = min(nkt, kt0 + per);
-    if (kt0 >= kt1) return;
-
-    TileLoaderF32<A_KC> la;
-    TileLoaderF32<B_KC> lb;
-    la.init(p.A, p.M, p.K, p.lda, m0, tid);
-    lb.init(p.B, p.N, p.K, p.ldb, n0, tid);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    f32x4 ra[2], rb[2];
-    la.load(ra, kt0);
-    lb.load(rb, kt0);
-    for (int kt = kt0; kt < kt1; ++kt) {
-        la.store(sA, ra);
-        lb.store(sB, rb);
-        __syncthreads();
-        if (kt + 1 < kt1) {
-            la.load(ra, kt + 1);
-            lb.load(rb, kt + 1);
-        }
-#pragma unroll
-        for (int kk = 0; kk < FBK; kk += 2) {
-            const int k = kk + (lane >> 5);
-            float a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = sA[k * FLD + wm * 64 + i * 32 + (lane & 31)];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = sB[k * FLD + wn * 64 + j * 32 + (lane & 31)];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // D'[n_local][m_local]: lane owns m_local = lane&31; register r -> n_local = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool atomic = gridDim.z > 1;
-    const bool add_bias = blockIdx.z == 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + (lane & 31);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
-                if (m < p.M && n < p.N) {
-                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    epilogue_store<float>(p, m, n, v, add_bias, atomic);
-                }
-            }
-    }
-}
-
-}  // namespace
 
 // ------------------------------------------------------------------------------------------------
 // host launcher
@@ -781,43 +47,20 @@ extern "C" void mebt_debug_gemm_tile(int bm, int bn) { g_gemm_force_tile = (bm &
 
 // one bf16 launch with an explicit (block tile, staging) choice; staging 0 = register-staged 2 stages,
 // 2..5 = LDS-DMA ring with that many stages (clamped to what the tile's LDS footprint admits)
-// LDS bytes of a two-pipeline (KS = 2) configuration; 0 = not available for this tile / ring depth
-static int ks2_lds(int tbm, int tbn, int ring) {
-    const bool tile_ok = (tbm == 96 && tbn == 64) || (tbm == 64 && tbn == 64) || (tbm == 96 && tbn == 128) || (tbm == 64 && tbn == 128) || (tbm == 128 && tbn == 64);
-    if (!tile_ok || ring < 2 || ring > 3) return 0;
-    const int bytes = 2 * ring * (tbm + tbn) * BK * 2;
-    const int need = 34 * 1024 + 4 * (tbm / 32) * (tbn / 32) * 1024;
-    return (bytes <= 160 * 1024 && bytes >= need) ? bytes : 0;
-}
-static void launch_bf16_ks2(const GemmParams& p, int tbm, int tbn, int ring, hipStream_t stream) {
-    const dim3 grid((p.N + tbn - 1) / tbn, (p.M + tbm - 1) / tbm, 1);
-    const int lds = ks2_lds(tbm, tbn, ring);
-#define KS2_T(AK, BKC, TM_, TN_)                                                                                                        \
-    do {                                                                                                                               \
-        if (ring == 3) hipLaunchKernelGGL((gemm_bf16_dma_ks2_kernel<AK, BKC, TM_, TN_, 3>), grid, dim3(512), lds, stream, p);            \
-        else hipLaunchKernelGGL((gemm_bf16_dma_ks2_kernel<AK, BKC, TM_, TN_, 2>), grid, dim3(512), lds, stream, p);                      \
-    } while (0)
-#define KS2_L(AK, BKC)                                              \
-    do {                                                            \
-        if (tbm == 96 && tbn == 64) KS2_T(AK, BKC, 96, 64);         \
-        else if (tbm == 64 && tbn == 64) KS2_T(AK, BKC, 64, 64);    \
-        else if (tbm == 96 && tbn == 128) KS2_T(AK, BKC, 96, 128);  \
-        else if (tbm == 64 && tbn == 128) KS2_T(AK, BKC, 64, 128);  \
-        else KS2_T(AK, BKC, 128, 64);                               \
-    } while (0)
-    if (p.a_kc && p.b_kc) KS2_L(true, true);
-    else if (p.a_kc && !p.b_kc) KS2_L(true, false);
-    else if (!p.a_kc && !p.b_kc) KS2_L(false, false);
-    else KS2_L(false, true);
-#undef KS2_L
-#undef KS2_T
-}
-
 // scratch for split-K partials (library-owned, grown on demand; launches that use it are ordered on ONE stream: the
 // autotuner only offers split configurations for bf16-output products, i.e. the forward / dgrad chain)
 static float* g_sk_buf = nullptr;
 static size_t g_sk_bytes = 0;
-static void launch_bf16_config(const GemmParams& p, int tbm, int tbn, int staging, int split, hipStream_t stream);
+static void launch_bf16_config(const GemmParams& p, int tbm, int tbn, int staging, int split, hipStream_t stream) {
+    if (staging >= 16) {          // two pipelines: whole reduction in the workgroup, an even number of k-tiles
+        if (split == 1 && p.K % (2 * BK) == 0 && ks2_lds(tbm, tbn, staging - 16)) { launch_bf16_ks2(p, tbm, tbn, staging - 16, stream); return; }
+        staging -= 16;
+    }
+    if (p.a_kc && p.b_kc) mebt_gemm_cfg_kk(p, tbm, tbn, staging, split, stream);
+    else if (p.a_kc && !p.b_kc) mebt_gemm_cfg_kr(p, tbm, tbn, staging, split, stream);
+    else if (!p.a_kc && !p.b_kc) mebt_gemm_cfg_rr(p, tbm, tbn, staging, split, stream);
+    else mebt_gemm_cfg_rk(p, tbm, tbn, staging, split, stream);
+}
 static int launch_bf16_splitk(const GemmParams& p, int tbm, int tbn, int ring, int S, hipStream_t stream) {
     const size_t need = (size_t)S * p.M * p.N * 4;
     if (need > g_sk_bytes) {
@@ -834,46 +77,6 @@ static int launch_bf16_splitk(const GemmParams& p, int tbm, int tbn, int ring, i
     if (S == 2) hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3(blocks), dim3(256), 0, stream, p, g_sk_buf, q.slab);
     else hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, stream, p, g_sk_buf, q.slab);
     return MEBT_OK;
-}
-
-static void launch_bf16_config(const GemmParams& p, int tbm, int tbn, int staging, int split, hipStream_t stream) {
-    if (staging >= 16) {          // two pipelines: whole reduction in the workgroup, an even number of k-tiles
-        if (split == 1 && p.K % (2 * BK) == 0 && ks2_lds(tbm, tbn, staging - 16)) { launch_bf16_ks2(p, tbm, tbn, staging - 16, stream); return; }
-        staging -= 16;
-    }
-    const dim3 grid((p.N + tbn - 1) / tbn, (p.M + tbm - 1) / tbm, split);
-#define LAUNCH_T(AK, BKC, TM_, TN_)                                                                                   \
-        do {                                                                                                         \
-            if (staging == 5 && 5 * (TM_ + TN_) * BK * 2 <= 160 * 1024) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, (5 * (TM_ + TN_) * BK * 2 <= 160 * 1024 ? 5 : 2)>), grid, dim3(256), 5 * (TM_ + TN_) * BK * 2, stream, p); \
-            else if (staging >= 4) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 4>), grid, dim3(256), 4 * (TM_ + TN_) * BK * 2, stream, p); \
-            else if (staging == 3) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 3>), grid, dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, p); \
-            else if (staging == 2) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 2>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p); \
-            else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC, TM_, TN_>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p);          \
-        } while (0)
-        /* tiles that exist as LDS-DMA kernels only (2..4 stages) */
-#define LAUNCH_D(AK, BKC, TM_, TN_)                                                                                   \
-        do {                                                                                                         \
-            if (staging >= 4 && 4 * (TM_ + TN_) * BK * 2 <= 128 * 1024) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024 ? 4 : 2)>), grid, dim3(256), 4 * (TM_ + TN_) * BK * 2, stream, p); \
-            else if (staging >= 3) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 3>), grid, dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, p); \
-            else hipLaunchKernelGGL((gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 2>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p); \
-        } while (0)
-#define LAUNCH_BF16(AK, BKC)                                           \
-        do {                                                           \
-            if (tbm == 128 && tbn == 128) LAUNCH_T(AK, BKC, 128, 128); \
-            else if (tbm == 192 && tbn == 128) LAUNCH_D(AK, BKC, 192, 128); \
-            else if (tbm == 96 && tbn == 128) LAUNCH_D(AK, BKC, 96, 128); \
-            else if (tbm == 96 && tbn == 64) LAUNCH_D(AK, BKC, 96, 64); \
-            else if (tbm == 128 && tbn == 64) LAUNCH_T(AK, BKC, 128, 64); \
-            else if (tbm == 64 && tbn == 128) LAUNCH_T(AK, BKC, 64, 128); \
-            else LAUNCH_T(AK, BKC, 64, 64);                            \
-        } while (0)
-    if (p.a_kc && p.b_kc) LAUNCH_BF16(true, true);
-    else if (p.a_kc && !p.b_kc) LAUNCH_BF16(true, false);
-    else if (!p.a_kc && !p.b_kc) LAUNCH_BF16(false, false);
-    else LAUNCH_BF16(false, true);
-#undef LAUNCH_BF16
-#undef LAUNCH_D
-#undef LAUNCH_T
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1074,36 +277,6 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     return MEBT_OK;
 }
 
-static void launch_pair_config(GemmPair& g, int tbm, int tbn, int staging, hipStream_t stream) {
-    int tiles[2];
-    for (int i = 0; i < 2; ++i) {
-        g.ntx[i] = (g.p[i].N + tbn - 1) / tbn;
-        tiles[i] = ((g.p[i].M + tbm - 1) / tbm) * g.ntx[i];
-    }
-    g.tiles0 = tiles[0];
-    const dim3 grid(tiles[0] + tiles[1]);
-#define PAIR_T(AK, BKC, TM_, TN_)                                                                                                                          \
-    do {                                                                                                                                                  \
-        if (staging >= 4 && 4 * (TM_ + TN_) * BK * 2 <= 128 * 1024) hipLaunchKernelGGL((gemm_pair_kernel<AK, BKC, TM_, TN_, (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024 ? 4 : 2)>), grid, dim3(256), 4 * (TM_ + TN_) * BK * 2, stream, g); \
-        else if (staging >= 3) hipLaunchKernelGGL((gemm_pair_kernel<AK, BKC, TM_, TN_, 3>), grid, dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, g);          \
-        else hipLaunchKernelGGL((gemm_pair_kernel<AK, BKC, TM_, TN_, 2>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, g);                           \
-    } while (0)
-#define PAIR_L(AK, BKC)                                                  \
-    do {                                                                 \
-        if (tbm == 128 && tbn == 128) PAIR_T(AK, BKC, 128, 128);         \
-        else if (tbm == 192 && tbn == 128) PAIR_T(AK, BKC, 192, 128);    \
-        else if (tbm == 96 && tbn == 128) PAIR_T(AK, BKC, 96, 128);      \
-        else if (tbm == 96 && tbn == 64) PAIR_T(AK, BKC, 96, 64);        \
-        else if (tbm == 128 && tbn == 64) PAIR_T(AK, BKC, 128, 64);      \
-        else if (tbm == 64 && tbn == 128) PAIR_T(AK, BKC, 64, 128);      \
-        else PAIR_T(AK, BKC, 64, 64);                                    \
-    } while (0)
-    if (g.p[0].b_kc) PAIR_L(true, true);
-    else PAIR_L(true, false);
-#undef PAIR_L
-#undef PAIR_T
-}
-
 int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipStream_t stream) {
     const bool ok = dtype == MEBT_BF16 && p0.a_kc && p1.a_kc && p0.b_kc == p1.b_kc && p0.M > 0 && p0.N > 0 && p1.M > 0 && p1.N > 0 &&
                     p0.K > 0 && p1.K > 0 && !p0.beta && !p1.beta && !p0.c_f32 && !p1.c_f32 && !g_gemm_force_tile && g_gemm_dma < 0 &&
@@ -1152,30 +325,6 @@ int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipS
     launch_pair_config(g, tbm, tbn, staging, stream);
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;
-}
-
-// grouped weight gradients of one block.  Items are ordered by reduction length, longest first (the key
-// projection reduces over twice as many tokens as the rest: started last, its tiles were the tail of the
-// launch), and the block tile / ring depth are autotuned per group signature like the single GEMMs.
-static void launch_grouped_config(GroupedWgrad& c, int tbm, int tbn, int stages, hipStream_t stream) {
-    int tiles = 0;
-    for (int i = 0; i < c.n; ++i) {
-        c.g[i].ntx = (c.g[i].N + tbn - 1) / tbn;
-        c.tile_start[i] = tiles;
-        tiles += ((c.g[i].M + tbm - 1) / tbm) * c.g[i].ntx;
-    }
-    for (int i = c.n; i <= MEBT_MAX_GROUP; ++i) c.tile_start[i] = tiles;
-#define LAUNCH_G(TM_, TN_)                                                                                                                   \
-    do {                                                                                                                                    \
-        if (stages >= 4) hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 4>), dim3(tiles), dim3(256), 4 * (TM_ + TN_) * BK * 2, stream, c);      \
-        else if (stages == 3) hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 3>), dim3(tiles), dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, c); \
-        else hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 2>), dim3(tiles), dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, c);                 \
-    } while (0)
-    if (tbm == 128 && tbn == 128) LAUNCH_G(128, 128);
-    else if (tbm == 128 && tbn == 64) LAUNCH_G(128, 64);
-    else if (tbm == 64 && tbn == 128) LAUNCH_G(64, 128);
-    else LAUNCH_G(64, 64);
-#undef LAUNCH_G
 }
 
 int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
@@ -1229,56 +378,8 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
 }
 
 int gemm_init_attributes() {
-#define SET_G(TM_, TN_)                                                                                                                                        \
-    do {                                                                                                                                                  \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2)); \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM_ + TN_) * BK * 2)); \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TM_, TN_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (TM_ + TN_) * BK * 2)); \
-    } while (0)
-    SET_G(128, 128); SET_G(128, 64); SET_G(64, 128); SET_G(64, 64);
-#undef SET_G
-#define SET_P(AK, BKC, TM_, TN_)                                                                                                                           \
-    do {                                                                                                                                                  \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pair_kernel<AK, BKC, TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2)); \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pair_kernel<AK, BKC, TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM_ + TN_) * BK * 2)); \
-        if (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pair_kernel<AK, BKC, TM_, TN_, (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024 ? 4 : 2)>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (TM_ + TN_) * BK * 2)); \
-    } while (0)
-#define SET_K(AK, BKC, TM_, TN_)                                                                                                                           \
-    do {                                                                                                                                                  \
-        if (ks2_lds(TM_, TN_, 2)) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_ks2_kernel<AK, BKC, TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ks2_lds(TM_, TN_, 2))); \
-        if (ks2_lds(TM_, TN_, 3)) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_ks2_kernel<AK, BKC, TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ks2_lds(TM_, TN_, 3))); \
-    } while (0)
-#define SET_KS2(AK, BKC) do { SET_K(AK, BKC, 96, 64); SET_K(AK, BKC, 64, 64); SET_K(AK, BKC, 96, 128); SET_K(AK, BKC, 64, 128); SET_K(AK, BKC, 128, 64); } while (0)
-    SET_KS2(true, true); SET_KS2(true, false); SET_KS2(false, false); SET_KS2(false, true);
-#undef SET_KS2
-#undef SET_K
-#define SET_PAIR(AK, BKC) do { SET_P(AK, BKC, 192, 128); SET_P(AK, BKC, 128, 128); SET_P(AK, BKC, 96, 128); SET_P(AK, BKC, 128, 64); SET_P(AK, BKC, 64, 128); SET_P(AK, BKC, 96, 64); SET_P(AK, BKC, 64, 64); } while (0)
-    SET_PAIR(true, true);
-    SET_PAIR(true, false);
-#undef SET_PAIR
-#undef SET_P
-    // dynamic LDS up to 64 KiB
-#define SET_T(AK, BKC, TM_, TN_)                                                                                                  \
-    do {                                                                                                                         \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AK, BKC, TM_, TN_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2)); \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM_ + TN_) * BK * 2)); \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2)); \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (TM_ + TN_) * BK * 2)); \
-        if (5 * (TM_ + TN_) * BK * 2 <= 160 * 1024) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, (5 * (TM_ + TN_) * BK * 2 <= 160 * 1024 ? 5 : 2)>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * (TM_ + TN_) * BK * 2)); \
-    } while (0)
-#define SET_D(AK, BKC, TM_, TN_)                                                                                                  \
-    do {                                                                                                                         \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2)); \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM_ + TN_) * BK * 2)); \
-        if (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<AK, BKC, TM_, TN_, (4 * (TM_ + TN_) * BK * 2 <= 128 * 1024 ? 4 : 2)>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (TM_ + TN_) * BK * 2)); \
-    } while (0)
-#define SET_ATTR(AK, BKC) do { SET_T(AK, BKC, 128, 128); SET_T(AK, BKC, 128, 64); SET_T(AK, BKC, 64, 128); SET_T(AK, BKC, 64, 64); SET_D(AK, BKC, 192, 128); SET_D(AK, BKC, 96, 128); SET_D(AK, BKC, 96, 64); } while (0)
-    SET_ATTR(true, true);
-    SET_ATTR(true, false);
-    SET_ATTR(false, false);
-    SET_ATTR(false, true);
-#undef SET_ATTR
-#undef SET_D
-#undef SET_T
-    return MEBT_OK;
+    if (int rc = mebt_gemm_attrs_kk()) return rc;
+    if (int rc = mebt_gemm_attrs_kr()) return rc;
+    if (int rc = mebt_gemm_attrs_rr()) return rc;
+    return mebt_gemm_attrs_rk();
 }
