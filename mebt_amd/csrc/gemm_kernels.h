@@ -88,7 +88,9 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
 // (always valid) addresses: a load under a per-row bounds/epilogue branch makes hipcc wait for it inside
 // the branch, which turned the 16 row passes of a wave into 16-32 dependent L2/HBM round trips.
 // EPI_ADAMW: the tile is a weight gradient; apply AdamW to the parameter tile in place (p, m, v fp32 + bf16 mirror)
-// instead of storing it.  Straight-line per 16-row slab: all 12 loads of the slab's 4 row passes first.
+// instead of storing it.  Straight-line per 16-row slab, software-pipelined over the slabs: the 12 loads of slab
+// i + 1 are in flight while slab i is staged through LDS, updated and stored (a tile's epilogue is one exposed HBM
+// round trip instead of one per slab).
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_adamw(const GemmParams& p, const f32x4 (&acc)[TM][TN], char* smem, int wave, int lane,
                                                int mbase, int nbase) {
@@ -99,19 +101,22 @@ __device__ __forceinline__ void epilogue_adamw(const GemmParams& p, const f32x4 
     const int n = nbase + c4;
     const bool n_ok = n < p.N;
     const int nc = n_ok ? n : 0;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        f32x4 pp[NPASS], mm[NPASS], vv[NPASS];
-        size_t ci[NPASS];
+    f32x4 pp[2][NPASS], mm[2][NPASS], vv[2][NPASS];
+    auto prefetch = [&](int i, int buf) {
 #pragma unroll
         for (int r = 0; r < NPASS; ++r) {
             const int m = min(mbase + i * 16 + r * RPI + r0, p.M - 1);
-            ci[r] = (size_t)m * p.ldc + nc;
-            pp[r] = *reinterpret_cast<const f32x4*>(p.opt_p + ci[r]);
-            mm[r] = *reinterpret_cast<const f32x4*>(p.opt_m + ci[r]);
-            vv[r] = *reinterpret_cast<const f32x4*>(p.opt_v + ci[r]);
+            const size_t ci = (size_t)m * p.ldc + nc;
+            pp[buf][r] = *reinterpret_cast<const f32x4*>(p.opt_p + ci);
+            mm[buf][r] = *reinterpret_cast<const f32x4*>(p.opt_m + ci);
+            vv[buf][r] = *reinterpret_cast<const f32x4*>(p.opt_v + ci);
         }
+    };
+    prefetch(0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (i + 1 < TM) prefetch(i + 1, (i + 1) & 1);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             *reinterpret_cast<f32x4*>(st + (lane & 15) * LD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
@@ -120,12 +125,14 @@ __device__ __forceinline__ void epilogue_adamw(const GemmParams& p, const f32x4 
         for (int r = 0; r < NPASS; ++r) {
             const int row = r * RPI + r0;
             const f32x4 g = *reinterpret_cast<const f32x4*>(st + row * LD + c4);
-            adamw_update4(pp[r], g, mm[r], vv[r], p.opt);
-            if (mbase + i * 16 + row < p.M && n_ok) {
-                *reinterpret_cast<f32x4*>(p.opt_p + ci[r]) = pp[r];
-                *reinterpret_cast<f32x4*>(p.opt_m + ci[r]) = mm[r];
-                *reinterpret_cast<f32x4*>(p.opt_v + ci[r]) = vv[r];
-                if (p.opt_lp) store4<bf16_t>(reinterpret_cast<bf16_t*>(p.opt_lp) + ci[r], pp[r]);
+            adamw_update4(pp[i & 1][r], g, mm[i & 1][r], vv[i & 1][r], p.opt);
+            const int m = mbase + i * 16 + row;
+            if (m < p.M && n_ok) {
+                const size_t ci = (size_t)m * p.ldc + n;
+                *reinterpret_cast<f32x4*>(p.opt_p + ci) = pp[i & 1][r];
+                *reinterpret_cast<f32x4*>(p.opt_m + ci) = mm[i & 1][r];
+                *reinterpret_cast<f32x4*>(p.opt_v + ci) = vv[i & 1][r];
+                if (p.opt_lp) store4<bf16_t>(reinterpret_cast<bf16_t*>(p.opt_lp) + ci, pp[i & 1][r]);
             }
         }
     }
