@@ -472,14 +472,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, i
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_grouped_kernel(const GroupedColsum c) {
+__device__ __forceinline__ void colsum_grouped_body(const GroupedColsum& c, int bid) {
     __shared__ float red[16][64 + 4];
     int g = 0;
 #pragma unroll
     for (int i = 1; i < MEBT_MAX_GROUP; ++i)
-        if (i < c.n && (int)blockIdx.x >= c.blk_start[i]) g = i;
+        if (i < c.n && bid >= c.blk_start[i]) g = i;
     const GroupedColsum::Item& it = c.g[g];
-    const int b = blockIdx.x - c.blk_start[g];
+    const int b = bid - c.blk_start[g];
     const int bx = b % it.gx, by = b / it.gx;
     const T* X = reinterpret_cast<const T*>(it.X);
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -498,6 +498,23 @@ __global__ __launch_bounds__(256) void colsum_grouped_kernel(const GroupedColsum
         for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
         const int col = bx * 64 + threadIdx.x;
         if (col < it.N) atomicAdd(it.out + col, t);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_grouped_kernel(const GroupedColsum c) { colsum_grouped_body<T>(c, blockIdx.x); }
+
+// LayerNorm backward + the bias column sums of the same block in ONE launch: workgroups [0, dx_blocks) dx rows,
+// [dx_blocks, cs_start) dgamma/dbeta column chunks, [cs_start, ...) grouped column sums (ln_bwd_kernel above is the
+// two-part form; the body functions are shared)
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_colsum_kernel(const LnBwdMulti mj, const LnBwdMulti mp, const GroupedColsum cs, int dx_blocks, int cs_start) {
+    if ((int)blockIdx.x < dx_blocks) {
+        if constexpr (NCH > 0) ln_bwd_dx_fast_body<T, NCH>(mj, blockIdx.x);
+        else ln_bwd_dx_body<T>(mj, blockIdx.x);
+    } else if ((int)blockIdx.x < cs_start) {
+        ln_bwd_param_body<T>(mp, blockIdx.x - dx_blocks);
+    } else {
+        colsum_grouped_body<T>(cs, blockIdx.x - cs_start);
     }
 }
 
@@ -699,7 +716,8 @@ int launch_ln_fwd_multi(const LnFwdParams* jobs, int n, int dtype, hipStream_t s
 
 int launch_ln_fwd(const LnFwdParams& p, int dtype, hipStream_t stream) { return launch_ln_fwd_multi(&p, 1, dtype, stream); }
 
-int launch_ln_bwd_multi(const LnBwdParams* jobs, int n, int dtype, hipStream_t stream, hipStream_t param_stream) {
+static int prepare_colsum(const GroupedColsum& c, GroupedColsum& k, int& blocks_out);
+int launch_ln_bwd_multi(const LnBwdParams* jobs, int n, int dtype, hipStream_t stream, hipStream_t param_stream, const GroupedColsum* colsums) {
     LnBwdMulti mj, mp;
     int k = 0, blocks = 0, pblocks = 0;
     for (int i = 0; i < n; ++i) {
@@ -723,10 +741,29 @@ int launch_ln_bwd_multi(const LnBwdParams* jobs, int n, int dtype, hipStream_t s
     if (!k) return MEBT_OK;
     mj.n = mp.n = k;
     for (int i = k; i <= MEBT_LN_MAXJ; ++i) { mj.blk_start[i] = blocks; mp.blk_start[i] = pblocks; }
-    (void)param_stream;                      // both parts are one launch on `stream` now
+    (void)param_stream;                      // all parts are one launch on `stream` now
     bool same_d = true;
     for (int i = 1; i < k; ++i) same_d = same_d && mj.j[i].d == mj.j[0].d;
     const int d0 = mj.j[0].d;
+    GroupedColsum cs;
+    int cblocks = 0;
+    if (colsums) { if (int rc = prepare_colsum(*colsums, cs, cblocks)) return rc; }
+    if (cblocks) {
+        const dim3 grid(blocks + pblocks + cblocks);
+        const int cs_start = blocks + pblocks;
+        if (dtype == MEBT_BF16) {
+            if (same_d && d0 == 1024) hipLaunchKernelGGL((ln_bwd_colsum_kernel<bf16_t, 2>), grid, dim3(256), 0, stream, mj, mp, cs, blocks, cs_start);
+            else if (same_d && d0 == 512) hipLaunchKernelGGL((ln_bwd_colsum_kernel<bf16_t, 1>), grid, dim3(256), 0, stream, mj, mp, cs, blocks, cs_start);
+            else if (same_d && d0 == 2048) hipLaunchKernelGGL((ln_bwd_colsum_kernel<bf16_t, 4>), grid, dim3(256), 0, stream, mj, mp, cs, blocks, cs_start);
+            else hipLaunchKernelGGL((ln_bwd_colsum_kernel<bf16_t, 0>), grid, dim3(256), 0, stream, mj, mp, cs, blocks, cs_start);
+        } else {
+            if (same_d && d0 == 1024) hipLaunchKernelGGL((ln_bwd_colsum_kernel<float, 4>), grid, dim3(256), 0, stream, mj, mp, cs, blocks, cs_start);
+            else if (same_d && d0 == 256) hipLaunchKernelGGL((ln_bwd_colsum_kernel<float, 1>), grid, dim3(256), 0, stream, mj, mp, cs, blocks, cs_start);
+            else hipLaunchKernelGGL((ln_bwd_colsum_kernel<float, 0>), grid, dim3(256), 0, stream, mj, mp, cs, blocks, cs_start);
+        }
+        CHECK_LAUNCH();
+        return MEBT_OK;
+    }
     const dim3 grid(blocks + pblocks);
     if (dtype == MEBT_BF16) {
         if (same_d && d0 == 1024) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 2>), grid, dim3(256), 0, stream, mj, mp, blocks);
@@ -742,7 +779,7 @@ int launch_ln_bwd_multi(const LnBwdParams* jobs, int n, int dtype, hipStream_t s
     return MEBT_OK;
 }
 
-int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream, hipStream_t param_stream) { return launch_ln_bwd_multi(&p, 1, dtype, stream, param_stream); }
+int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream, hipStream_t param_stream) { return launch_ln_bwd_multi(&p, 1, dtype, stream, param_stream, nullptr); }
 
 int launch_colsum(const void* X, int M, int N, int ldx, float* out, int dtype, hipStream_t stream) {
     if (M <= 0 || N <= 0) return MEBT_OK;
@@ -758,8 +795,7 @@ int launch_colsum(const void* X, int M, int N, int ldx, float* out, int dtype, h
     return MEBT_OK;
 }
 
-int launch_colsum_grouped(GroupedColsum& c, int dtype, hipStream_t stream) {
-    GroupedColsum k;
+static int prepare_colsum(const GroupedColsum& c, GroupedColsum& k, int& blocks_out) {
     int n = 0, blocks = 0;
     for (int i = 0; i < c.n; ++i) {
         if (c.g[i].M <= 0 || c.g[i].N <= 0) continue;
@@ -776,6 +812,14 @@ int launch_colsum_grouped(GroupedColsum& c, int dtype, hipStream_t stream) {
     }
     k.n = n;
     for (int i = n; i <= MEBT_MAX_GROUP; ++i) k.blk_start[i] = blocks;
+    blocks_out = blocks;
+    return MEBT_OK;
+}
+
+int launch_colsum_grouped(GroupedColsum& c, int dtype, hipStream_t stream) {
+    GroupedColsum k;
+    int blocks = 0;
+    if (int rc = prepare_colsum(c, k, blocks)) return rc;
     if (!blocks) return MEBT_OK;
     if (dtype == MEBT_BF16) hipLaunchKernelGGL(colsum_grouped_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, k);
     else hipLaunchKernelGGL(colsum_grouped_kernel<float>, dim3(blocks), dim3(256), 0, stream, k);

@@ -673,9 +673,11 @@ static int fused_adamw_slice(mebt_model* m, const float* g, int64_t n, hipStream
     return launch_adamw(a, st);
 }
 
-static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd) {
+// weight gradients of a block (one grouped launch); its bias column sums ride along with the block's LN1-backward
+// launch (launch_ln_bwd_multi(..., &lv.c)) unless `with_colsum`
+static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd, bool with_colsum = false) {
     const int dt = m->d.dtype;
-    RC(launch_colsum_grouped(lv.c, dt, sd));
+    if (with_colsum) RC(launch_colsum_grouped(lv.c, dt, sd));
     for (int i = 0; i < lv.w.n; ++i) {      // empty reductions (NC = 0): the gradient is zero
         const GroupedWgrad::Item& it = lv.w.g[i];
         if (it.K <= 0 && it.M > 0 && it.N > 0) MEBT_HIP_CHECK(hipMemset2DAsync(it.C, (size_t)it.ldc * 4, 0, (size_t)it.N * 4, it.M, sd));
@@ -827,7 +829,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
             x.gT_defined = true;
         }
     }
-    RC(launch_ln_bwd_multi(lj, nj, dt, st, sd));
+    RC(launch_ln_bwd_multi(lj, nj, dt, st, sd, &lv.c));
     if (side) MEBT_HIP_CHECK(hipEventRecord(m->ev_layer[i & 1], sd));   // this scratch set is free once the side stream gets here
     return MEBT_OK;
 }

@@ -117,7 +117,9 @@ struct LnBwdParams {
 };
 // dx rows and the dgamma/dbeta column reduction of `n` jobs in ONE launch on `stream` (param_stream is ignored: kept for callers)
 int launch_ln_bwd(const LnBwdParams& p, int dtype, hipStream_t stream, hipStream_t param_stream = nullptr);
-int launch_ln_bwd_multi(const LnBwdParams* jobs, int n, int dtype, hipStream_t stream, hipStream_t param_stream = nullptr);
+struct GroupedColsum;
+// `colsums` (optional): grouped column sums (bias gradients) executed by extra workgroups of the same launch
+int launch_ln_bwd_multi(const LnBwdParams* jobs, int n, int dtype, hipStream_t stream, hipStream_t param_stream = nullptr, const GroupedColsum* colsums = nullptr);
 
 // dst[i] = src[i] * keep(site, i)  (dropout mask re-applied in backward); TS/TD chosen by flags
 int launch_apply_dropout(const void* src, void* dst, size_t n, int src_f32, int dst_f32, const DropCfg& d, hipStream_t stream);
