@@ -14,6 +14,10 @@ void mebt_gemm_ks2_kk(const GemmParams&, int, int, int, hipStream_t);
 void mebt_gemm_ks2_kr(const GemmParams&, int, int, int, hipStream_t);
 void mebt_gemm_ks2_rr(const GemmParams&, int, int, int, hipStream_t);
 void mebt_gemm_ks2_rk(const GemmParams&, int, int, int, hipStream_t);
+void mebt_gemm_w8_kk(const GemmParams&, int, hipStream_t);
+void mebt_gemm_w8_kr(const GemmParams&, int, hipStream_t);
+void mebt_gemm_w8_rr(const GemmParams&, int, hipStream_t);
+void mebt_gemm_w8_rk(const GemmParams&, int, hipStream_t);
 int mebt_gemm_attrs_kk(); int mebt_gemm_attrs_kr(); int mebt_gemm_attrs_rr(); int mebt_gemm_attrs_rk();
 void mebt_gemm_pair_kk(GemmPair&, int, int, int, hipStream_t);
 void mebt_gemm_pair_kr(GemmPair&, int, int, int, hipStream_t);
@@ -36,14 +40,14 @@ static void launch_grouped_config(GroupedWgrad& c, int tbm, int tbn, int stages,
 // host launcher
 // ------------------------------------------------------------------------------------------------
 static int g_gemm_force_split = 0;
-static int g_gemm_force_tile = 0;     // (BM << 8) | BN, benchmarking only
+static int g_gemm_force_tile = 0;     // (BM << 12) | BN, tests / tools only
 static int g_grouped_stages = 2;
 extern "C" void mebt_debug_grouped_stages(int n) { g_grouped_stages = n; }
 static int g_gemm_dma = -1;           // -1 autotune / heuristic; forced (tests, tools): 0 register-staged, 2..5 LDS-DMA ring depth, 16+r two pipelines, 32+r / 64+r split-K 2 / 4
 static int g_gemm_nostore = 0;        // experiments only (variant >= 100): skip the C store of plain epilogues
 extern "C" void mebt_debug_gemm_variant(int dma) { g_gemm_nostore = dma >= 100; g_gemm_dma = dma >= 100 ? (dma == 199 ? -1 : dma - 100) : dma; }
 void mebt_gemm_force_split(int s) { g_gemm_force_split = s; }
-extern "C" void mebt_debug_gemm_tile(int bm, int bn) { g_gemm_force_tile = (bm && bn) ? ((bm << 8) | bn) : 0; }
+extern "C" void mebt_debug_gemm_tile(int bm, int bn) { g_gemm_force_tile = (bm && bn) ? ((bm << 12) | bn) : 0; }
 
 // one bf16 launch with an explicit (block tile, staging) choice; staging 0 = register-staged 2 stages,
 // 2..5 = LDS-DMA ring with that many stages (clamped to what the tile's LDS footprint admits)
@@ -52,6 +56,13 @@ extern "C" void mebt_debug_gemm_tile(int bm, int bn) { g_gemm_force_tile = (bm &
 static float* g_sk_buf = nullptr;
 static size_t g_sk_bytes = 0;
 static void launch_bf16_config(const GemmParams& p, int tbm, int tbn, int staging, int split, hipStream_t stream) {
+    if (tbm == 256 && tbn == 256) {   // the 8-wave tile: whole reduction in the workgroup, ring 2
+        if (p.a_kc && p.b_kc) mebt_gemm_w8_kk(p, 2, stream);
+        else if (p.a_kc && !p.b_kc) mebt_gemm_w8_kr(p, 2, stream);
+        else if (!p.a_kc && !p.b_kc) mebt_gemm_w8_rr(p, 2, stream);
+        else mebt_gemm_w8_rk(p, 2, stream);
+        return;
+    }
     if (staging >= 16) {          // two pipelines: whole reduction in the workgroup, an even number of k-tiles
         if (split == 1 && p.K % (2 * BK) == 0 && ks2_lds(tbm, tbn, staging - 16)) { launch_bf16_ks2(p, tbm, tbn, staging - 16, stream); return; }
         staging -= 16;
@@ -101,7 +112,7 @@ struct TuneHash {
         return (size_t)(h ^ (h >> 29));
     }
 };
-static std::unordered_map<TuneKey, int, TuneHash> g_tuned;      // -> (tbm << 16) | (tbn << 8) | staging
+static std::unordered_map<TuneKey, int, TuneHash> g_tuned;      // -> (tbm << 20) | (tbn << 8) | staging
 static int g_autotune = -1, g_tune_log = 0;
 static const char* g_tune_cache = nullptr;                       // MEBT_GEMM_TUNE_CACHE: text file of tuned choices
 
@@ -204,6 +215,11 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
                 if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = 16 + st; }
             }
     }
+    if ((long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 96 && (p.a_kc ? p.K % BK == 0 : true)) {   // 8-wave 256 x 256 tile
+        float ms = 0.f;
+        if (int rc = time_cold([&] { launch_bf16_config(p, 256, 256, 2, 1, stream); }, stream, e0, e1, ms)) return rc;
+        if (ms < best) { best = ms; tbm = 256; tbn = 256; staging = 2; }
+    }
     if (g_tune_log)
         fprintf(stderr, "[mebt gemm autotune] M=%d N=%d K=%d a_kc=%d b_kc=%d epi=%d c_f32=%d -> %dx%d ring %d%s (%.1f us cold)\n", p.M, p.N, p.K,
                 p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, staging & 15, staging >= 64 ? " split-K 4" : staging >= 32 ? " split-K 2" : staging >= 16 ? " x2 pipelines" : "", best * 1e3f);
@@ -245,13 +261,13 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
             if (it == g_tuned.end()) {
                 heuristic_config(p, tbm, tbn, staging);
                 if (int rc = autotune_config(p, stream, tbm, tbn, staging)) return rc;
-                it = g_tuned.emplace(key, (tbm << 16) | (tbn << 8) | staging).first;
+                it = g_tuned.emplace(key, (tbm << 20) | (tbn << 8) | staging).first;
                 tune_remember(key, it->second);
             }
-            tbm = it->second >> 16; tbn = (it->second >> 8) & 255; staging = it->second & 255;
+            tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; staging = it->second & 255;
         } else {
             heuristic_config(p, tbm, tbn, staging);
-            if (g_gemm_force_tile) { tbm = g_gemm_force_tile >> 8; tbn = g_gemm_force_tile & 255; }
+            if (g_gemm_force_tile) { tbm = g_gemm_force_tile >> 12; tbn = g_gemm_force_tile & 0xFFF; }
             if (g_gemm_dma >= 0) staging = g_gemm_dma == 1 ? 3 : g_gemm_dma;       // forced: 0 reg, 2..5 LDS-DMA stages (1 = 3)
         }
         if (staging >= 32) {
@@ -313,14 +329,14 @@ int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipS
             if (g_tune_log)
                 fprintf(stderr, "[mebt gemm autotune] pair %dx%dx%d + %dx%dx%d b_kc=%d -> %dx%d ring %d (%.1f us cold; separate launches %.1f us)\n",
                         p0.M, p0.N, p0.K, p1.M, p1.N, p1.K, p0.b_kc, tbm, tbn, staging, best * 1e3f, sep * 1e3f);
-            it = g_tuned.emplace(key, sep <= best ? 0 : ((tbm << 16) | (tbn << 8) | staging)).first;
+            it = g_tuned.emplace(key, sep <= best ? 0 : ((tbm << 20) | (tbn << 8) | staging)).first;
             tune_remember(key, it->second);
         }
         if (it->second == 0) {       // the pair did not win on this shape
             if (int rc = launch_gemm(p0, dtype, stream)) return rc;
             return launch_gemm(p1, dtype, stream);
         }
-        tbm = it->second >> 16; tbn = (it->second >> 8) & 255; staging = it->second & 255;
+        tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; staging = it->second & 255;
     }
     launch_pair_config(g, tbm, tbn, staging, stream);
     MEBT_HIP_CHECK(hipGetLastError());
@@ -367,10 +383,10 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
                 for (int i = 0; i < n; ++i) fprintf(stderr, " %dx%dx%d", c.g[i].M, c.g[i].N, c.g[i].K);
                 fprintf(stderr, " -> %dx%d ring %d (%.1f us cold)\n", tbm, tbn, stages, best * 1e3f);
             }
-            it = g_tuned.emplace(key, (tbm << 16) | (tbn << 8) | stages).first;
+            it = g_tuned.emplace(key, (tbm << 20) | (tbn << 8) | stages).first;
             tune_remember(key, it->second);
         }
-        tbm = it->second >> 16; tbn = (it->second >> 8) & 255; stages = it->second & 255;
+        tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; stages = it->second & 255;
     }
     launch_grouped_config(c, tbm, tbn, stages, stream);
     MEBT_HIP_CHECK(hipGetLastError());

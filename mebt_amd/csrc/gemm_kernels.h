@@ -231,6 +231,8 @@ template <> __device__ __forceinline__ int rc_swizzle<64>(int krow) { return (((
 // 32-lane half) coincide mod 256 B -> move the second group to the neighbouring 32-B pair
 template <> __device__ __forceinline__ int rc_swizzle<96>(int krow) { return ((krow >> 3) & 1) << 1; }
 // 384-B rows: rows q and q+2 coincide mod 256 B, and so do r and r+8
+// 512-B rows: every k-row starts on the same bank -> the 8 k-rows of a 32-lane half (q = 0..3 of two groups) get 8 different 32-B pairs
+template <> __device__ __forceinline__ int rc_swizzle<256>(int krow) { return ((krow & 3) << 1) | (((krow >> 3) & 1) << 3); }
 template <> __device__ __forceinline__ int rc_swizzle<192>(int krow) { return (((krow >> 1) & 1) << 1) | (((krow >> 3) & 1) << 2); }
 
 // XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs (consecutive linear ids on
@@ -412,9 +414,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
 // are counted (`s_waitcnt vmcnt(N)`, never 0 inside the loop) and the barrier is the raw s_barrier
 // (a __syncthreads() would drain the DMA queue).
 // ------------------------------------------------------------------------------------------------
-template <bool KC, int ROWS>
+template <bool KC, int ROWS, int NW = 4>
 struct DmaLoader {
-    static constexpr int NP = ROWS / 32;      // 1-KiB pieces per wave per tile (ROWS/8 pieces, 4 waves)
+    static constexpr int NP = ROWS / (8 * NW);   // 1-KiB pieces per wave per tile (ROWS/8 pieces over NW waves)
     uint32_t goff[NP];
     bool ok[NP];
     uint32_t step;
@@ -426,7 +428,7 @@ struct DmaLoader {
             step = BK * 2;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const int row = 8 * (4 * i + wave) + (lane >> 3), slot = lane & 7;
+                const int row = 8 * (NW * i + wave) + (lane >> 3), slot = lane & 7;
                 const int c = slot ^ ((row >> 1) & 7);
                 goff[i] = ((uint32_t)row * ld + 8 * c) * 2;
                 ok[i] = true;
@@ -437,7 +439,7 @@ struct DmaLoader {
             step = (uint32_t)BK * ld * 2;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const int id = 64 * (4 * i + wave) + lane;
+                const int id = 64 * (NW * i + wave) + lane;
                 const int krow = id / CPR, slot = id % CPR;
                 const int c = slot ^ rc_swizzle<ROWS>(krow);
                 const int col = r0 + 8 * c;
@@ -451,7 +453,7 @@ struct DmaLoader {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const uint32_t off = ok[i] ? goff[i] + (uint32_t)kt * step : (uint32_t)MEBT_OOB;
-            dma16(rsrc, (unsigned)(size_t)(lds_char_ptr)(tile + (4 * i + wave) * 1024), off);
+            dma16(rsrc, (unsigned)(size_t)(lds_char_ptr)(tile + (NW * i + wave) * 1024), off);
         }
     }
 };
@@ -549,6 +551,72 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
     } else {
         epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
     }
+}
+
+// 8-wave workgroup on ONE 256 x 256 tile: waves 2 (M) x 4 (N), wave tile 128 x 64.  Per k-tile it moves 64 KiB for
+// 8.4 MFLOP (7.8 B per KFLOP, 40 % less than 192 x 128), which lifts the fill-rate cap of the large products
+// (outputs of >= 12 M elements: the MLP up-projection at 3072 rows, the vocabulary head).
+template <bool A_KC, bool B_KC, int NSTAGE>
+__global__ __launch_bounds__(512) void gemm_bf16_w8_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TBM = 256, TBN = 256, NW = 8;
+    constexpr int STAGE = (TBM + TBN) * BK * 2;
+    constexpr int TM = 8, TN = 4;                       // 16x16 MFMA tiles per wave
+    constexpr int LPT = (TBM + TBN) / (8 * NW);         // DMA instructions per wave per tile
+    const int ntx = gridDim.x, nty = gridDim.y;
+    int tr, tc;
+    xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
+    const int m0 = tr * TBM, n0 = tc * TBN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nk = (p.K + BK - 1) / BK;
+
+    DmaLoader<A_KC, TBM, NW> la;
+    DmaLoader<B_KC, TBN, NW> lb;
+    la.init(p.A, p.M, p.K, p.lda, m0, wave, lane);
+    lb.init(p.B, p.N, p.K, p.ldb, n0, wave, lane);
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int AHEAD = NSTAGE - 1;
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        if (a < nk) {
+            la.issue(smem + a * STAGE, a, wave);
+            lb.issue(smem + a * STAGE + TBM * BK * 2, a, wave);
+        }
+    int st = 0;
+    for (int t = 0; t < nk; ++t) {
+        const int younger = min(AHEAD - 1, nk - 1 - t);
+        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");       // NSTAGE <= 3: at most one younger tile
+        __builtin_amdgcn_s_barrier();
+        if (t + AHEAD < nk) {
+            int s2 = st + AHEAD; if (s2 >= NSTAGE) s2 -= NSTAGE;
+            la.issue(smem + s2 * STAGE, t + AHEAD, wave);
+            lb.issue(smem + s2 * STAGE + TBM * BK * 2, t + AHEAD, wave);
+        }
+        const char* sA = smem + st * STAGE;
+        const char* sB = sA + TBM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = read_frag<A_KC, TBM>(sA, wm * TM + i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = read_frag<B_KC, TBN>(sB, wn * TN + j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (++st == NSTAGE) st = 0;
+    }
+    epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 4), true, false);
 }
 
 // two pipelines per workgroup (KS = 2): whole reduction in one workgroup, K a multiple of 128
@@ -889,6 +957,13 @@ static void layout_launch_grouped(GroupedWgrad& c, int tbm, int tbn, int stages,
 #undef LAUNCH_G
 }
 
+template <bool AK, bool BKC>
+static void layout_launch_w8(const GemmParams& p, int ring, hipStream_t stream) {
+    const dim3 grid((p.N + 255) / 256, (p.M + 255) / 256, 1);
+    if (ring >= 3) return;                          // 3 x 64 KiB does not fit the 160 KiB LDS: ring 2 only
+    hipLaunchKernelGGL((gemm_bf16_w8_kernel<AK, BKC, 2>), grid, dim3(512), 2 * 512 * BK * 2, stream, p);
+}
+
 // dynamic-LDS attributes of every instantiation of one operand layout (called once per process)
 template <bool AK, bool BKC>
 static int layout_set_attrs() {
@@ -912,6 +987,7 @@ static int layout_set_attrs() {
         if (ks2_lds(TM_, TN_, 3)) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_ks2_kernel<AK, BKC, TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ks2_lds(TM_, TN_, 3))); \
     } while (0)
     SET_T(128, 128); SET_T(128, 64); SET_T(64, 128); SET_T(64, 64); SET_D(192, 128); SET_D(96, 128); SET_D(96, 64);
+    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w8_kernel<AK, BKC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * BK * 2));
     SET_K(96, 64); SET_K(64, 64); SET_K(96, 128); SET_K(64, 128); SET_K(128, 64);
 #undef SET_K
 #undef SET_D

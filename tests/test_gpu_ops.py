@@ -67,7 +67,7 @@ def test_gemm_layouts_exact_integers(dtype, a_kc, b_kc, M, N, K):
 
 
 @pytest.mark.parametrize("staging", [0, 2, 1])
-@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 128), (64, 64), (192, 128), (96, 128), (96, 64)])
+@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 128), (64, 64), (192, 128), (96, 128), (96, 64), (256, 256)])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0), (0, 1)])
 def test_gemm_every_tile_variant(tile, a_kc, b_kc, staging):
     """each block-tile x staging instantiation of the bf16 kernel (register-staged, LDS-DMA 2-stage,
