@@ -208,7 +208,8 @@ def attn_ref(qq, kk, vv, H):
 
 
 @pytest.mark.parametrize("dtype,tol,generic", [(_lib.F32, 2e-5, 1), (_lib.BF16, 2e-2, 1), (_lib.BF16, 2e-2, 0)])
-@pytest.mark.parametrize("B,H,NQ,NK,HD", [(2, 2, 70, 45, 32), (2, 4, 64, 130, 64), (1, 3, 200, 1, 64), (2, 2, 33, 0, 64), (1, 2, 256, 513, 64)])
+@pytest.mark.parametrize("B,H,NQ,NK,HD", [(2, 2, 70, 45, 32), (2, 4, 64, 130, 64), (1, 3, 200, 1, 64), (2, 2, 33, 0, 64), (1, 2, 256, 513, 64),
+                                         (1, 2, 129, 257, 64), (1, 1, 300, 769, 64), (1, 2, 385, 256, 64)])
 def test_attention_fwd_bwd(dtype, tol, generic, B, H, NQ, NK, HD):
     t = tdt(dtype)
     C = H * HD
