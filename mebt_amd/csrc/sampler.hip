@@ -85,12 +85,20 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
     for (int e = tid; e < V; e += 256) sv[e] = sv[e] / se;
     __syncthreads();
     if (TOP_P) {                                         // :873-874, :898-910
-        // bitonic sort (descending) of (prob, id) pairs, n padded to a power of two
+        // bitonic sort (descending) of the ids by (probability, then lower id first).  Only entries with a non-zero
+        // probability take part: after top-k filtering that is k (+ ties) of the 16384, and the zeros neither move the
+        // cumulative sum nor need zeroing — same kept set as sorting the whole row (transformer.py:898-910).
+        __shared__ unsigned int nz_count;
+        if (tid == 0) nz_count = 0;
+        __syncthreads();
+        for (int e = tid; e < V; e += 256)
+            if (sv[e] > 0.f) si[atomicAdd(&nz_count, 1u)] = (unsigned short)e;
+        __syncthreads();
+        const int nnz = (int)nz_count;
         int n = 1;
-        while (n < V) n <<= 1;
-        // (ids only: the probabilities are looked up through the id, which keeps the row in place)
+        while (n < nnz) n <<= 1;
         auto pr = [&](int i) -> float { const unsigned id = si[i]; return id < (unsigned)V ? sv[id] : -1.0f; };
-        for (int e = tid; e < n; e += 256) si[e] = (unsigned short)(e < V ? e : 0xFFFF);
+        for (int e = nnz + tid; e < n; e += 256) si[e] = (unsigned short)0xFFFF;
         __syncthreads();
         for (int k = 2; k <= n; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -107,15 +115,15 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
             }
         if (tid == 0) {   // sequential cumulative sum, same order as torch.cumsum over the sorted row
             float c = 0.f;
-            int J = V;
-            for (int j = 0; j < V; ++j) {
+            int J = nnz;
+            for (int j = 0; j < nnz; ++j) {
                 if (j > 0 && c >= p.top_p) { J = j; break; }
                 c += sv[si[j]];
             }
             sJ = J;
         }
         __syncthreads();
-        for (int j = sJ + tid; j < V; j += 256) sv[si[j]] = 0.f;
+        for (int j = sJ + tid; j < nnz; j += 256) sv[si[j]] = 0.f;
         __syncthreads();
         float s = 0.f;
         for (int e = tid; e < V; e += 256) s += sv[e];
