@@ -123,7 +123,7 @@ static void tune_init() {
     const char* e = getenv("MEBT_GEMM_AUTOTUNE");
     g_autotune = (e && e[0] == '0') ? 0 : 1;
     const char* l = getenv("MEBT_GEMM_TUNE_LOG");
-    g_tune_log = (l && l[0] == '1') ? 1 : 0;
+    g_tune_log = l ? atoi(l) : 0;                     // 1: decisions, 2: every candidate
     g_tune_cache = getenv("MEBT_GEMM_TUNE_CACHE");
     if (g_tune_cache && g_tune_cache[0]) {
         if (FILE* f = fopen(g_tune_cache, "r")) {
@@ -193,6 +193,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
             if (st * (bm + bn) * BK * 2 > 128 * 1024) continue;
             float ms = 0.f;
             if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, st, 1, stream); }, stream, e0, e1, ms)) return rc;
+            if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d: %.1f us\n", bm, bn, st, ms * 1e3f);
             if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = st; }
         }
         if (!p.c_f32 && p.C && nt <= 256 && (long)bm * bn >= 128 * 128)          // split-K into fp32 slabs + reduce/epilogue kernel (staging 32 * log2(S) + ring)
@@ -204,6 +205,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
                     int rc2 = MEBT_OK;
                     if (int rc = time_cold([&] { rc2 |= launch_bf16_splitk(p, bm, bn, st, S, stream); }, stream, e0, e1, ms)) return rc;
                     if (rc2) return rc2;
+                    if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d split-K %d: %.1f us\n", bm, bn, st, S, ms * 1e3f);
                     if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = (S == 2 ? 32 : 64) + st; }
                 }
             }
@@ -212,12 +214,14 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
                 if (!ks2_lds(bm, bn, st)) continue;
                 float ms = 0.f;
                 if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, 16 + st, 1, stream); }, stream, e0, e1, ms)) return rc;
+                if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d x2 pipelines: %.1f us\n", bm, bn, st, ms * 1e3f);
                 if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = 16 + st; }
             }
     }
     if ((long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 96 && (p.a_kc ? p.K % BK == 0 : true)) {   // 8-wave 256 x 256 tile
         float ms = 0.f;
         if (int rc = time_cold([&] { launch_bf16_config(p, 256, 256, 2, 1, stream); }, stream, e0, e1, ms)) return rc;
+        if (g_tune_log >= 2) fprintf(stderr, "    cand 256x256 (8 waves): %.1f us\n", ms * 1e3f);
         if (ms < best) { best = ms; tbm = 256; tbn = 256; staging = 2; }
     }
     if (g_tune_log)
