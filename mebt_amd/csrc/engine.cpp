@@ -11,6 +11,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <cstdlib>
 
 namespace {
 
@@ -59,6 +60,7 @@ struct FwdCtx {
     struct Scratch { void *d4, *dh, *dx, *dqkv_q, *dqkv_k, *dqn, *dkn, *dout_m, *dx_m; } sc[2];
     float* delta = nullptr;
     bool gS_defined = false, gT_defined = false, gC_defined = false;
+    int doutm_ready = -1;      // block whose dropout-masked output gradient was already written by the LN1 backward above it
     bool drop_on = false; uint64_t drop_seed = 0;
 };
 
@@ -590,7 +592,7 @@ static int head_backward_common(mebt_model* m, hipStream_t st) {
     RC(wgrad(m, x.dlogits, V, x.hf, d, m->head_w, V, d, R, sd));
     RC(dgrad(m, x.dlogits, V, m->head_w, x.dhf, R, V, d, EPI_NONE, nullptr, 0, st));
     RC(ln_bwd(m, x.T_final, x.dhf, nullptr, m->lnf_w, m->lnf_b, x.meanf, x.rstdf, x.g_T, 0, 0, R, 0, 0, 0, st));
-    x.gT_defined = true; x.gS_defined = false; x.gC_defined = false;
+    x.gT_defined = true; x.gS_defined = false; x.gC_defined = false; x.doutm_ready = -1;
     return join_side(m, st);
 }
 
@@ -741,7 +743,8 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     // out = x + dropout(u W2^T + b2): the branch gradient is dout * mask (the mask is recomputed, never
     // stored).  It is materialised in scratch either way: the leaves read it after this block's LN1
     // backward has overwritten the stream gradient.
-    if (p_res > 0.f) RC(launch_apply_dropout(dout, sc.dout_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_MLP, p_res), st));
+    if (x.doutm_ready == i) x.doutm_ready = -1;     // written by the LN1 backward of the block above (see the end of this function)
+    else if (p_res > 0.f) RC(launch_apply_dropout(dout, sc.dout_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_MLP, p_res), st));
     else MEBT_HIP_CHECK(hipMemcpyAsync(sc.dout_m, dout, (size_t)Mq * d * esz, hipMemcpyDeviceToDevice, st));
     const void* dmlp = sc.dout_m;
     lv.colsum(dmlp, Mq, d, d, m->gP + o.b2);
@@ -827,6 +830,21 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
             ln1(a.q_in, sc.dkn, sc.dqn, a.mean1k, a.rstd1k, x.g_S, 0, 0, B * NS, NS, NS + NT, 0);
             ln1(a.k_in, sc.dkn, nullptr, a.mean1k, a.rstd1k, x.g_T, 0, x.gT_defined ? 1 : 0, B * NT, NT, NS + NT, NS);
             x.gT_defined = true;
+        }
+    }
+    // The job that finalises the stream gradient the block below consumes also writes that block's dropout-masked copy
+    // (its MLP branch gradient, dout * mask): one elementwise launch less per block.  Not with the side stream: the
+    // leaves of block i+1 may still be reading the other scratch set's dout_m.
+    static const int fuse_doutm = [] { const char* e = getenv("MEBT_FUSE_DOUTM"); return e ? atoi(e) : 1; }();
+    if (i > 0 && !side && p_res > 0.f && fuse_doutm) {
+        const bool below_dec = m->d.modes[i - 1] == MEBT_MODE_LATENT_DEC;
+        const void* want = below_dec ? x.g_T : x.g_S;
+        int k = -1;
+        for (int j = 0; j < nj; ++j) if (lj[j].dx == want) k = j;       // the last job writing it
+        if (k >= 0 && !lj[k].dx_f32) {
+            lj[k].dx2 = x.sc[(i - 1) & 1].dout_m;
+            lj[k].drop2 = make_drop(x.drop_seed, 16 * (i - 1) + SITE_MLP, p_res);
+            x.doutm_ready = i - 1;
         }
     }
     RC(launch_ln_bwd_multi(lj, nj, dt, st, sd, &lv.c));
