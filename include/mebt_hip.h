@@ -4,9 +4,16 @@
  * `mebt.transformer.Net2NetTransformer.forward / reconstruct_mask / shared_step / sample*` and the
  * optimiser step of the reference (Ugness/MeBT) — i.e. what the reference hands to ATen / cuBLAS /
  * NCCL through torch — as hand-written HIP kernels.  Plain pointers and sizes only: no torch types.
- * Every pointer is a DEVICE pointer owned by the caller (PyTorch allocates; kernels never
- * allocate), `stream` is a hipStream_t passed as an opaque pointer (NULL = default stream).  No
- * entry point synchronises with the host or allocates, so all of them are graph-capturable.
+ * Every pointer is a DEVICE pointer owned by the caller (PyTorch allocates; the library never
+ * allocates device memory: its only scratch — the GEMM tuner's cache-flush buffer and the split-K
+ * slabs — is part of the workspace the caller sizes with mebt_workspace_bytes), `stream` is a
+ * hipStream_t passed as an opaque pointer (NULL = default stream).  Entry points launch on that
+ * stream only and do not synchronise with the host, with ONE exception: in bf16 mode the first
+ * launch of a GEMM signature the process has not seen times its tile candidates on the caller's
+ * stream (hipEventSynchronize) before it returns.  mebt_gemm_autotune(0), MEBT_GEMM_AUTOTUNE=0 or
+ * a populated MEBT_GEMM_TUNE_CACHE remove that exception; then every entry point is capturable.
+ * Re-entrancy: one thread per model handle + workspace; the tuned-configuration table shared by
+ * all handles is a mutex-guarded shape -> configuration cache.
  *
  * Each entry point cites the reference code it replaces (paths relative to the reference root).
  * All functions return 0 on success, non-zero on error (MEBT_E*); mebt_last_error() holds a
@@ -33,7 +40,8 @@ enum mebt_status { MEBT_STATUS_OK = 0, MEBT_STATUS_EINVAL = 1, MEBT_STATUS_ESHAP
                    MEBT_STATUS_EWORKSPACE = 4, MEBT_STATUS_EDTYPE = 5 };
 enum mebt_dtype { MEBT_DTYPE_F32 = 0, MEBT_DTYPE_BF16 = 1 };
 /* Block routing modes, reference mebt/modules/gpt.py:164-179 */
-enum mebt_mode { MEBT_MODE_LATENT_ENC = 0, MEBT_MODE_LATENT_SELF = 1, MEBT_MODE_LATENT_DEC = 2, MEBT_MODE_LT2L = 3 };
+enum mebt_mode { MEBT_MODE_LATENT_ENC = 0, MEBT_MODE_LATENT_SELF = 1, MEBT_MODE_LATENT_DEC = 2, MEBT_MODE_LT2L = 3,
+                 MEBT_MODE_MASKGIT = 4 /* full attention over cat[contexts, targets]: the padding mode of gpt.py:176-178,191-192,208-209 */ };
 
 /* GPT hyper-parameters (reference mebt/modules/gpt.py:200-220, mebt/transformer.py:105-140). */
 typedef struct mebt_model_desc {
@@ -72,9 +80,20 @@ int mebt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N
                  const int64_t* x_ids, const int64_t* ci, const int64_t* ti, float* logits,
                  int32_t training, uint64_t dropout_seed, mebt_stream_t stream);
 /* GPT.forward on caller-embedded inputs (reference gpt.py:234-253): sos [B,NS,d], contexts [B,NC,d],
- * targets [B,NT,d] fp32 -> logits [B,NT,V].  Inference only (no activations kept). */
+ * targets [B,NT,d] fp32 -> logits [B,NT,V].  Inference (no activations kept); see mebt_gpt_forward_train. */
 int mebt_gpt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t NC, int32_t NT, const float* sos,
                      const float* contexts, const float* targets, float* logits, mebt_stream_t stream);
+/* The same in training mode: keeps the activations in `ws` for mebt_gpt_backward; dropout != 0 enables the
+ * embd / attn / resid dropout sites of gpt.py:135,140,154,238-240 under `dropout_seed`. */
+int mebt_gpt_forward_train(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t NC, int32_t NT, const float* sos,
+                           const float* contexts, const float* targets, float* logits, int32_t dropout, uint64_t dropout_seed,
+                           mebt_stream_t stream);
+/* Backward of GPT.forward (the autograd backward of gpt.py:234-253) from dL/dlogits [B,NT,V] fp32 after
+ * mebt_gpt_forward_train: block / ln_f / head parameter gradients into gW, gP (the embedding slices of gP are left zero) and the
+ * gradients of the three embedded inputs, fp32 like the inputs (each may be NULL).  Inputs the logits do not depend on
+ * get zeros. */
+int mebt_gpt_backward(mebt_model* m, void* ws, const float* dlogits, float* d_sos, float* d_contexts, float* d_targets,
+                      mebt_stream_t stream);
 /* Masked-token loss + top-1/top-5 of the last mebt_forward: replaces F.cross_entropy(sum,
  * label_smoothing) and utils.accuracy (transformer.py:726-731, utils.py:80-94).
  * out4 (device, 4 doubles) = { CE sum, #top-1 hits, #top-5 hits, #rows }. */
@@ -112,6 +131,11 @@ int mebt_adamw_range(mebt_model* m, float* mW, float* vW, float* mP, float* vP, 
  * or inspected first. */
 int mebt_model_set_fused_adamw(mebt_model* m, float* mW, float* vW, float lr, float beta1, float beta2, float eps,
                                float weight_decay, int32_t step, float grad_scale);
+
+/* Gradient accumulation over micro-batches (reference train_transformer.py:46-49, Lightning's accumulate_grad_batches):
+ * on = 1: the following mebt_backward_* calls ADD to gW / gP; on = 0 (default): they overwrite.  Not together with
+ * mebt_model_set_fused_adamw. */
+int mebt_model_set_grad_accumulate(mebt_model* m, int32_t on);
 
 /* ---- operator entry points (building blocks; also what the parity tests call) ---------------------- */
 /* C[M,N] = sum_k A(m,k) B(n,k) + bias, epilogue 0 none / 1 GELU (C=pre, C2=gelu) / 2 +aux residual /
@@ -156,6 +180,10 @@ int mebt_op_next_mask(const int64_t* ci, const int64_t* ti, const float* score, 
 /* fp32 -> bf16 cast of a flat buffer (n multiple of 4). */
 int mebt_op_cast_bf16(const float* src, void* dst, int64_t n, mebt_stream_t stream);
 
+/* 0: never time GEMM candidates (measured heuristic or cached choices only: no host synchronisation anywhere);
+ * 1: tune unseen signatures at their first launch (default; environment MEBT_GEMM_AUTOTUNE). */
+void mebt_gemm_autotune(int32_t mode);
+
 /* ---- instrumentation ----------------------------------------------------------------------------- */
 /* Per-kernel-family timing with HIP events on the launch stream (bench.py roofline): enable, run,
  * then read {launches, total ms, total algorithmic flops} of the GEMM family (family 0), or the
@@ -173,6 +201,9 @@ void mebt_debug_gemm_tile(int32_t bm, int32_t bn);
 /* Benchmarking / tests only: force the bf16 GEMM staging: 0 register-staged, 2 LDS-DMA 2 stages, 1 LDS-DMA
  * 3-stage ring; -1 restores the measured heuristic. */
 void mebt_debug_gemm_variant(int32_t dma);
+/* Benchmarking only: a caller-owned device buffer (>= 496 MiB) the operator-level mebt_op_gemm may use as tuner /
+ * split-K scratch (model-level entry points use their workspace); NULL removes it. */
+void mebt_debug_gemm_scratch(void* buf, int64_t bytes);
 /* Benchmarking only: LDS-DMA ring depth (2 or 3) of the grouped weight-gradient GEMM. */
 void mebt_debug_grouped_stages(int32_t n);
 

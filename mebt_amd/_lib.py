@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmebt_hip.so")
 MEBT_MAX_LAYERS = 128
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_GELU_BWD = 0, 1, 2, 3
-MODE_IDS = {"latent_enc": 0, "latent_self": 1, "latent_dec": 2, "lt2l": 3}
+MODE_IDS = {"latent_enc": 0, "latent_self": 1, "latent_dec": 2, "lt2l": 3, "maskgit": 4}
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -36,6 +36,8 @@ PROTOTYPES = {
     "mebt_workspace_bytes": (c_i64, [c_vp, c_i32, c_i32, c_i32, c_i32]),
     "mebt_forward": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.c_uint64, c_vp]),
     "mebt_gpt_forward": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mebt_gpt_forward_train": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.c_uint64, c_vp]),
+    "mebt_gpt_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mebt_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mebt_backward_head": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     "mebt_backward_head_dlogits": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
@@ -44,6 +46,7 @@ PROTOTYPES = {
     "mebt_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp]),
     "mebt_adamw_range": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_i32, c_i32, c_i32, c_vp]),
     "mebt_model_set_fused_adamw": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32]),
+    "mebt_model_set_grad_accumulate": (c_i32, [c_vp, c_i32]),
     "mebt_op_gemm": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 13 + [c_vp]),
     "mebt_op_layernorm_fwd": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "mebt_op_layernorm_bwd": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
@@ -59,6 +62,8 @@ PROTOTYPES = {
     "mebt_debug_gemm_tile": (None, [c_i32, c_i32]),
     "mebt_debug_gemm_variant": (None, [c_i32]),
     "mebt_debug_grouped_stages": (None, [c_i32]),
+    "mebt_debug_gemm_scratch": (None, [c_vp, c_i64]),
+    "mebt_gemm_autotune": (None, [c_i32]),
     "mebt_profile_enable": (c_i32, [c_i32]),
     "mebt_profile_read": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

@@ -644,6 +644,18 @@ __global__ __launch_bounds__(256) void apply_dropout_kernel(const TS* src, TD* d
     }
 }
 
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const TS* src, TD* dst, long rows, int d, int s_seg, int s_stride, int s_off,
+                                                        int d_seg, int d_stride, int d_off) {
+    const int d4 = d / 4;
+    const long total = rows * d4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / d4;
+        const int e = (int)(i % d4) * 4;
+        store4<TD>(dst + (size_t)map_row(r, d_seg, d_stride, d_off) * d + e, load4<TS>(src + (size_t)map_row(r, s_seg, s_stride, s_off) * d + e));
+    }
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16_t* dst, size_t n) {
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024)
         store4<bf16_t>(dst + i, *reinterpret_cast<const f32x4*>(src + i));
@@ -863,6 +875,22 @@ int launch_apply_dropout(const void* src, void* dst, size_t n, int src_f32, int 
     if (src_f32 && dst_f32) hipLaunchKernelGGL((apply_dropout_kernel<float, float>), grid, dim3(256), 0, stream, (const float*)src, (float*)dst, n, d);
     else if (!src_f32 && !dst_f32) hipLaunchKernelGGL((apply_dropout_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, n, d);
     else { mebt_set_error("dropout: mixed element types are not supported"); return MEBT_EDTYPE; }
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+
+int launch_copy_rows(const void* src, void* dst, long rows, int d, int src_f32, int dst_f32, int s_seg, int s_stride, int s_off,
+                     int d_seg, int d_stride, int d_off, hipStream_t stream) {
+    if (rows <= 0 || d <= 0) return MEBT_OK;
+    if (d % 4) { mebt_set_error("copy_rows: d must be a multiple of 4"); return MEBT_ESHAPE; }
+    const long blocks = (rows * (d / 4) + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192));
+#define COPY_ROWS(TS, TD) hipLaunchKernelGGL((copy_rows_kernel<TS, TD>), grid, dim3(256), 0, stream, (const TS*)src, (TD*)dst, rows, d, s_seg, s_stride, s_off, d_seg, d_stride, d_off)
+    if (src_f32 && dst_f32) COPY_ROWS(float, float);
+    else if (src_f32) COPY_ROWS(float, bf16_t);
+    else if (dst_f32) COPY_ROWS(bf16_t, float);
+    else COPY_ROWS(bf16_t, bf16_t);
+#undef COPY_ROWS
     CHECK_LAUNCH();
     return MEBT_OK;
 }

@@ -35,8 +35,9 @@ struct Carve {   // bump allocator over the workspace; query mode when base == n
 struct LayerAct {   // saved activations of one block
     void *qn, *kn, *q, *k, *v, *att, *x, *hn, *pre, *u, *out;
     float *mean1q, *rstd1q, *mean1k, *rstd1k, *mean2, *rstd2, *lse;
-    const void* q_in;   // LN1 input of the query side (previous stream value)
-    const void* k_in;   // LN1 input of the key side (enc: contexts, dec: sos); lt2l uses S and T
+    const void* q_in;   // LN1 input of the query side (previous stream value); maskgit: the contexts stream
+    const void* k_in;   // LN1 input of the key side (enc: contexts, dec: sos); lt2l uses S and T; maskgit: the targets stream
+    void *c_out, *t_out;   // maskgit: the block output split back into contiguous contexts / targets (gpt.py:191-192)
     int NQ, NK, ldqkv_q, ldqkv_k;
 };
 
@@ -54,6 +55,7 @@ struct FwdCtx {
     bool loss_done = false;
     // backward scratch
     void *g_S = nullptr, *g_T = nullptr; float* g_C = nullptr;
+    void* g_cat = nullptr;     // maskgit: cat[g_C, g_T], the gradient of a block output that spans both streams
     void *dlogits = nullptr, *dhf = nullptr, *datt = nullptr;
     // per-layer backward scratch, two sets (layer parity): the side stream may still read layer i's
     // operands while the main stream already produces layer i-1's
@@ -61,7 +63,9 @@ struct FwdCtx {
     float* delta = nullptr;
     bool gS_defined = false, gT_defined = false, gC_defined = false;
     int doutm_ready = -1;      // block whose dropout-masked output gradient was already written by the LN1 backward above it
+    int last_bwd_lo = -1;      // lowest block the previous mebt_backward_layers call finished (doutm_ready is only valid for a contiguous descent)
     bool drop_on = false; uint64_t drop_seed = 0;
+    GemmScratch tune = {nullptr, 0, nullptr, 0};     // GEMM tuner / split-K scratch, carved from the caller's workspace (bf16 mode)
 };
 
 }  // namespace
@@ -75,6 +79,7 @@ struct mebt_model {
     void* Wlp = nullptr;
     std::vector<char> live;   // per layer: does the loss depend on this block?
     bool tok_live = false;
+    bool has_maskgit = false;
     FwdCtx ctx;
     // side stream for work that nothing on the critical path waits for in backward (weight / bias / LN-affine
     // gradients).  It bought +14 % while the per-layer kernels were too small to fill 256 CUs; with the tuned,
@@ -86,6 +91,7 @@ struct mebt_model {
     // optimizer-in-backward (mebt_model_set_fused_adamw): when armed, the weight gradients of the blocks are applied
     // to W (AdamW) inside the weight-gradient launch instead of being stored in gW
     bool fused_on = false;
+    bool grad_acc = false;     // mebt_model_set_grad_accumulate: backward adds to gW / gP instead of overwriting them
     float *fused_mW = nullptr, *fused_vW = nullptr;
     AdamWHyper fused_h = {0, 0, 0, 0, 0, 1, 1, 1};
     int esz() const { return d.dtype == MEBT_BF16 ? 2 : 4; }
@@ -122,6 +128,7 @@ static int gemm(const mebt_model* m, GemmParams p, hipStream_t st) {
         else if (p.M > 0 && p.N > 0) { mebt_set_error("gemm: K = 0 with a fused epilogue is not supported"); return MEBT_ESHAPE; }
         return MEBT_OK;
     }
+    p.scratch = m->ctx.tune.flush ? &m->ctx.tune : nullptr;
     ProfRec r;
     const bool prof = g_prof_on && p.M > 0 && p.N > 0;
     if (prof) {
@@ -135,11 +142,13 @@ static int gemm(const mebt_model* m, GemmParams p, hipStream_t st) {
     return rc;
 }
 
-static int gemm_pair(const mebt_model* m, const GemmParams& p0, const GemmParams& p1, hipStream_t st) {
+static int gemm_pair(const mebt_model* m, const GemmParams& p0_in, const GemmParams& p1_in, hipStream_t st) {
+    GemmParams p0 = p0_in, p1 = p1_in;
     if (m->d.dtype != MEBT_BF16 || p0.K <= 0 || p1.K <= 0 || p0.M <= 0 || p1.M <= 0) {
         if (int rc = gemm(m, p0, st)) return rc;
         return gemm(m, p1, st);
     }
+    p0.scratch = p1.scratch = m->ctx.tune.flush ? &m->ctx.tune : nullptr;
     ProfRec r;
     if (g_prof_on) {
         r.a = get_event(); r.b = get_event(); r.flops = 2.0 * p0.M * p0.N * p0.K + 2.0 * p1.M * p1.N * p1.K;
@@ -188,8 +197,8 @@ extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) 
     if (d.n_latent <= 0) { mebt_set_error("model_create: sos_emb (latent tokens) must be > 0 for the latent routing modes"); return MEBT_ESHAPE; }
     if (d.dtype != MEBT_F32 && d.dtype != MEBT_BF16) { mebt_set_error("model_create: dtype must be f32 or bf16"); return MEBT_EDTYPE; }
     for (int i = 0; i < d.n_layer; ++i)
-        if (d.modes[i] < 0 || d.modes[i] > MEBT_MODE_LT2L) {
-            mebt_set_error("model_create: unsupported block mode (only latent_enc/latent_self/latent_dec/lt2l; 'maskgit' full attention is not built)");
+        if (d.modes[i] < 0 || d.modes[i] > MEBT_MODE_MASKGIT) {
+            mebt_set_error("model_create: unknown block mode (latent_enc / latent_self / latent_dec / lt2l / maskgit)");
             return MEBT_EINVAL;
         }
     if (d.embd_pdrop < 0.f || d.embd_pdrop >= 1.f || d.resid_pdrop < 0.f || d.resid_pdrop >= 1.f || d.attn_pdrop < 0.f || d.attn_pdrop >= 1.f) {
@@ -225,6 +234,7 @@ extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) 
             case MEBT_MODE_LATENT_SELF: if (gS) m->live[i] = 1; break;
             case MEBT_MODE_LT2L: if (gS) { m->live[i] = 1; gT = true; } break;
             case MEBT_MODE_LATENT_DEC: if (gT) { m->live[i] = 1; gS = true; } break;
+            case MEBT_MODE_MASKGIT: m->live[i] = 1; m->tok_live = true; m->has_maskgit = true; break;   // gT is always defined here
         }
     }
     int rc = gemm_init_attributes();
@@ -283,6 +293,7 @@ static void mode_shape(const mebt_model* m, int mode, int NC, int NT, int& NQ, i
         case MEBT_MODE_LATENT_ENC: NQ = NS; NK = NC; break;
         case MEBT_MODE_LATENT_SELF: NQ = NS; NK = NS; break;
         case MEBT_MODE_LATENT_DEC: NQ = NT; NK = NS; break;
+        case MEBT_MODE_MASKGIT: NQ = NC + NT; NK = NC + NT; break;
         default: NQ = NS; NK = NS + NT; break;
     }
 }
@@ -291,6 +302,12 @@ static void mode_shape(const mebt_model* m, int mode, int NC, int NT, int& NQ, i
 // all per-layer buffers alias one layer-sized region and the stream outputs ping-pong.
 static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int NT, int training) {
     const int64_t d = m->d.n_embd, e = m->esz(), NS = m->d.n_latent, H = m->d.n_head, V = m->d.vocab;
+    if (m->d.dtype == MEBT_BF16) {     // the library allocates nothing: the tuner's flush buffer and the split-K slabs come from here
+        x.tune.flush = c.take((int64_t)MEBT_TUNE_FLUSH_BYTES); x.tune.flush_bytes = MEBT_TUNE_FLUSH_BYTES;
+        x.tune.splitk = (float*)c.take((int64_t)MEBT_TUNE_SPLITK_BYTES); x.tune.splitk_bytes = MEBT_TUNE_SPLITK_BYTES;
+    } else {
+        x.tune = {nullptr, 0, nullptr, 0};
+    }
     x.sos0 = c.take(B * NS * d * e);
     x.ctx = c.take((int64_t)B * NC * d * e);
     x.tgt0 = c.take((int64_t)B * NT * d * e);
@@ -303,6 +320,11 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
         pingS[0] = c.take(B * NS * d * e); pingS[1] = c.take(B * NS * d * e);
         pingT[0] = c.take((int64_t)B * NT * d * e); pingT[1] = c.take((int64_t)B * NT * d * e);
     }
+    for (int i = 0; i < m->d.n_layer; ++i)      // a maskgit block rewrites both streams: its split outputs outlive the per-layer region
+        if (m->d.modes[i] == MEBT_MODE_MASKGIT) {
+            x.L[i].c_out = c.take((int64_t)B * NC * d * e);
+            x.L[i].t_out = c.take((int64_t)B * NT * d * e);
+        }
     const int64_t after_ping = c.off;
     int nS = 0, nT = 0;
     for (int i = 0; i < m->d.n_layer; ++i) {
@@ -313,7 +335,7 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
         if (!training) c.off = after_ping;
         a.qn = c.take(Mq * d * e);
         a.mean1q = (float*)c.take(Mq * 4); a.rstd1q = (float*)c.take(Mq * 4);
-        if (mode == MEBT_MODE_LATENT_SELF) {
+        if (mode == MEBT_MODE_LATENT_SELF || mode == MEBT_MODE_MASKGIT) {
             a.kn = a.qn; a.mean1k = a.mean1q; a.rstd1k = a.rstd1q;
             a.q = c.take(Mq * 3 * d * e);
             a.k = (char*)a.q + d * e; a.v = (char*)a.q + 2 * d * e;
@@ -332,7 +354,7 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
         a.hn = c.take(Mq * d * e);
         a.pre = training ? c.take(Mq * 4 * d * e) : nullptr;
         a.u = c.take(Mq * 4 * d * e);
-        if (training) a.out = c.take(Mq * d * e);
+        if (training || mode == MEBT_MODE_MASKGIT) a.out = c.take(Mq * d * e);
         else a.out = (mode == MEBT_MODE_LATENT_DEC) ? pingT[(nT++) & 1] : pingS[(nS++) & 1];
         if (c.off > layer_max) layer_max = c.off;
     }
@@ -347,6 +369,8 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
         x.loss_out = (double*)c.take(32);
         int64_t Mmax = (int64_t)B * (NS + NT);
         if ((int64_t)B * NC > Mmax) Mmax = (int64_t)B * NC;
+        if (m->has_maskgit && (int64_t)B * (NC + NT) > Mmax) Mmax = (int64_t)B * (NC + NT);
+        x.g_cat = m->has_maskgit ? c.take((int64_t)B * (NC + NT) * d * e) : nullptr;
         x.g_S = c.take(B * NS * d * e);
         x.g_T = c.take(R * d * e);
         x.g_C = (float*)c.take((int64_t)B * NC * d * 4);
@@ -365,7 +389,7 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
             s.dout_m = c.take(Mmax * d * e);
             s.dx_m = m->d.resid_pdrop > 0.f ? c.take(Mmax * d * e) : nullptr;
         }
-        x.delta = (float*)c.take((int64_t)B * H * (NS + NT) * 4);
+        x.delta = (float*)c.take((int64_t)B * H * (m->has_maskgit && NC > NS ? NC + NT : NS + NT) * 4);
     }
 }
 
@@ -408,7 +432,6 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
     if (!embedded && (!x_ids || !ti || (NC > 0 && !ci))) { mebt_set_error("forward: null pointer"); return MEBT_EINVAL; }
     const bool drop_on = (training & 2) != 0 && (m->d.embd_pdrop > 0.f || m->d.resid_pdrop > 0.f || m->d.attn_pdrop > 0.f);
     training = training & 1;
-    if (drop_on && embedded) { mebt_set_error("forward: dropout with caller-embedded inputs is not supported"); return MEBT_EINVAL; }
     FwdCtx& x = m->ctx;
     x.valid = false;
     Carve c{(char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), 0};
@@ -428,7 +451,10 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
             if (!embedded[k]) { mebt_set_error("forward: null embedded input"); return MEBT_EINVAL; }
             if (dt == MEBT_BF16) RC(launch_cast_f32_to_bf16(embedded[k], dst[k], cnt[k], st));
             else MEBT_HIP_CHECK(hipMemcpyAsync(dst[k], embedded[k], cnt[k] * 4, hipMemcpyDeviceToDevice, st));
+            static const uint32_t site[3] = {SITE_EMB_SOS, SITE_EMB_CTX, SITE_EMB_TGT};     // self.drop on the three inputs (gpt.py:238-240)
+            if (p_emb > 0.f) RC(launch_apply_dropout(dst[k], dst[k], cnt[k], dt == MEBT_F32, dt == MEBT_F32, make_drop(dropout_seed, site[k], p_emb), st));
         }
+        x.x_ids = nullptr; x.ci = nullptr; x.ti = nullptr;
     } else {
         EmbedParams ep;
         ep.x_ids = x_ids; ep.ci = ci; ep.ti = ti;
@@ -441,12 +467,13 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
 
     const void* Sv = x.sos0;
     const void* Tv = x.tgt0;
+    const void* Cv = x.ctx;          // read-only unless the model has 'maskgit' blocks (gpt.py:191-192)
     for (int i = 0; i < m->d.n_layer; ++i) {
         LayerAct& a = x.L[i];
         const LayerOffsets& o = m->lo[i];
         const int mode = m->d.modes[i];
         const int Mq = B * a.NQ, Mk = B * a.NK;
-        a.q_in = (mode == MEBT_MODE_LATENT_DEC) ? Tv : Sv;
+        a.q_in = (mode == MEBT_MODE_LATENT_DEC) ? Tv : (mode == MEBT_MODE_MASKGIT) ? Cv : Sv;
         // LN1 on query and key with the SAME parameters (gpt.py:180-181), then the projections
         // (gpt.py:126-128); the three [d,d] weights are adjacent in W so QKV / KV fuse.  The key side
         // is independent of the query side: both LayerNorms are one launch, both projections are one launch.
@@ -458,10 +485,16 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
                 p.x = xin; p.y = y; p.gamma = m->P + o.ln1w; p.beta = m->P + o.ln1b; p.mean = mean; p.rstd = rstd;
                 p.rows = rows; p.d = d; p.seg = seg; p.seg_stride = seg_stride; p.seg_off = seg_off;
             };
-            job(a.q_in, a.qn, a.mean1q, a.rstd1q, Mq, 0, 0, 0);
+            if (mode == MEBT_MODE_MASKGIT) {       // query = key = LN1(cat[contexts, targets]) (gpt.py:176-181)
+                a.k_in = Tv;
+                job(Cv, a.qn, a.mean1q, a.rstd1q, B * NC, NC, NC + NT, 0);
+                job(Tv, a.qn, a.mean1q, a.rstd1q, B * NT, NT, NC + NT, NC);
+            } else {
+                job(a.q_in, a.qn, a.mean1q, a.rstd1q, Mq, 0, 0, 0);
+            }
             if (mode == MEBT_MODE_LATENT_ENC) {
-                a.k_in = x.ctx;
-                job(x.ctx, a.kn, a.mean1k, a.rstd1k, Mk, 0, 0, 0);
+                a.k_in = Cv;
+                job(Cv, a.kn, a.mean1k, a.rstd1k, Mk, 0, 0, 0);
             } else if (mode == MEBT_MODE_LATENT_DEC) {
                 a.k_in = Sv;
                 job(Sv, a.kn, a.mean1k, a.rstd1k, Mk, 0, 0, 0);
@@ -469,12 +502,12 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
                 a.k_in = Tv;
                 job(Sv, a.kn, a.mean1k, a.rstd1k, B * NS, NS, NS + NT, 0);
                 job(Tv, a.kn, a.mean1k, a.rstd1k, B * NT, NT, NS + NT, NS);
-            } else {
+            } else if (mode == MEBT_MODE_LATENT_SELF) {
                 a.k_in = nullptr;
             }
             RC(launch_ln_fwd_multi(lj, nj, dt, st));
         }
-        if (mode == MEBT_MODE_LATENT_SELF) {
+        if (mode == MEBT_MODE_LATENT_SELF || mode == MEBT_MODE_MASKGIT) {
             GemmParams p = gp(a.qn, m->Wop(o.wq), a.q, Mq, 3 * d, d, d, d, 3 * d, 1, 1);
             p.bias = m->P + o.bq;
             RC(gemm(m, p, st));
@@ -513,7 +546,13 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
             p.drop = make_drop(dropout_seed, 16 * i + SITE_MLP, p_res);     // gpt.py:154
             RC(gemm(m, p, st));
         }
-        if (mode == MEBT_MODE_LATENT_DEC) Tv = a.out; else Sv = a.out;   // gpt.py:187-190
+        if (mode == MEBT_MODE_LATENT_DEC) Tv = a.out;                    // gpt.py:187-192
+        else if (mode == MEBT_MODE_MASKGIT) {                            // contexts, targets = x[:, :NC], x[:, NC:]
+            const int f32 = dt == MEBT_F32;
+            RC(launch_copy_rows(a.out, a.c_out, (long)B * NC, d, f32, f32, NC, NC + NT, 0, 0, 0, 0, st));
+            RC(launch_copy_rows(a.out, a.t_out, (long)B * NT, d, f32, f32, NT, NC + NT, NC, 0, 0, 0, st));
+            Cv = a.c_out; Tv = a.t_out;
+        } else Sv = a.out;
     }
     x.S_final = Sv; x.T_final = Tv;
     // logits = head(ln_f(targets))  (gpt.py:247-248; head has no bias)
@@ -540,9 +579,18 @@ extern "C" int mebt_gpt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32
     return forward_impl(m, ws, ws_bytes, B, 1, NC, NT, nullptr, nullptr, nullptr, e, logits, 0, 0, stream);
 }
 
+// GPT.forward in training mode on caller-embedded inputs: keeps the activations for mebt_gpt_backward
+extern "C" int mebt_gpt_forward_train(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t NC, int32_t NT, const float* sos,
+                                      const float* contexts, const float* targets, float* logits, int32_t dropout, uint64_t dropout_seed,
+                                      mebt_stream_t stream) {
+    const float* e[3] = {sos, contexts, targets};
+    return forward_impl(m, ws, ws_bytes, B, 1, NC, NT, nullptr, nullptr, nullptr, e, logits, 1 | (dropout ? 2 : 0), dropout_seed, stream);
+}
+
 extern "C" int mebt_loss(mebt_model* m, void* ws, const float* logits, double* out4, mebt_stream_t stream) {
     if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("loss: no training-mode forward on this workspace"); return MEBT_EINVAL; }
     FwdCtx& x = m->ctx;
+    if (!x.x_ids) { mebt_set_error("loss: the last forward ran on caller-embedded inputs (no token ids to score against)"); return MEBT_EINVAL; }
     if (!out4) out4 = x.loss_out;
     x.loss_done = true;
     CeParams p;
@@ -567,7 +615,7 @@ static int ln_bwd(const mebt_model* m, const void* x, const void* dy, const void
 // dW[n_out,k_in] = dY^T X (reduction over tokens), into the fp32 gradient buffer
 static int wgrad(const mebt_model* m, const void* dY, int ld_dy, const void* X, int ld_x, int64_t w_off, int n_out, int k_in, int tokens, hipStream_t st) {
     GemmParams p = gp(dY, X, m->gW + w_off, n_out, k_in, tokens, ld_dy, ld_x, k_in, 0, 0);
-    p.c_f32 = 1; p.split_k = 0;
+    p.c_f32 = 1; p.split_k = 0; p.beta = m->grad_acc ? 1 : 0;
     return gemm(m, p, st);
 }
 // dX[tokens,k_in] = dY W  (+aux)
@@ -592,7 +640,7 @@ static int head_backward_common(mebt_model* m, hipStream_t st) {
     RC(wgrad(m, x.dlogits, V, x.hf, d, m->head_w, V, d, R, sd));
     RC(dgrad(m, x.dlogits, V, m->head_w, x.dhf, R, V, d, EPI_NONE, nullptr, 0, st));
     RC(ln_bwd(m, x.T_final, x.dhf, nullptr, m->lnf_w, m->lnf_b, x.meanf, x.rstdf, x.g_T, 0, 0, R, 0, 0, 0, st));
-    x.gT_defined = true; x.gS_defined = false; x.gC_defined = false; x.doutm_ready = -1;
+    x.gT_defined = true; x.gS_defined = false; x.gC_defined = false; x.doutm_ready = -1; x.last_bwd_lo = m->d.n_layer;
     return join_side(m, st);
 }
 
@@ -600,6 +648,10 @@ static int backward_prologue(mebt_model* m, void* ws, hipStream_t st) {
     if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("backward: no training-mode forward on this workspace"); return MEBT_EINVAL; }
     if (!m->gW || !m->gP) { mebt_set_error("backward: gradient buffers not bound"); return MEBT_EINVAL; }
     const int d = m->d.n_embd;
+    if (m->grad_acc) {           // a further micro-batch: everything below adds to what the buffers hold
+        if (m->fused_on) { mebt_set_error("backward: gradient accumulation and the optimizer-in-backward exclude each other"); return MEBT_EINVAL; }
+        return MEBT_OK;
+    }
     // P-side gradients are accumulated with atomics (LN affine, biases, embeddings): zero them first
     MEBT_HIP_CHECK(hipMemsetAsync(m->gP, 0, (size_t)m->n_p * 4, st));
     for (int i = 0; i < m->d.n_layer; ++i)
@@ -682,7 +734,7 @@ static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd, bool with_col
     if (with_colsum) RC(launch_colsum_grouped(lv.c, dt, sd));
     for (int i = 0; i < lv.w.n; ++i) {      // empty reductions (NC = 0): the gradient is zero
         const GroupedWgrad::Item& it = lv.w.g[i];
-        if (it.K <= 0 && it.M > 0 && it.N > 0) MEBT_HIP_CHECK(hipMemset2DAsync(it.C, (size_t)it.ldc * 4, 0, (size_t)it.N * 4, it.M, sd));
+        if (it.K <= 0 && it.M > 0 && it.N > 0 && !m->grad_acc) MEBT_HIP_CHECK(hipMemset2DAsync(it.C, (size_t)it.ldc * 4, 0, (size_t)it.N * 4, it.M, sd));
     }
     if (dt == MEBT_BF16) {
         ProfRec r;
@@ -698,6 +750,8 @@ static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd, bool with_col
             }
             (void)hipEventRecord(r.a, sd);
         }
+        lv.w.scratch = m->ctx.tune.flush ? &m->ctx.tune : nullptr;
+        lv.w.beta = m->grad_acc ? 1 : 0;
         if (m->fused_on) {
             lv.w.fused = 1; lv.w.W = m->W; lv.w.gW = m->gW; lv.w.mW = m->fused_mW; lv.w.vW = m->fused_vW; lv.w.Wlp = m->Wlp;
             lv.w.opt = m->fused_h;
@@ -714,7 +768,7 @@ static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd, bool with_col
         const GroupedWgrad::Item& it = lv.w.g[i];
         if (it.K > 0) {
             GemmParams p = gp(it.A, it.B, it.C, it.M, it.N, it.K, it.lda, it.ldb, it.ldc, 0, 0);
-            p.c_f32 = 1;
+            p.c_f32 = 1; p.beta = m->grad_acc ? 1 : 0;
             RC(gemm(m, p, sd));
         }
         // fp32 parity mode has no fused epilogue: same semantics with the streaming kernel on this weight
@@ -729,16 +783,24 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     const LayerOffsets& o = m->lo[i];
     const int mode = m->d.modes[i], d = m->d.n_embd, dt = m->d.dtype, B = x.B, NS = m->d.n_latent, NT = x.NT, H = m->d.n_head;
     const int Mq = B * a.NQ, Mk = B * a.NK;
-    const bool isdec = mode == MEBT_MODE_LATENT_DEC;
-    if (isdec ? !x.gT_defined : !x.gS_defined) return MEBT_OK;   // the loss does not depend on this block
+    const bool isdec = mode == MEBT_MODE_LATENT_DEC, ismg = mode == MEBT_MODE_MASKGIT;
+    if (ismg ? !(x.gT_defined || x.gC_defined) : isdec ? !x.gT_defined : !x.gS_defined) return MEBT_OK;   // the loss does not depend on this block
     const bool side = m->use_side;
     hipStream_t sd = side ? m->side : st;          // leaves (dW, db, dLN-affine) go here
     FwdCtx::Scratch& sc = x.sc[i & 1];
     if (side) MEBT_HIP_CHECK(hipStreamWaitEvent(st, m->ev_layer[i & 1], 0));   // side readers of this scratch set (layer i+2) are done
     const void* dout = isdec ? x.g_T : x.g_S;
-    const float p_res = x.drop_on ? m->d.resid_pdrop : 0.f, p_att = x.drop_on ? m->d.attn_pdrop : 0.f;
     const int f32 = dt == MEBT_F32;
     const size_t esz = m->esz();
+    if (ismg) {      // the block output spans both streams: dout = cat[g_C (fp32 accumulator), g_T]
+        const int NC = x.NC;
+        if (x.gC_defined) RC(launch_copy_rows(x.g_C, x.g_cat, (long)B * NC, d, 1, f32, 0, 0, 0, NC, NC + NT, 0, st));
+        else if (NC > 0) MEBT_HIP_CHECK(hipMemset2DAsync(x.g_cat, (size_t)(NC + NT) * d * esz, 0, (size_t)NC * d * esz, B, st));
+        if (x.gT_defined) RC(launch_copy_rows(x.g_T, x.g_cat, (long)B * NT, d, f32, f32, 0, 0, 0, NT, NC + NT, NC, st));
+        else MEBT_HIP_CHECK(hipMemset2DAsync((char*)x.g_cat + (size_t)NC * d * esz, (size_t)(NC + NT) * d * esz, 0, (size_t)NT * d * esz, B, st));
+        dout = x.g_cat;
+    }
+    const float p_res = x.drop_on ? m->d.resid_pdrop : 0.f, p_att = x.drop_on ? m->d.attn_pdrop : 0.f;
     Leaves lv;
     // out = x + dropout(u W2^T + b2): the branch gradient is dout * mask (the mask is recomputed, never
     // stored).  It is materialised in scratch either way: the leaves read it after this block's LN1
@@ -778,7 +840,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     ap.ldq = a.ldqkv_q; ap.ldk = a.ldqkv_k; ap.ldv = a.ldqkv_k; ap.ldo = d;
     ap.d_o = x.datt; ap.lddo = d; ap.delta = x.delta;
     ap.drop = make_drop(x.drop_seed, 16 * i + SITE_ATTN, p_att);
-    if (mode == MEBT_MODE_LATENT_SELF) {
+    if (mode == MEBT_MODE_LATENT_SELF || ismg) {
         ap.dq = sc.dqkv_q; ap.dk = (char*)sc.dqkv_q + (size_t)d * esz; ap.dv = (char*)sc.dqkv_q + (size_t)2 * d * esz;
         ap.lddq = ap.lddk = ap.lddv = 3 * d;
     } else {
@@ -796,13 +858,20 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         p.dx = dxp; p.dx_f32 = dx_f32 || f32; p.dx_accumulate = acc; p.dgamma = m->gP + o.ln1w; p.dbeta = m->gP + o.ln1b;
         p.rows = rows; p.d = d; p.seg = seg; p.seg_stride = seg_stride; p.seg_off = seg_off;
     };
-    if (mode == MEBT_MODE_LATENT_SELF) {
+    if (mode == MEBT_MODE_LATENT_SELF || ismg) {
         lv.colsum(sc.dqkv_q, Mq, 3 * d, 3 * d, m->gP + o.bq);
         lv.wgrad(sc.dqkv_q, 3 * d, a.qn, d, m->gW + o.wq, 3 * d, d, Mq);
         RC(dgrad(m, sc.dqkv_q, 3 * d, o.wq, sc.dqn, Mq, 3 * d, d, EPI_RESID, sc.dx, d, st));   // + dx (residual on qn)
         if (side) RC(fork_side(m, st));
         RC(flush_leaves(m, lv, sd));
-        ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0);
+        if (ismg) {      // LN1 rows [0,NC) of each sample came from the contexts stream, the rest from the targets stream
+            const int NC = x.NC;
+            ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_C, 1, 0, B * NC, NC, NC + NT, 0);
+            ln1(a.k_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_T, 0, 0, B * NT, NT, NC + NT, NC);
+            x.gC_defined = NC > 0; x.gT_defined = true;
+        } else {
+            ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0);
+        }
     } else {
         lv.colsum(sc.dqkv_q, Mq, d, d, m->gP + o.bq);
         lv.wgrad(sc.dqkv_q, d, a.qn, d, m->gW + o.wq, d, d, Mq);
@@ -819,7 +888,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         if (mode == MEBT_MODE_LATENT_ENC) {
             ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0);
             if (Mk > 0) {   // contexts feed every latent_enc block: accumulate in fp32
-                ln1(x.ctx, sc.dkn, nullptr, a.mean1k, a.rstd1k, x.g_C, 1, x.gC_defined ? 1 : 0, Mk, 0, 0, 0);
+                ln1(a.k_in, sc.dkn, nullptr, a.mean1k, a.rstd1k, x.g_C, 1, x.gC_defined ? 1 : 0, Mk, 0, 0, 0);
                 x.gC_defined = true;
             }
         } else if (mode == MEBT_MODE_LATENT_DEC) {
@@ -836,7 +905,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     // (its MLP branch gradient, dout * mask): one elementwise launch less per block.  Not with the side stream: the
     // leaves of block i+1 may still be reading the other scratch set's dout_m.
     static const int fuse_doutm = [] { const char* e = getenv("MEBT_FUSE_DOUTM"); return e ? atoi(e) : 1; }();
-    if (i > 0 && !side && p_res > 0.f && fuse_doutm) {
+    if (i > 0 && !side && p_res > 0.f && fuse_doutm && m->d.modes[i - 1] != MEBT_MODE_MASKGIT) {
         const bool below_dec = m->d.modes[i - 1] == MEBT_MODE_LATENT_DEC;
         const void* want = below_dec ? x.g_T : x.g_S;
         int k = -1;
@@ -855,21 +924,54 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
 extern "C" int mebt_backward_layers(mebt_model* m, void* ws, int32_t layer_hi, int32_t layer_lo, mebt_stream_t stream) {
     if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("backward: no training-mode forward on this workspace"); return MEBT_EINVAL; }
     if (layer_hi >= m->d.n_layer || layer_lo < 0 || layer_lo > layer_hi) { mebt_set_error("backward_layers: bad layer range"); return MEBT_EINVAL; }
+    if (m->ctx.last_bwd_lo != layer_hi + 1) m->ctx.doutm_ready = -1;     // not the block right below the previous call's range
     for (int i = layer_hi; i >= layer_lo; --i) RC(backward_layer(m, i, S(stream)));
+    m->ctx.last_bwd_lo = layer_lo;
     return join_side(m, S(stream));          // the caller may all-reduce these gradients next
+}
+
+// embd dropout (gpt.py:238-240) on the stream gradients that reached the network inputs
+static int input_grad_dropout(mebt_model* m, hipStream_t st);
+
+// Backward of GPT.forward (gpt.py:234-253) from dL/dlogits: parameter gradients of the blocks / ln_f / head into gW, gP and
+// the gradients with respect to the three embedded inputs (fp32, like the inputs; NULL = not wanted).
+extern "C" int mebt_gpt_backward(mebt_model* m, void* ws, const float* dlogits, float* d_sos, float* d_contexts, float* d_targets,
+                                 mebt_stream_t stream) {
+    RC(mebt_backward_head_dlogits(m, ws, dlogits, stream));
+    RC(mebt_backward_layers(m, ws, m->d.n_layer - 1, 0, stream));
+    FwdCtx& x = m->ctx;
+    hipStream_t st = S(stream);
+    RC(input_grad_dropout(m, st));
+    const int d = m->d.n_embd, f32 = m->d.dtype == MEBT_F32;
+    struct { float* dst; const void* src; bool defined; long rows; int src_f32; } o[3] = {
+        {d_sos, x.g_S, x.gS_defined, (long)x.B * m->d.n_latent, f32}, {d_contexts, x.g_C, x.gC_defined, (long)x.B * x.NC, 1},
+        {d_targets, x.g_T, x.gT_defined, (long)x.B * x.NT, f32}};
+    for (auto& t : o) {
+        if (!t.dst || t.rows <= 0) continue;
+        if (t.defined) RC(launch_copy_rows(t.src, t.dst, t.rows, d, t.src_f32, 1, 0, 0, 0, 0, 0, 0, st));
+        else MEBT_HIP_CHECK(hipMemsetAsync(t.dst, 0, (size_t)t.rows * d * 4, st));      // the logits do not depend on this input
+    }
+    return MEBT_OK;
+}
+
+static int input_grad_dropout(mebt_model* m, hipStream_t st) {
+    FwdCtx& x = m->ctx;
+    if (x.drop_on && m->d.embd_pdrop > 0.f) {
+        const int f32 = m->d.dtype == MEBT_F32;
+        const size_t dd = m->d.n_embd;
+        const float pe = m->d.embd_pdrop;
+        if (x.gS_defined) RC(launch_apply_dropout(x.g_S, x.g_S, (size_t)x.B * m->d.n_latent * dd, f32, f32, make_drop(x.drop_seed, SITE_EMB_SOS, pe), st));
+        if (x.gT_defined) RC(launch_apply_dropout(x.g_T, x.g_T, (size_t)x.B * x.NT * dd, f32, f32, make_drop(x.drop_seed, SITE_EMB_TGT, pe), st));
+        if (x.gC_defined) RC(launch_apply_dropout(x.g_C, x.g_C, (size_t)x.B * x.NC * dd, 1, 1, make_drop(x.drop_seed, SITE_EMB_CTX, pe), st));
+    }
+    return MEBT_OK;
 }
 
 extern "C" int mebt_backward_embed(mebt_model* m, void* ws, mebt_stream_t stream) {
     if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("backward: no training-mode forward on this workspace"); return MEBT_EINVAL; }
     FwdCtx& x = m->ctx;
-    if (x.drop_on && m->d.embd_pdrop > 0.f) {   // embd dropout (gpt.py:238-240): gradients pass through the same masks
-        const int f32 = m->d.dtype == MEBT_F32;
-        const size_t dd = m->d.n_embd;
-        const float pe = m->d.embd_pdrop;
-        if (x.gS_defined) RC(launch_apply_dropout(x.g_S, x.g_S, (size_t)x.B * m->d.n_latent * dd, f32, f32, make_drop(x.drop_seed, SITE_EMB_SOS, pe), S(stream)));
-        if (x.gT_defined) RC(launch_apply_dropout(x.g_T, x.g_T, (size_t)x.B * x.NT * dd, f32, f32, make_drop(x.drop_seed, SITE_EMB_TGT, pe), S(stream)));
-        if (x.gC_defined) RC(launch_apply_dropout(x.g_C, x.g_C, (size_t)x.B * x.NC * dd, 1, 1, make_drop(x.drop_seed, SITE_EMB_CTX, pe), S(stream)));
-    }
+    if (!x.x_ids) { mebt_set_error("backward_embed: the last forward ran on caller-embedded inputs: use mebt_gpt_backward"); return MEBT_EINVAL; }
+    RC(input_grad_dropout(m, S(stream)));
     EmbedBwdParams p;
     p.x_ids = x.x_ids; p.ci = x.ci; p.ti = x.ti;
     p.g_ctx = x.g_C; p.g_tgt = x.g_T; p.g_sos = x.g_S;
@@ -922,6 +1024,15 @@ extern "C" int mebt_adamw_range(mebt_model* m, float* mW, float* vW, float* mP, 
         const int64_t tail_n = (m->tok_live ? m->n_p : m->tok_emb) - m->lnf_w;
         RC(run(m->P, m->gP, mP, vP, nullptr, m->lnf_w, tail_n, 0.f));
     }
+    return MEBT_OK;
+}
+
+// Gradient accumulation over micro-batches (reference train_transformer.py:46-49, Lightning accumulate_grad_batches):
+// on = 1 makes the following backward ADD its gradients to gW / gP (fp32 C += in the weight-gradient epilogues, no
+// zero-fill of the atomically accumulated P side); on = 0 (default) overwrites.
+extern "C" int mebt_model_set_grad_accumulate(mebt_model* m, int32_t on) {
+    if (!m) { mebt_set_error("set_grad_accumulate: null model"); return MEBT_EINVAL; }
+    m->grad_acc = on != 0;
     return MEBT_OK;
 }
 

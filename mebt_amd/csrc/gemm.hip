@@ -4,7 +4,9 @@
 #include "gemm_kernels.h"
 #include <cstdio>
 #include <cstdlib>
-#include <unordered_map>
+#include <map>
+#include <mutex>
+#include <vector>
 
 void mebt_gemm_cfg_kk(const GemmParams&, int, int, int, int, hipStream_t);
 void mebt_gemm_cfg_kr(const GemmParams&, int, int, int, int, hipStream_t);
@@ -53,8 +55,15 @@ extern "C" void mebt_debug_gemm_tile(int bm, int bn) { g_gemm_force_tile = (bm &
 // 2..5 = LDS-DMA ring with that many stages (clamped to what the tile's LDS footprint admits)
 // scratch for split-K partials (library-owned, grown on demand; launches that use it are ordered on ONE stream: the
 // autotuner only offers split configurations for bf16-output products, i.e. the forward / dgrad chain)
-static float* g_sk_buf = nullptr;
-static size_t g_sk_bytes = 0;
+// Scratch of the tuner and of the split-K variant.  Caller-owned (the engine carves it out of the workspace PyTorch
+// allocated, `GemmParams::scratch`); operator-level callers without one get the heuristic configuration, or the
+// process-wide buffer a benchmark tool installed through mebt_debug_gemm_scratch().
+static GemmScratch g_default_scratch = {nullptr, 0, nullptr, 0};
+static const GemmScratch* scratch_of(const GemmScratch* s) { return (s && s->flush) ? s : (g_default_scratch.flush ? &g_default_scratch : nullptr); }
+extern "C" void mebt_debug_gemm_scratch(void* buf, int64_t bytes) {
+    if (!buf || bytes < (int64_t)(MEBT_TUNE_FLUSH_BYTES + MEBT_TUNE_SPLITK_BYTES)) { g_default_scratch = {nullptr, 0, nullptr, 0}; return; }
+    g_default_scratch = {buf, MEBT_TUNE_FLUSH_BYTES, (float*)((char*)buf + MEBT_TUNE_FLUSH_BYTES), (size_t)bytes - MEBT_TUNE_FLUSH_BYTES};
+}
 static void launch_bf16_config(const GemmParams& p, int tbm, int tbn, int staging, int split, hipStream_t stream) {
     if (tbm == 256 && tbn == 256) {   // the 8-wave tile: whole reduction in the workgroup, ring 2
         if (p.a_kc && p.b_kc) mebt_gemm_w8_kk(p, 2, stream);
@@ -72,13 +81,14 @@ static void launch_bf16_config(const GemmParams& p, int tbm, int tbn, int stagin
     else if (!p.a_kc && !p.b_kc) mebt_gemm_cfg_rr(p, tbm, tbn, staging, split, stream);
     else mebt_gemm_cfg_rk(p, tbm, tbn, staging, split, stream);
 }
+static bool splitk_fits(const GemmParams& p, int S) {
+    const GemmScratch* sc = scratch_of(p.scratch);
+    return sc && sc->splitk && (size_t)S * p.M * p.N * 4 <= sc->splitk_bytes;
+}
 static int launch_bf16_splitk(const GemmParams& p, int tbm, int tbn, int ring, int S, hipStream_t stream) {
-    const size_t need = (size_t)S * p.M * p.N * 4;
-    if (need > g_sk_bytes) {
-        if (g_sk_buf) { MEBT_HIP_CHECK(hipStreamSynchronize(stream)); MEBT_HIP_CHECK(hipFree(g_sk_buf)); g_sk_buf = nullptr; g_sk_bytes = 0; }
-        MEBT_HIP_CHECK(hipMalloc(&g_sk_buf, need));
-        g_sk_bytes = need;
-    }
+    const GemmScratch* sc = scratch_of(p.scratch);
+    if (!splitk_fits(p, S)) { mebt_set_error("gemm: split-K scratch missing or too small"); return MEBT_EWORKSPACE; }
+    float* g_sk_buf = sc->splitk;
     GemmParams q = p;
     q.C = g_sk_buf; q.C2 = nullptr; q.c_f32 = 1; q.ldc = p.N; q.epilogue = EPI_NONE; q.bias = nullptr; q.aux = nullptr; q.beta = 0;
     q.drop.thresh = 0; q.slab = (long)p.M * p.N;
@@ -102,17 +112,16 @@ static int launch_bf16_splitk(const GemmParams& p, int tbm, int tbn, int ring, i
 // launches are tuned (no beta accumulation, no split-K atomics).  MEBT_GEMM_AUTOTUNE=0 disables it
 // (heuristic below), MEBT_GEMM_TUNE_LOG=1 prints the choices.
 // ------------------------------------------------------------------------------------------------
-struct TuneKey {
-    int M, N, K, flags;
-    bool operator==(const TuneKey& o) const { return M == o.M && N == o.N && K == o.K && flags == o.flags; }
-};
-struct TuneHash {
-    size_t operator()(const TuneKey& k) const {
-        uint64_t h = (uint64_t)k.M * 0x9E3779B97F4A7C15ull ^ ((uint64_t)k.N << 21) ^ ((uint64_t)k.K << 42) ^ (uint64_t)k.flags * 0xC2B2AE3D27D4EB4Full;
-        return (size_t)(h ^ (h >> 29));
-    }
-};
-static std::unordered_map<TuneKey, int, TuneHash> g_tuned;      // -> (tbm << 20) | (tbn << 8) | staging
+// A signature = {kind | flags, then (M, N, K) of every product of the launch} with the real dimensions (no hashing:
+// two different shape sets never share an entry).  The token-count dimensions (M of forward / dgrad, K of the weight
+// gradients) are bucketed to multiples of 128: in real training t ~ U(0,1) makes NC / NT differ at almost every step,
+// and an exact key would tune ~20 new signatures per step forever; bucketed, a config has 48 buckets per token count
+// (weight dimensions are multiples of 128 and unaffected).  The table is process-wide (a pure shape -> configuration
+// cache) and guarded by a mutex; tuning itself runs under the same lock with the CALLER's scratch and events of its own.
+typedef std::vector<int> TuneKey;
+static int tune_bucket(int v) { return v <= 128 ? v : ((v + 127) / 128) * 128; }
+static std::map<TuneKey, int> g_tuned;      // -> (tbm << 20) | (tbn << 8) | staging
+static std::mutex g_tune_mutex;
 static int g_autotune = -1, g_tune_log = 0;
 static const char* g_tune_cache = nullptr;                       // MEBT_GEMM_TUNE_CACHE: text file of tuned choices
 
@@ -126,9 +135,16 @@ static void tune_init() {
     g_tune_log = l ? atoi(l) : 0;                     // 1: decisions, 2: every candidate
     g_tune_cache = getenv("MEBT_GEMM_TUNE_CACHE");
     if (g_tune_cache && g_tune_cache[0]) {
-        if (FILE* f = fopen(g_tune_cache, "r")) {
-            TuneKey k; int v;
-            while (fscanf(f, "%d %d %d %d %d", &k.M, &k.N, &k.K, &k.flags, &v) == 5) g_tuned[k] = v;
+        if (FILE* f = fopen(g_tune_cache, "r")) {      // one entry per line: n k_0 ... k_{n-1} value
+            int n;
+            while (fscanf(f, "%d", &n) == 1 && n > 0 && n < 64) {
+                TuneKey k(n);
+                bool ok = true;
+                for (int i = 0; i < n; ++i) ok = ok && fscanf(f, "%d", &k[i]) == 1;
+                int v;
+                if (!ok || fscanf(f, "%d", &v) != 1) break;
+                g_tuned[k] = v;
+            }
             fclose(f);
         }
     } else {
@@ -137,8 +153,16 @@ static void tune_init() {
 }
 static void tune_remember(const TuneKey& k, int v) {
     if (!g_tune_cache) return;
-    if (FILE* f = fopen(g_tune_cache, "a")) { fprintf(f, "%d %d %d %d %d\n", k.M, k.N, k.K, k.flags, v); fclose(f); }
+    if (FILE* f = fopen(g_tune_cache, "a")) {
+        fprintf(f, "%d", (int)k.size());
+        for (int x : k) fprintf(f, " %d", x);
+        fprintf(f, " %d\n", v);
+        fclose(f);
+    }
 }
+// 0: never tune (heuristic / cached choices only; every entry point is then free of host synchronisation and
+// capture-safe), 1: tune unseen signatures at their first launch.  Default: MEBT_GEMM_AUTOTUNE (1).
+extern "C" void mebt_gemm_autotune(int32_t mode) { std::lock_guard<std::mutex> lk(g_tune_mutex); tune_init(); g_autotune = mode ? 1 : 0; }
 
 static void heuristic_config(const GemmParams& p, int& tbm, int& tbn, int& staging) {
     // cold-operand measurements (profiles/r01_gemm_variants_cold.txt), all three layouts alike:
@@ -154,18 +178,24 @@ static void heuristic_config(const GemmParams& p, int& tbm, int& tbn, int& stagi
 // Candidates are timed with COLD caches: in the train step the weights (676 MB in bf16) never survive in the
 // 256 MB Infinity Cache from one use to the next, and a warm-cache timing favours shallow rings.  Before every
 // timed launch a 384 MB scratch buffer is overwritten (L2 and Infinity Cache hold nothing of the operands).
-static void* g_flush = nullptr;
-static constexpr size_t FLUSH_BYTES = 384ull << 20;
-static int tune_begin() {
-    if (!g_flush) MEBT_HIP_CHECK(hipMalloc(&g_flush, FLUSH_BYTES));
-    return MEBT_OK;
-}
+struct TuneRun {        // one tuning session: the caller's flush buffer + two events of its own
+    const GemmScratch* sc = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int begin(const GemmScratch* s) {
+        sc = s;
+        MEBT_HIP_CHECK(hipEventCreate(&e0));
+        MEBT_HIP_CHECK(hipEventCreate(&e1));
+        return MEBT_OK;
+    }
+    ~TuneRun() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
 template <typename F>
-static int time_cold(F&& launch, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, float& best_ms) {
+static int time_cold(F&& launch, hipStream_t stream, const TuneRun& tr, float& best_ms) {
     float tot = 0.f;
+    hipEvent_t e0 = tr.e0, e1 = tr.e1;
     launch();                                                                    // code object, TLBs
     for (int r = 0; r < 2; ++r) {
-        MEBT_HIP_CHECK(hipMemsetAsync(g_flush, r, FLUSH_BYTES, stream));
+        MEBT_HIP_CHECK(hipMemsetAsync(tr.sc->flush, r, tr.sc->flush_bytes, stream));
         MEBT_HIP_CHECK(hipEventRecord(e0, stream));
         launch();
         MEBT_HIP_CHECK(hipEventRecord(e1, stream));
@@ -179,9 +209,8 @@ static int time_cold(F&& launch, hipStream_t stream, hipEvent_t e0, hipEvent_t e
 }
 
 static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, int& tbn, int& staging) {
-    static hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (!e0) { MEBT_HIP_CHECK(hipEventCreate(&e0)); MEBT_HIP_CHECK(hipEventCreate(&e1)); }
-    if (int rc = tune_begin()) return rc;
+    TuneRun tr;
+    if (int rc = tr.begin(scratch_of(p.scratch))) return rc;
     static const int tiles[7][2] = {{192, 128}, {128, 128}, {96, 128}, {128, 64}, {64, 128}, {96, 64}, {64, 64}};
     const long out = (long)p.M * p.N;
     float best = 1e30f;
@@ -192,18 +221,18 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
         for (int st = 2; st <= 4 && !few; ++st) {
             if (st * (bm + bn) * BK * 2 > 128 * 1024) continue;
             float ms = 0.f;
-            if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, st, 1, stream); }, stream, e0, e1, ms)) return rc;
+            if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, st, 1, stream); }, stream, tr, ms)) return rc;
             if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d: %.1f us\n", bm, bn, st, ms * 1e3f);
             if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = st; }
         }
         if (!p.c_f32 && p.C && nt <= 256 && (long)bm * bn >= 128 * 128)          // split-K into fp32 slabs + reduce/epilogue kernel (staging 32 * log2(S) + ring)
             for (int S = 2; S <= 4; S *= 2) {
-                if (p.K % (S * BK) || p.K / S < 8 * BK) continue;
+                if (p.K % (S * BK) || p.K / S < 8 * BK || !splitk_fits(p, S)) continue;
                 for (int st = 2; st <= 3; ++st) {
                     if (st * (bm + bn) * BK * 2 > 128 * 1024) continue;
                     float ms = 0.f;
                     int rc2 = MEBT_OK;
-                    if (int rc = time_cold([&] { rc2 |= launch_bf16_splitk(p, bm, bn, st, S, stream); }, stream, e0, e1, ms)) return rc;
+                    if (int rc = time_cold([&] { rc2 |= launch_bf16_splitk(p, bm, bn, st, S, stream); }, stream, tr, ms)) return rc;
                     if (rc2) return rc2;
                     if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d split-K %d: %.1f us\n", bm, bn, st, S, ms * 1e3f);
                     if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = (S == 2 ? 32 : 64) + st; }
@@ -213,14 +242,14 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
             for (int st = 2; st <= 3; ++st) {
                 if (!ks2_lds(bm, bn, st)) continue;
                 float ms = 0.f;
-                if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, 16 + st, 1, stream); }, stream, e0, e1, ms)) return rc;
+                if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, 16 + st, 1, stream); }, stream, tr, ms)) return rc;
                 if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d x2 pipelines: %.1f us\n", bm, bn, st, ms * 1e3f);
                 if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = 16 + st; }
             }
     }
     if ((long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 96 && (p.a_kc ? p.K % BK == 0 : true)) {   // 8-wave 256 x 256 tile
         float ms = 0.f;
-        if (int rc = time_cold([&] { launch_bf16_config(p, 256, 256, 2, 1, stream); }, stream, e0, e1, ms)) return rc;
+        if (int rc = time_cold([&] { launch_bf16_config(p, 256, 256, 2, 1, stream); }, stream, tr, ms)) return rc;
         if (g_tune_log >= 2) fprintf(stderr, "    cand 256x256 (8 waves): %.1f us\n", ms * 1e3f);
         if (ms < best) { best = ms; tbm = 256; tbn = 256; staging = 2; }
     }
@@ -255,28 +284,36 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         MEBT_HIP_CHECK(hipMemset2DAsync(p.C, (size_t)p.ldc * 4, 0, (size_t)p.N * 4, p.M, stream));
     }
     if (dtype == MEBT_BF16) {
-        tune_init();
         int tbm = 128, tbn = 128, staging = 2;
         const bool forced = g_gemm_force_tile || g_gemm_dma >= 0;
-        const bool idempotent = !p.beta && split == 1 && p.C != p.aux;
-        if (g_autotune && !forced && idempotent && (long)p.M * p.N >= 128 * 128) {
-            const TuneKey key{p.M, p.N, p.K, p.a_kc | (p.b_kc << 1) | (p.epilogue << 2) | (p.c_f32 << 5) | ((p.bias != nullptr) << 6) | ((p.drop.thresh != 0) << 7)};
+        const bool idempotent = !p.beta && split == 1 && p.C != p.aux;     // only such launches can be repeated to time them
+        bool have = false;
+        if (!forced && split == 1 && (long)p.M * p.N >= 128 * 128) {
+            std::lock_guard<std::mutex> lk(g_tune_mutex);
+            tune_init();
+            const TuneKey key{p.a_kc | (p.b_kc << 1) | (p.epilogue << 2) | (p.c_f32 << 5) | ((p.bias != nullptr) << 6) | ((p.drop.thresh != 0) << 7),
+                              tune_bucket(p.M), p.N, tune_bucket(p.K)};
             auto it = g_tuned.find(key);
-            if (it == g_tuned.end()) {
+            if (it == g_tuned.end() && g_autotune && idempotent && scratch_of(p.scratch)) {
                 heuristic_config(p, tbm, tbn, staging);
                 if (int rc = autotune_config(p, stream, tbm, tbn, staging)) return rc;
                 it = g_tuned.emplace(key, (tbm << 20) | (tbn << 8) | staging).first;
                 tune_remember(key, it->second);
             }
-            tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; staging = it->second & 255;
-        } else {
+            if (it != g_tuned.end()) {
+                tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; staging = it->second & 255;
+                have = true;
+                if ((staging >= 16 && staging < 32 && p.K % (2 * BK)) || (tbm == 256 && p.a_kc && p.K % BK)) have = false;   // a bucket neighbour's variant that this K cannot run
+            }
+        }
+        if (!have) {
             heuristic_config(p, tbm, tbn, staging);
             if (g_gemm_force_tile) { tbm = g_gemm_force_tile >> 12; tbn = g_gemm_force_tile & 0xFFF; }
             if (g_gemm_dma >= 0) staging = g_gemm_dma == 1 ? 3 : g_gemm_dma;       // forced: 0 reg, 2..5 LDS-DMA stages (1 = 3)
         }
         if (staging >= 32) {
             const int S = staging >= 64 ? 4 : 2;
-            if (!p.c_f32 && p.C && split == 1 && p.K % (S * BK) == 0 && !p.beta) { if (int rc = launch_bf16_splitk(p, tbm, tbn, staging & 15, S, stream)) return rc; }
+            if (!p.c_f32 && p.C && split == 1 && p.K % (S * BK) == 0 && !p.beta && splitk_fits(p, S)) { if (int rc = launch_bf16_splitk(p, tbm, tbn, staging & 15, S, stream)) return rc; }
             else launch_bf16_config(p, tbm, tbn, staging & 15, split, stream);
         } else {
             launch_bf16_config(p, tbm, tbn, staging, split, stream);
@@ -305,43 +342,47 @@ int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipS
         if (int rc = launch_gemm(p0, dtype, stream)) return rc;
         return launch_gemm(p1, dtype, stream);
     }
-    tune_init();
     GemmPair g;
     g.p[0] = p0; g.p[1] = p1;
     int tbm = 96, tbn = 128, staging = 3;
-    if (g_autotune) {
-        const TuneKey key{p0.M * 131 + p1.M, p0.N * 131 + p1.N, p0.K * 131 + p1.K,
-                          0x20000000 | p0.b_kc | (p0.epilogue << 2) | (p1.epilogue << 5) | ((p0.drop.thresh != 0) << 8)};
+    int choice = -1;
+    {
+        std::unique_lock<std::mutex> lk(g_tune_mutex);
+        tune_init();
+        const TuneKey key{0x20000000 | p0.b_kc | (p0.epilogue << 2) | (p1.epilogue << 5) | ((p0.drop.thresh != 0) << 8),
+                          tune_bucket(p0.M), p0.N, tune_bucket(p0.K), tune_bucket(p1.M), p1.N, tune_bucket(p1.K)};
         auto it = g_tuned.find(key);
-        if (it == g_tuned.end()) {
-            static hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (!e0) { MEBT_HIP_CHECK(hipEventCreate(&e0)); MEBT_HIP_CHECK(hipEventCreate(&e1)); }
-            if (int rc = tune_begin()) return rc;
+        if (it == g_tuned.end() && g_autotune && scratch_of(p0.scratch)) {
+            TuneRun tr;
+            if (int rc = tr.begin(scratch_of(p0.scratch))) return rc;
+            lk.unlock();            // the separate-launch baseline below goes through launch_gemm, which takes the lock itself
             static const int tiles[7][2] = {{192, 128}, {128, 128}, {96, 128}, {128, 64}, {64, 128}, {96, 64}, {64, 64}};
             float best = 1e30f;
             for (int t = 0; t < 7; ++t)
                 for (int st = 2; st <= 4; ++st) {
                     if (st * (tiles[t][0] + tiles[t][1]) * BK * 2 > 128 * 1024) continue;
                     float ms = 0.f;
-                    if (int rc = time_cold([&] { launch_pair_config(g, tiles[t][0], tiles[t][1], st, stream); }, stream, e0, e1, ms)) return rc;
+                    if (int rc = time_cold([&] { launch_pair_config(g, tiles[t][0], tiles[t][1], st, stream); }, stream, tr, ms)) return rc;
                     if (ms < best) { best = ms; tbm = tiles[t][0]; tbn = tiles[t][1]; staging = st; }
                 }
             // ... against the two products launched one after the other with their own tuned configurations
             float sep = 0.f;
-            if (int rc = time_cold([&] { launch_gemm(p0, MEBT_BF16, stream); launch_gemm(p1, MEBT_BF16, stream); }, stream, e0, e1, sep)) return rc;
-            if (int rc = time_cold([&] { launch_gemm(p0, MEBT_BF16, stream); launch_gemm(p1, MEBT_BF16, stream); }, stream, e0, e1, sep)) return rc;
+            if (int rc = time_cold([&] { launch_gemm(p0, MEBT_BF16, stream); launch_gemm(p1, MEBT_BF16, stream); }, stream, tr, sep)) return rc;
+            if (int rc = time_cold([&] { launch_gemm(p0, MEBT_BF16, stream); launch_gemm(p1, MEBT_BF16, stream); }, stream, tr, sep)) return rc;
             if (g_tune_log)
                 fprintf(stderr, "[mebt gemm autotune] pair %dx%dx%d + %dx%dx%d b_kc=%d -> %dx%d ring %d (%.1f us cold; separate launches %.1f us)\n",
                         p0.M, p0.N, p0.K, p1.M, p1.N, p1.K, p0.b_kc, tbm, tbn, staging, best * 1e3f, sep * 1e3f);
+            lk.lock();
             it = g_tuned.emplace(key, sep <= best ? 0 : ((tbm << 20) | (tbn << 8) | staging)).first;
             tune_remember(key, it->second);
         }
-        if (it->second == 0) {       // the pair did not win on this shape
-            if (int rc = launch_gemm(p0, dtype, stream)) return rc;
-            return launch_gemm(p1, dtype, stream);
-        }
-        tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; staging = it->second & 255;
+        if (it != g_tuned.end()) choice = it->second;
     }
+    if (choice == 0) {           // the pair did not win on this shape
+        if (int rc = launch_gemm(p0, dtype, stream)) return rc;
+        return launch_gemm(p1, dtype, stream);
+    }
+    if (choice > 0) { tbm = choice >> 20; tbn = (choice >> 8) & 0xFFF; staging = choice & 255; }
     launch_pair_config(g, tbm, tbn, staging, stream);
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;
@@ -357,19 +398,20 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
     }
     c.n = n;
     if (!n) return MEBT_OK;
+    c.beta = w.beta; c.scratch = w.scratch;
     c.fused = w.fused; c.W = w.W; c.gW = w.gW; c.mW = w.mW; c.vW = w.vW; c.Wlp = w.Wlp; c.opt = w.opt;
     for (int i = 1; i < n; ++i)              // insertion sort, K descending
         for (int j = i; j > 0 && c.g[j].K > c.g[j - 1].K; --j) { const GroupedWgrad::Item t = c.g[j]; c.g[j] = c.g[j - 1]; c.g[j - 1] = t; }
-    tune_init();
     int tbm = 128, tbn = 128, stages = g_grouped_stages == 3 ? 3 : 2;
-    if (g_autotune) {
-        TuneKey key{0, 0, 0, 0x40000000 | n | (c.fused ? 0x100 : 0)};
-        for (int i = 0; i < n; ++i) { key.M = key.M * 31 + c.g[i].M; key.N = key.N * 31 + c.g[i].N; key.K = key.K * 31 + c.g[i].K; }
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mutex);
+        tune_init();
+        TuneKey key{0x40000000 | n | (c.fused ? 0x100 : 0) | (c.beta ? 0x200 : 0)};
+        for (int i = 0; i < n; ++i) { key.push_back(c.g[i].M); key.push_back(c.g[i].N); key.push_back(tune_bucket(c.g[i].K)); }
         auto it = g_tuned.find(key);
-        if (it == g_tuned.end()) {
-            static hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (!e0) { MEBT_HIP_CHECK(hipEventCreate(&e0)); MEBT_HIP_CHECK(hipEventCreate(&e1)); }
-            if (int rc = tune_begin()) return rc;
+        if (it == g_tuned.end() && g_autotune && !c.beta && scratch_of(w.scratch)) {
+            TuneRun tr;
+            if (int rc = tr.begin(scratch_of(w.scratch))) return rc;
             static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
             float best = 1e30f;
             // candidates are timed in the mode that will run; a fused launch is not idempotent, so its candidates
@@ -379,7 +421,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
             for (int t = 0; t < 4; ++t)
                 for (int st = 2; st <= 4; ++st) {
                     float ms = 0.f;
-                    if (int rc = time_cold([&] { launch_grouped_config(tc, tiles[t][0], tiles[t][1], st, stream); }, stream, e0, e1, ms)) return rc;
+                    if (int rc = time_cold([&] { launch_grouped_config(tc, tiles[t][0], tiles[t][1], st, stream); }, stream, tr, ms)) return rc;
                     if (ms < best) { best = ms; tbm = tiles[t][0]; tbn = tiles[t][1]; stages = st; }
                 }
             if (g_tune_log) {
@@ -390,7 +432,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
             it = g_tuned.emplace(key, (tbm << 20) | (tbn << 8) | stages).first;
             tune_remember(key, it->second);
         }
-        tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; stages = it->second & 255;
+        if (it != g_tuned.end()) { tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; stages = it->second & 255; }
     }
     launch_grouped_config(c, tbm, tbn, stages, stream);
     MEBT_HIP_CHECK(hipGetLastError());

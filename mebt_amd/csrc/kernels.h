@@ -16,6 +16,11 @@ static inline DropCfg make_drop(uint64_t seed, uint32_t site, float p) {
 }
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_GELU_BWD = 3, EPI_ADAMW = 4 /* internal: grouped weight gradients only */ };
 
+// Caller-owned scratch of the GEMM autotuner (cache-flush buffer) and of the split-K variant (fp32 partial slabs).
+struct GemmScratch { void* flush; size_t flush_bytes; float* splitk; size_t splitk_bytes; };
+#define MEBT_TUNE_FLUSH_BYTES (384ull << 20)      // > L2 + Infinity Cache: candidates are timed on cold operands
+#define MEBT_TUNE_SPLITK_BYTES (112ull << 20)     // 4 slabs of the largest output split-K is offered for (256 tiles of 192 x 128)
+
 // C[M,N] = sum_k A(m,k) B(n,k) (+bias) (+epilogue).  *_kc = 1: operand stored [rows][K];
 // *_kc = 0: stored [K][rows].  ld* are element strides of the slow dimension.
 struct GemmParams {
@@ -37,6 +42,7 @@ struct GemmParams {
     // EPI_ADAMW: the result is a weight gradient; it is not stored, the parameter is updated in place
     float* opt_p = nullptr; float* opt_m = nullptr; float* opt_v = nullptr; void* opt_lp = nullptr;   // [M,ldc] like C
     AdamWHyper opt = {0, 0, 0, 0, 0, 1, 1, 1};
+    const GemmScratch* scratch = nullptr;   // host side only: where the tuner / split-K may put their scratch (null: heuristic, no split-K)
 };
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 // two independent products with the same operand layouts in ONE launch (query- and key-side projections of a
@@ -54,6 +60,8 @@ struct GroupedWgrad {
     int fused = 0;
     float* W = nullptr; float* gW = nullptr; float* mW = nullptr; float* vW = nullptr; void* Wlp = nullptr;
     AdamWHyper opt = {0, 0, 0, 0, 0, 1, 1, 1};
+    int beta = 0;                           // C += result (gradient accumulation over micro-batches); not with `fused`
+    const GemmScratch* scratch = nullptr;   // host side only, see GemmParams
 };
 int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream);   // fills tile_start / ntx
 struct GroupedColsum {
@@ -123,6 +131,11 @@ int launch_ln_bwd_multi(const LnBwdParams* jobs, int n, int dtype, hipStream_t s
 
 // dst[i] = src[i] * keep(site, i)  (dropout mask re-applied in backward); TS/TD chosen by flags
 int launch_apply_dropout(const void* src, void* dst, size_t n, int src_f32, int dst_f32, const DropCfg& d, hipStream_t stream);
+
+// dst[map_d(r)] = src[map_s(r)] for r < rows, rows of d elements, with element conversion; map(r) = (r / seg) * stride + off
+// + r % seg (seg = 0: identity).  Splits / concatenates the [contexts; targets] stream of a 'maskgit' block.
+int launch_copy_rows(const void* src, void* dst, long rows, int d, int src_f32, int dst_f32, int s_seg, int s_stride, int s_off,
+                     int d_seg, int d_stride, int d_off, hipStream_t stream);
 
 // out[n] += sum_m X[m,n]   (bias gradients, mask_emb / sos_emb gradients)
 int launch_colsum(const void* X, int M, int N, int ldx, float* out, int dtype, hipStream_t stream);

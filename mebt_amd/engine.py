@@ -53,9 +53,7 @@ class NativeModel:
             raise ValueError("too many layers")
         for i, m in enumerate(modes):
             if m not in _lib.MODE_IDS:
-                raise NotImplementedError(
-                    f"block mode {m!r} is not supported by the HIP engine (supported: {sorted(_lib.MODE_IDS)}); "
-                    "'maskgit' full attention (reference gpt.py:176-178) is unused by the shipped configs")
+                raise NotImplementedError(f"block mode {m!r} is not supported by the HIP engine (supported: {sorted(_lib.MODE_IDS)})")
             d.modes[i] = _lib.MODE_IDS[m]
         d.label_smoothing = float(label_smoothing)
         d.embd_pdrop, d.resid_pdrop, d.attn_pdrop = float(embd_pdrop), float(resid_pdrop), float(attn_pdrop)
@@ -77,6 +75,8 @@ class NativeModel:
         self.ws = None
         self.ws_key = None
         self._w_version = None
+        self.weight_params = []     # the nn.Parameters whose storage is a view of W (set by the module that owns them)
+        self.generation = 0         # bumped by every training-mode forward: a backward must match the forward it belongs to
         self.device = None
         self.adam = None
 
@@ -110,11 +110,13 @@ class NativeModel:
         check(self.lib.mebt_model_bind(self.h, ptr(self.W), ptr(self.Wlp), ptr(self.gW), ptr(self.P), ptr(self.gP)))
 
     def sync_lowp(self, force=False):
-        """Refresh the bf16 weight mirror if the fp32 master was modified through torch (in-place
-        ops bump the version counter of the flat buffer; our own AdamW kernel updates both)."""
+        """Refresh the bf16 weight mirror if the fp32 master was modified through torch.  In-place ops bump the version
+        counter of the tensor they are applied to: the flat buffer itself, or one of the nn.Parameters that view it
+        (`load_state_dict`, `p.mul_()`, a stock torch optimizer) — each Parameter has its own counter, so all of them
+        are watched.  Our own AdamW kernels update W and the mirror together and bump nothing."""
         if self.Wlp is None:
             return
-        v = self.W._version
+        v = (self.W._version, sum(p._version for p in self.weight_params))
         if force or v != self._w_version:
             check(self.lib.mebt_model_sync_lowp(self.h, cur_stream()))
             self._w_version = v
@@ -146,6 +148,8 @@ class NativeModel:
                                     (1 | (2 if dropout else 0)) if training else 0,
                                     int(dropout_seed), cur_stream()))
         self._keep = (x_ids, ci, ti, logits)   # the native context holds raw pointers to these
+        if training:
+            self.generation += 1
         return logits
 
     def gpt_forward(self, sos, contexts, targets):
@@ -158,6 +162,27 @@ class NativeModel:
         check(self.lib.mebt_gpt_forward(self.h, ptr(ws), ws.numel(), B, NC, NT, ptr(sos), ptr(contexts) if NC > 0 else None,
                                         ptr(targets), ptr(logits), cur_stream()))
         return logits
+
+    def gpt_forward_train(self, sos, contexts, targets, dropout_seed=0, dropout=True):
+        """GPT.forward boundary in training mode (activations kept for gpt_backward)"""
+        sos, contexts, targets = (t.to(self.device, torch.float32).contiguous() for t in (sos, contexts, targets))
+        B, NC, NT = sos.shape[0], contexts.shape[1], targets.shape[1]
+        self.sync_lowp()
+        ws = self.workspace(B, NC, NT, True)
+        logits = torch.empty(B, NT, self.vocab, device=self.device, dtype=torch.float32)
+        check(self.lib.mebt_gpt_forward_train(self.h, ptr(ws), ws.numel(), B, NC, NT, ptr(sos), ptr(contexts) if NC > 0 else None,
+                                              ptr(targets), ptr(logits), 1 if dropout else 0, int(dropout_seed), cur_stream()))
+        self._keep = (sos, contexts, targets, logits)
+        self.generation += 1
+        return logits
+
+    def gpt_backward(self, dlogits, shapes):
+        """-> (d_sos, d_contexts, d_targets) fp32; parameter gradients of blocks / ln_f / head land in gW, gP"""
+        self.ensure_grads()
+        dlogits = dlogits.to(torch.float32).contiguous()
+        outs = [torch.empty(s, device=self.device, dtype=torch.float32) for s in shapes]
+        check(self.lib.mebt_gpt_backward(self.h, ptr(self.ws), ptr(dlogits), *[ptr(o) if o.numel() else None for o in outs], cur_stream()))
+        return outs
 
     def loss_stats(self, logits):
         """device tensor [4] float64: CE sum, #top-1, #top-5, #rows (of the last training forward)."""
@@ -218,6 +243,10 @@ class NativeModel:
         mW, vW, _, _ = self._adam_state()
         check(self.lib.mebt_model_set_fused_adamw(self.h, ptr(mW), ptr(vW), float(lr), float(betas[0]), float(betas[1]), float(eps),
                                                   float(weight_decay), int(step), float(grad_scale)))
+
+    def set_grad_accumulate(self, on):
+        """on: the next backward adds to the gradient buffers (a further micro-batch); off: it overwrites them"""
+        check(self.lib.mebt_model_set_grad_accumulate(self.h, 1 if on else 0))
 
     def adamw_step(self, lr, weight_decay, step, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0):
         self._adam_state()

@@ -10,7 +10,8 @@ draw the same `t`; one process per GPU with RCCL all-reduce (DDP, :39-41).  Data
 `.npz` / `.h5` token file with the reference's `{train,test}_data` / `_idx` keys (`--tokens` or `data.data_path`,
 mebt_amd/data.py) or synthetic grids; every item carries `indices = randperm(T*H*W)` like the reference datasets
 (mebt/data.py:85,233,413,471); ranks read disjoint shards (DistributedSampler semantics).
-Checkpoints use the Lightning layout {'state_dict','hyper_parameters','global_step'}.
+Checkpoints use the Lightning layout {'state_dict','hyper_parameters','global_step','epoch'} plus 'mebt_amd_loop'
+(AdamW moments, step counters, RNG states); `--ckpt_path` RESUMES from them (weights only when the file has no loop state).
 """
 import argparse
 import os
@@ -31,6 +32,7 @@ def main():
     ap.add_argument("--ckpt_every", type=int, default=0)
     ap.add_argument("--default_root_dir", default="runs")
     ap.add_argument("--ckpt_path", default=None)
+    ap.add_argument("--accumulate_grad_batches", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     args, unknown = ap.parse_known_args()
 
@@ -53,11 +55,17 @@ def main():
     cfg = getattr(presets, args.preset)() if args.preset else load_config(args.base, unknown)
     cfg.model.params.class_cond_dim = None
     model = presets.build_model(cfg, compute_dtype=args.dtype)
+    ckpt = None
     if args.ckpt_path:
-        sd = torch.load(args.ckpt_path, map_location="cpu", weights_only=False)
-        model.load_state_dict(sd["state_dict"], strict=False)
+        ckpt = torch.load(args.ckpt_path, map_location="cpu", weights_only=False)
+        model.load_state_dict(ckpt["state_dict"], strict=False)
     model = model.to(dev).train()
-    loop = TrainLoop(model, GradReducer(world_size=world), max_steps=args.max_steps)
+    accum = cfg.exp.get("accumulate_grad_batches", None) or args.accumulate_grad_batches or 1      # train_transformer.py:46-49
+    loop = TrainLoop(model, GradReducer(world_size=world), max_steps=args.max_steps, accumulate_grad_batches=accum)
+    start_step = 0
+    if ckpt is not None and "mebt_amd_loop" in ckpt:      # resume: optimizer moments, step counters, RNG (like trainer.fit(ckpt_path=))
+        loop.load_state_dict(ckpt["mebt_amd_loop"])
+        start_step = int(ckpt.get("global_step", 0))
 
     shape = list(cfg.model.mask.params.shape)
     # data: the reference's `vtokens` contract (mebt/data.py:236-305,330-414) — token clips from an .npz / .h5 file with
@@ -75,9 +83,12 @@ def main():
     dargs["spatial_length"] = shape[1]
     dargs.setdefault("batch_size", 6)
     loader = TokenData(dargs, world_size=world, rank=rank).train_dataloader()
-    epoch, it = 0, iter(loader)
+    epoch = start_step // max(1, len(loader))
+    if hasattr(loader.sampler, "set_epoch"):
+        loader.sampler.set_epoch(epoch)
+    it = iter(loader)
     t0 = time.perf_counter()
-    for step in range(args.max_steps):
+    for step in range(start_step, args.max_steps):
         try:
             batch = next(it)
         except StopIteration:
@@ -93,11 +104,12 @@ def main():
             if rank == 0:
                 dt = time.perf_counter() - t0
                 print(f"step {step + 1}: train/loss {s[0]:.4f} acc1 {s[1]:.2f} acc5 {s[2]:.2f} "
-                      f"lr {model.learning_rate * model.lr_scale():.3e}  {dt / (step + 1) * 1e3:.1f} ms/step", flush=True)
+                      f"lr {model.learning_rate * model.lr_scale():.3e}  {dt / (step + 1 - start_step) * 1e3:.1f} ms/step", flush=True)
         if args.ckpt_every and rank == 0 and (step + 1) % args.ckpt_every == 0:
             os.makedirs(args.default_root_dir, exist_ok=True)
             torch.save({"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-                        "hyper_parameters": model.hparams, "global_step": step + 1},
+                        "hyper_parameters": model.hparams, "global_step": step + 1, "epoch": epoch,
+                        "mebt_amd_loop": loop.state_dict()},
                        os.path.join(args.default_root_dir, f"step={step + 1}.ckpt"))
     if world > 1:
         dist.barrier()

@@ -12,7 +12,8 @@ from .parallel import GradReducer
 
 
 class TrainLoop:
-    def __init__(self, model, reducer=None, max_steps=0, overlap_optimizer=None, fused_optimizer=None):
+    def __init__(self, model, reducer=None, max_steps=0, overlap_optimizer=None, fused_optimizer=None,
+                 accumulate_grad_batches=1):
         if overlap_optimizer is None:   # pays when there is an all-reduce to hide behind; on one GPU both contend for HBM
             world = reducer.world_size if reducer is not None else 1
             overlap_optimizer = os.environ.get("MEBT_OVERLAP_OPT", "1" if world > 1 else "0") != "0"
@@ -36,6 +37,14 @@ class TrainLoop:
         if fused_optimizer is None:   # the fp32 parity mode has no fused epilogue (the engine would fall back to one AdamW launch per weight)
             fused_optimizer = os.environ.get("MEBT_FUSED_ADAMW", "1") != "0" and model.compute_dtype == "bf16"
         self.fused_optimizer = bool(fused_optimizer) and self.reducer.world_size == 1
+        # gradient accumulation (train_transformer.py:46-49 -> Lightning accumulate_grad_batches): `step` is called once per
+        # micro-batch; gradients of k consecutive calls are averaged (loss / k, as Lightning scales it), the all-reduce, the
+        # optimizer and the step counters run on the k-th.  The optimizer-in-backward needs the whole gradient in one
+        # backward, so accumulation uses the separate optimizer.
+        self.accum = max(1, int(accumulate_grad_batches))
+        self._micro = 0
+        if self.accum > 1:
+            self.fused_optimizer = False
 
     def step(self, x, indices, t=None):
         """x [B,T,H,W] int64 tokens, indices [B,N] permutations.  Returns a device tensor
@@ -51,16 +60,27 @@ class TrainLoop:
         ratio = float(seq_len - ci.shape[1]) / float(seq_len)
         scale = 1.0 / (B * seq_len * ratio ** m.config.avg_loss)
         lr = m.learning_rate * m.lr_scale()
-        self.step_count += 1
         logits = nm.forward(x_ids, ci, ti, training=True, dropout_seed=m._next_seed())
         stats = nm.loss_stats(logits)
+        if self.accum > 1:
+            self._micro += 1
+            nm.set_grad_accumulate(self._micro > 1)
+            if self._micro < self.accum:                   # not the last micro-batch: local accumulation only (DDP no_sync)
+                nm.backward(logits, scale / self.accum)
+                nm.set_grad_accumulate(False)
+                return torch.cat([stats, (stats[0] * scale).reshape(1)])
+            self._micro = 0
+            bwd_scale = scale / self.accum
+        else:
+            bwd_scale = scale
+        self.step_count += 1
         if self.fused_optimizer:
             nm.set_fused_adamw(lr, m.weight_decay, self.step_count)
             nm.backward(logits, scale)
             nm.set_fused_adamw(step=0)
             nm.adamw_range("rest", None, None, lr, m.weight_decay, self.step_count)
         elif self.opt_stream is None:
-            nm.backward(logits, scale, between=lambda s, hi, lo: red.bucket_ready(nm, s, hi, lo))
+            nm.backward(logits, bwd_scale, between=lambda s, hi, lo: red.bucket_ready(nm, s, hi, lo))
             red.wait()
             nm.adamw_step(lr, m.weight_decay, self.step_count, grad_scale=red.grad_scale)
         else:
@@ -74,9 +94,34 @@ class TrainLoop:
                         w.wait()                                    # ... and reduced across ranks
                     nm.adamw_range(stage, hi, lo, lr, m.weight_decay, self.step_count, grad_scale=red.grad_scale)
 
-            nm.backward(logits, scale, between=bucket)
+            nm.backward(logits, bwd_scale, between=bucket)
             red.pending = []
             main.wait_stream(opt)                                   # the next forward reads the updated weights
+        if self.accum > 1:
+            nm.set_grad_accumulate(False)
         m.trainer.global_step += 1
         m.global_step += 1
         return torch.cat([stats, (stats[0] * scale).reshape(1)])
+
+    # ---- resume (reference: trainer.fit(..., ckpt_path=...) restores optimizer, step counters and RNG) ---------------
+    def state_dict(self):
+        """Everything a resumed run needs besides the model's state_dict: AdamW moments, the optimizer step (bias
+        correction), the step counters that drive the LR / beta(t) / t_prior schedules and the dropout seeds, and the
+        python / numpy / torch RNG states (`t` is drawn from the python RNG, mebt/transformer.py:228)."""
+        m = self.model
+        return {"adam": [t.detach().cpu().clone() for t in self.native._adam_state()], "step_count": self.step_count,
+                "global_step": m.global_step, "trainer_global_step": m.trainer.global_step, "seed_ctr": m._seed_ctr,
+                "rng": {"python": random.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state()}}
+
+    def load_state_dict(self, sd, restore_rng=True):
+        m = self.model
+        for dst, src in zip(self.native._adam_state(), sd["adam"]):
+            dst.copy_(src)
+        self.step_count = int(sd["step_count"])
+        m.global_step = int(sd["global_step"])
+        m.trainer.global_step = int(sd["trainer_global_step"])
+        m._seed_ctr = int(sd["seed_ctr"])
+        if restore_rng and "rng" in sd:
+            random.setstate(sd["rng"]["python"])
+            np.random.set_state(sd["rng"]["numpy"])
+            torch.set_rng_state(sd["rng"]["torch"])

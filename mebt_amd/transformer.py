@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import _lib
 from .config import instantiate_from_config
-from .engine import NativeModel
+from .engine import NativeModel, flat_layout
 from .lightning_shim import LightningModuleShim
 from .modules.gpt import GPT
 from .modules.encoders import SOSProvider
@@ -82,6 +82,15 @@ def _cfg_has(cfg, key):
 
 
 # ---- autograd bridges ----------------------------------------------------------------------------------
+def _check_generation(model, generation):
+    """The engine keeps ONE set of saved activations (the last training-mode forward): a backward that belongs to an
+    earlier forward would silently use the wrong activations and indices."""
+    if model._native.generation != generation:
+        raise RuntimeError("mebt_amd: backward of a forward whose activations were overwritten by a later training-mode "
+                           "forward (the engine keeps one set of saved activations: run forward -> backward pairs in order; "
+                           "for gradient accumulation use TrainLoop(accumulate_grad_batches=k))")
+
+
 class _LogitsFn(torch.autograd.Function):
     """logits = engine.forward(...); backward feeds dL/dlogits to the HIP backward, which writes the
     parameter gradients straight into the flat gradient buffers (`param.grad` are views of them)."""
@@ -89,14 +98,39 @@ class _LogitsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, trigger, model, x_ids, ci, ti):
         ctx.model = model
-        return model._native.forward(x_ids, ci, ti, training=True, dropout_seed=model._next_seed())
+        out = model._native.forward(x_ids, ci, ti, training=True, dropout_seed=model._next_seed())
+        ctx.generation = model._native.generation
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
         m = ctx.model
+        _check_generation(m, ctx.generation)
         m._native.backward(None, 0.0, between=m._bucket_hook, dlogits=dlogits)
         m._attach_grads()
         return torch.zeros((), device=dlogits.device), None, None, None, None
+
+
+class _GptFn(torch.autograd.Function):
+    """GPT.forward on caller-embedded tensors with autograd: gradients flow to the three inputs and into the flat
+    parameter-gradient buffers (reference gpt.py:234-253 under torch autograd)."""
+
+    @staticmethod
+    def forward(ctx, model, sos, contexts, targets):
+        nm = model._native
+        ctx.model = model
+        ctx.shapes = (tuple(sos.shape), tuple(contexts.shape), tuple(targets.shape))
+        out = nm.gpt_forward_train(sos, contexts, targets, dropout_seed=model._next_seed(), dropout=model.transformer.training)
+        ctx.generation = nm.generation
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        m = ctx.model
+        _check_generation(m, ctx.generation)
+        ds, dc, dt = m._native.gpt_backward(dlogits, ctx.shapes)
+        m._attach_grads()
+        return None, ds, dc, dt
 
 
 class _LossFn(torch.autograd.Function):
@@ -106,6 +140,7 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, trigger, model, logits, scale):
         ctx.model, ctx.logits, ctx.scale = model, logits, scale
+        ctx.generation = model._native.generation
         stats = model._native.loss_stats(logits)
         ctx.mark_non_differentiable(stats)
         return (stats[0] * scale).to(torch.float32), stats
@@ -113,6 +148,7 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _gstats):
         m = ctx.model
+        _check_generation(m, ctx.generation)
         up = gloss.to(torch.float32).contiguous()
         m._native.backward(ctx.logits, ctx.scale, upstream=up, between=m._bucket_hook)
         m._attach_grads()
@@ -146,6 +182,22 @@ class MebtAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         pass        # every backward overwrites the gradient buffers
+
+    # the moments live in the engine's flat buffers (not in self.state): persist them and the step count
+    def state_dict(self):
+        m = self._model()
+        nm = m._ensure_native()
+        return {"mebt_flat_adam": [t.detach().cpu().clone() for t in nm._adam_state()], "steps": self._steps,
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        m = self._model()
+        nm = m._ensure_native()
+        for dst, src in zip(nm._adam_state(), sd["mebt_flat_adam"]):
+            dst.copy_(src)
+        self._steps = int(sd["steps"])
+        for g, saved in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update(saved)
 
 
 class Net2NetTransformer(LightningModuleShim):
@@ -218,6 +270,9 @@ class Net2NetTransformer(LightningModuleShim):
         self._reducer = None            # mebt_amd.parallel.GradReducer when data-parallel
         self._seed_ctr = 0
         self.noise_hook = None          # tests inject Exp(1) noise: fn(kind, shape) -> tensor
+        # weights loaded after the engine exists go straight into its flat fp32 buffer: refresh the bf16 mirror
+        self.register_load_state_dict_post_hook(
+            lambda module, incompatible: module._native.sync_lowp(force=True) if module._native is not None else None)
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
         self.pkeep = pkeep
@@ -280,6 +335,8 @@ class Net2NetTransformer(LightningModuleShim):
             for k, p in params.items():
                 views[k].copy_(p.data)
                 p.data = views[k]           # the Parameter object survives; its storage is now the flat buffer
+        Wn, _ = flat_layout(cfg.n_layer, has_sos=cfg.sos_emb > 0)
+        nm.weight_params = [params[k] for k in Wn]
         nm.sync_lowp(force=True)
         self._native, self._tok_ptr = nm, self.tok_emb.weight.data_ptr()
         return nm
@@ -305,7 +362,10 @@ class Net2NetTransformer(LightningModuleShim):
         return torch.zeros((), device=dev, requires_grad=True)
 
     def _gpt_forward_embedded(self, sos_emb, contexts, targets):
-        return self._ensure_native().gpt_forward(sos_emb, contexts, targets)
+        nm = self._ensure_native()
+        if torch.is_grad_enabled() and (self.transformer.training or any(t.requires_grad for t in (sos_emb, contexts, targets))):
+            return _GptFn.apply(self, sos_emb, contexts, targets)
+        return nm.gpt_forward(sos_emb, contexts, targets)
 
     # ---- forward ----------------------------------------------------------------------------------------
     @torch.no_grad()

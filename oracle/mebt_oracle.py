@@ -329,14 +329,14 @@ class TrainState:
         self.decay_names = {"transformer." + n for n in decay}
 
 
-def train_step(state, cfg, x, indices, t, window=None, grad_hook=None):
+def train_step(state, cfg, x, indices, t, window=None, grad_hook=None, drop=_nodrop):
     """One optimiser step: forward (transformer.py:216-286), loss (:717-732), backward, AdamW
     (:665-681,:790-797).  `grad_hook(grads)` lets the DP tests average gradients across ranks
     before the update (train_transformer.py:39-41 DDP).  Returns dict(loss, acc1, acc5, grads)."""
     P = state.P
     for p in P.values():
         p.grad = None
-    logits, z_tgt, NT_weight, seq_len = forward(P, cfg, x, indices, t, training=True, window=window)
+    logits, z_tgt, NT_weight, seq_len = forward(P, cfg, x, indices, t, training=True, window=window, drop=drop)
     acc1, acc5, loss = loss_and_acc(logits, z_tgt, NT_weight, seq_len, cfg)
     loss.backward()
     # a parameter the loss does not depend on (e.g. an `lt2l` block placed last) has grad None and

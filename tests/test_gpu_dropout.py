@@ -80,3 +80,44 @@ def test_dropout_sites_forward_backward(name, dtype):
     lg3 = nm.forward(x.reshape(B, -1).to(DEV), ci.to(DEV), ti.to(DEV), training=False)
     ref_eval = orc.reconstruct_mask(P, cfg, x, ci, ti)
     assert (lg3.cpu() - ref_eval).abs().max().item() < tol
+
+
+def test_fused_doutm_is_bit_identical():
+    """MEBT_FUSE_DOUTM (the LN1-backward launch of block i also writes block i-1's dropout-masked output gradient, bf16
+    only, on by default) against the separate elementwise launch: every gradient identical except the atomically
+    accumulated P-side ones, which agree to fp32 summation order.  Runs the two settings in child processes (the switch
+    is read once per process)."""
+    import os, subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch, numpy as np
+sys.path.insert(0, %r)
+from mebt_amd.engine import NativeModel
+from oracle import mebt_oracle as orc
+from tests.golden import make_golden as mg
+cfg = mg.oracle_cfg("c1")
+nm = NativeModel(cfg.n_layer, cfg.n_head, cfg.n_embd, cfg.vocab_size, cfg.sos_emb, cfg.block_size, cfg.mode, dtype="bf16",
+                 embd_pdrop=0.1, resid_pdrop=0.2, attn_pdrop=0.15)
+nm.allocate("cuda")
+views = nm.views(orc.param_shapes(cfg))
+with torch.no_grad():
+    for k, v in orc.closed_form_params(cfg).items():
+        views[k].copy_(v)
+nm.sync_lowp(force=True)
+x, idx = mg.inputs("c1", 2, "drop")
+ci, ti, seq_len = orc.divide_indices(idx, 0.45, cfg, True)
+lg = nm.forward(x.reshape(2, -1).cuda(), ci.cuda(), ti.cuda(), training=True, dropout_seed=77)
+nm.backward(lg, 1.0 / (2 * seq_len))
+torch.cuda.synchronize()
+np.savez(sys.argv[1], gW=nm.gW.cpu().numpy(), gP=nm.gP.cpu().numpy())
+''' % root
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("0", "1"):
+            path = os.path.join(td, f"g{flag}.npz")
+            env = dict(os.environ, MEBT_FUSE_DOUTM=flag, MEBT_GEMM_AUTOTUNE="0")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=root)
+            outs.append(np.load(path))
+    assert np.array_equal(outs[0]["gW"], outs[1]["gW"])
+    scale = np.abs(outs[0]["gP"]).max()
+    assert np.abs(outs[0]["gP"] - outs[1]["gP"]).max() <= 1e-5 * scale

@@ -266,3 +266,199 @@ def test_launcher_trains_from_token_file(tmp_path):
     from mebt.transformer import Net2NetTransformer
     m = Net2NetTransformer.load_from_checkpoint(str(tmp_path / "runs" / "step=6.ckpt"))
     assert torch.equal(m.state_dict()["transformer.head.weight"].cpu(), ck["state_dict"]["transformer.head.weight"])
+
+
+# ---- robustness of the host side -------------------------------------------------------------------------
+def test_bf16_mirror_follows_torch_side_weight_writes():
+    """The bf16 weight mirror must follow writes made through torch AFTER the engine exists: load_state_dict, an in-place
+    op on a Parameter (each Parameter has its own version counter, separate from the flat buffer's)."""
+    from oracle import closed_form as cf
+    m = build_product("c1", "bf16").eval()
+    g = load_golden("forward_c1")
+    x, idx = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["indices"]).to(DEV)
+    ci, ti = idx[:, :70].contiguous(), idx[:, 70:].contiguous()
+    l0, _ = m.reconstruct_mask(x, ci, ti)
+    l0 = l0.clone()
+    sd2 = {k: (v * 1.5 if k.endswith("mlp.0.weight") or k.endswith("attn.query.weight") else v) for k, v in m.state_dict().items()}
+    sd2 = {k: v.detach().cpu().clone() for k, v in sd2.items()}
+    m.load_state_dict(sd2)
+    l1, _ = m.reconstruct_mask(x, ci, ti)
+    fresh = build_product("c1", "bf16").eval()
+    fresh.load_state_dict(sd2)
+    fresh = fresh.to(DEV)
+    lf, _ = fresh.reconstruct_mask(x, ci, ti)
+    assert (l1 - l0).abs().max().item() > 1e-2                 # the new weights are in use ...
+    assert torch.equal(l1, lf)                                  # ... exactly as in a model built with them
+    with torch.no_grad():
+        m.transformer.blocks[1].mlp[2].weight.mul_(0.5)         # in-place op on one Parameter
+        fresh.transformer.blocks[1].mlp[2].weight.mul_(0.5)
+    l2, _ = m.reconstruct_mask(x, ci, ti)
+    fresh._native.sync_lowp(force=True)
+    lf2, _ = fresh.reconstruct_mask(x, ci, ti)
+    assert (l2 - l1).abs().max().item() > 1e-3 and torch.equal(l2, lf2)
+
+
+def test_resume_equals_uninterrupted_training(tmp_path):
+    """6 steps straight == 3 steps, save (model + TrainLoop state), load into a NEW model, 3 more: moments, optimizer
+    step, LR warm-up position, dropout seeds and the python RNG (which draws t) all continue (fp32 parity mode; the
+    P-side gradients are atomically accumulated, hence the 1e-6 instead of bit equality)."""
+    import random
+    from mebt_amd import presets
+    from mebt_amd.trainer import TrainLoop
+
+    def make():
+        torch.manual_seed(3)
+        cfg = presets.tiny()
+        cfg.model.params.embd_pdrop = cfg.model.params.resid_pdrop = cfg.model.params.attn_pdrop = 0.1
+        cfg.exp.exact_lr, cfg.exp.warmup_steps = 1e-3, 5
+        return presets.build_model(cfg, compute_dtype="f32")
+
+    g = torch.Generator().manual_seed(8)
+    xs = [torch.randint(0, 16384, (4, 2, 8, 8), generator=g).to(DEV) for _ in range(6)]
+    idxs = [torch.stack([torch.randperm(128, generator=g) for _ in range(4)]).to(DEV) for _ in range(6)]
+    ref = make().to(DEV).train()
+    sd0 = {k: v.detach().cpu().clone() for k, v in ref.state_dict().items()}
+    loop = TrainLoop(ref, max_steps=10)
+    random.seed(123)
+    for i in range(6):
+        loop.step(xs[i], idxs[i])                              # t drawn from the python RNG
+    a = make()
+    a.load_state_dict(sd0)
+    a = a.to(DEV).train()
+    la = TrainLoop(a, max_steps=10)
+    random.seed(123)
+    for i in range(3):
+        la.step(xs[i], idxs[i])
+    path = str(tmp_path / "ck.pt")
+    torch.save({"state_dict": {k: v.detach().cpu() for k, v in a.state_dict().items()}, "loop": la.state_dict()}, path)
+    random.seed(999)                                            # the resumed run must not depend on the process RNG state
+    ck = torch.load(path, weights_only=False)
+    b = make()
+    b.load_state_dict(ck["state_dict"])
+    b = b.to(DEV).train()
+    lb = TrainLoop(b, max_steps=10)
+    lb.load_state_dict(ck["loop"])
+    assert lb.step_count == 3 and b.global_step == 3 and b.trainer.global_step == 3
+    for i in range(3, 6):
+        lb.step(xs[i], idxs[i])
+    for (k, p), (_, q) in zip(ref.state_dict().items(), b.state_dict().items()):
+        assert (p - q).abs().max().item() <= 1e-6 * (1 + p.abs().max().item()), k
+    for u, v in zip(loop.native.adam, lb.native.adam):
+        assert (u - v).abs().max().item() <= 1e-6 * (1e-3 + u.abs().max().item())
+    # a run that restarts the counters (weights only) is NOT the same: the warm-up LR and bias correction restart
+    c = make()
+    c.load_state_dict(ck["state_dict"])
+    c = c.to(DEV).train()
+    lc = TrainLoop(c, max_steps=10)
+    random.seed(123)
+    for i in range(3, 6):
+        lc.step(xs[i], idxs[i])
+    assert max((p - q).abs().max().item() for p, q in zip(ref.state_dict().values(), c.state_dict().values())) > 1e-4
+    # the Lightning-style optimizer facade persists its state too
+    opt = b.configure_optimizers()
+    osd = opt.state_dict()
+    assert len(osd["mebt_flat_adam"]) == 4 and "steps" in osd
+    opt.load_state_dict(osd)
+
+
+def test_backward_of_a_stale_forward_raises():
+    """one set of saved activations: forward, forward, backward(first) must not silently use the second's"""
+    model = build_product("micro", "f32").train()
+    g = load_golden("forward_micro")
+    x, idx = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["indices"]).to(DEV)
+    l1, *_ = model(x, None, t=0.5, indices=idx)
+    l2, *_ = model(x, None, t=0.3, indices=idx)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        l1.sum().backward()
+    l2.sum().backward()                                          # the latest one is fine
+    assert model.transformer.head.weight.grad is not None
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gradient_accumulation_equals_mean_of_microbatch_gradients(dtype):
+    """accumulate_grad_batches = 3 (reference train_transformer.py:46-49): the optimizer sees the mean of the three
+    micro-batch gradients (each with its own t, NC/NT), compared with the oracle's autograd gradients averaged on the host,
+    and takes ONE step for three calls."""
+    from mebt_amd.trainer import TrainLoop
+    model = build_product("c1", dtype).train()
+    model.learning_rate = 1e-3
+    loop = TrainLoop(model, accumulate_grad_batches=3)
+    assert not loop.fused_optimizer
+    cfg = mg.oracle_cfg("c1")
+    P = {k: v.clone().requires_grad_(True) for k, v in orc.closed_form_params(cfg).items()}
+    ts = (0.5, 0.2, 0.7)
+    acc = {k: torch.zeros_like(v) for k, v in P.items()}
+    for i, t in enumerate(ts):
+        x, idx = mg.inputs("c1", 2, f"acc{i}")
+        for p in P.values():
+            p.grad = None
+        logits, z_t, ntw, seq_len = orc.forward(P, cfg, x, idx, t, training=True)
+        _, _, loss = orc.loss_and_acc(logits, z_t, ntw, seq_len, cfg)
+        loss.backward()
+        for k, p in P.items():
+            if p.grad is not None:
+                acc[k] += p.grad / 3
+        loop.step(x.to(DEV), idx.to(DEV), t=t)
+        assert loop.step_count == (1 if i == 2 else 0) and model.global_step == (1 if i == 2 else 0)
+    torch.cuda.synchronize()
+    gv = loop.native.views(orc.param_shapes(cfg), grads=True)
+    lim = 2e-3 if dtype == "f32" else 8e-2
+    bad = []
+    for k, ref in acc.items():
+        err = (gv[k].cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-6)
+        if not err < lim:
+            bad.append((k, round(err, 5)))
+    assert not bad, bad[:20]
+    # the fused optimizer cannot accumulate: the engine refuses instead of silently dropping micro-batches
+    nm = loop.native
+    nm.set_grad_accumulate(True)
+    nm.set_fused_adamw(1e-3, 0.01, 1)
+    x, idx = mg.inputs("c1", 2, "acc0")
+    ci, ti, _ = orc.divide_indices(idx, 0.5, cfg, True)
+    lg = nm.forward(x.reshape(2, -1).to(DEV), ci.to(DEV), ti.to(DEV), training=True)
+    with pytest.raises(RuntimeError, match="exclude each other"):
+        nm.backward(lg, 1.0)
+    nm.set_fused_adamw(step=0)
+    nm.set_grad_accumulate(False)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gpt_forward_boundary_backward(dtype):
+    """GPT.forward(sos, contexts, targets) on caller-embedded tensors under autograd (mebt_gpt_forward
+    'and the matching _backward'): gradients with respect to the three inputs and every block / ln_f / head parameter
+    against the oracle's autograd (reference gpt.py:234-253)."""
+    model = build_product("micro", dtype).eval()
+    cfg = mg.oracle_cfg("micro")
+    P = {k: v.clone().requires_grad_(True) for k, v in orc.closed_form_params(cfg).items()}
+    xx, idx = mg.inputs("micro", 2, "gptbwd")
+    ci, ti = idx[:, :9], idx[:, 9:]
+    with torch.no_grad():
+        sos, ctx, tgt = orc.embed(P, cfg, xx.reshape(2, -1), ci, ti)
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(2, ti.shape[1], 16384, generator=g) * 1e-2
+    ins = [t.clone().requires_grad_(True) for t in (sos, ctx, tgt)]
+    ref = orc.gpt_forward(P, cfg, *ins)
+    (ref * w).sum().backward()
+    dev_ins = [t.detach().to(DEV).requires_grad_(True) for t in (sos, ctx, tgt)]
+    got, _ = model.transformer(*dev_ins, None, 0.)
+    assert got.requires_grad
+    tol = 1e-4 if dtype == "f32" else 2e-2
+    assert (got.detach().cpu() - ref.detach()).abs().max().item() < tol
+    (got * w.to(DEV)).sum().backward()
+    lim = 2e-3 if dtype == "f32" else 8e-2
+    for a, b, name in zip(dev_ins, ins, ("sos", "contexts", "targets")):
+        err = (a.grad.cpu() - b.grad).abs().max().item() / b.grad.abs().max().item()
+        assert err < lim, (name, err)
+    bad = []
+    for k, p in model.named_parameters():
+        if not k.startswith("transformer."):
+            continue
+        refg = P[k].grad
+        err = (p.grad.cpu() - refg).abs().max().item() / (refg.abs().max().item() + 1e-6)
+        if not err < lim:
+            bad.append((k, round(err, 5)))
+    assert not bad, bad[:20]
+    # without autograd interest the inference path is taken (no activations kept)
+    with torch.no_grad():
+        inf, _ = model.transformer(sos.to(DEV), ctx.to(DEV), tgt.to(DEV), None, 0.)
+    assert not inf.requires_grad and (inf.cpu() - ref.detach()).abs().max().item() < tol
