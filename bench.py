@@ -4,21 +4,27 @@
 metric  : masked video tokens/sec/GPU, train step (BASELINE.json `metric`)
 workload: Sky-Timelapse 16f config (BASELINE.json configs[1]): 24L / d=1024 / 16 heads, 1024 VQ
           tokens + 256 latents, batch 6 per GPU, t = 0.5 -> NC = NT = 512 (SURVEY.md §8d headline
-          point), synthetic token grids, random-init weights.
+          point), synthetic token grids, random-init weights, dropout 0.1 as the config trains.
 step    : embed -> 24 blocks -> head -> masked-token CE (+top-1/5) -> full backward ->
-          (all-reduce when N>1) -> fused AdamW.  Inputs are resident in HBM before timing starts.
+          (reduce-scatter / sharded AdamW / all-gather when N>1) -> AdamW.  Inputs are resident in HBM
+          before timing starts.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--secondary none|light|full]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `roofline` = the GEMM kernel family (93 % of the step's FLOPs),
 achieved = algorithmic FLOPs / HIP-event time on the launch stream, measured live after the timed
 region; `cpu_baseline` = the CPU oracle (kind "port") timed on this box's host cores on a bounded
-sample of the same workload.
+sample of the same workload; `secondary` (N = 1 only, outside the timed region) = the other metrics
+of SURVEY.md §8(d): the step with the separate optimizer (what every data-parallel rank runs), the eval
+forward, the t sweep, a variable-t run, the samplers at C2, the C4 revise schedule and the HBM rate of
+the embedding gather / scatter kernels.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import random
 import sys
 import time
 
@@ -29,6 +35,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.29 TB/s measured with a float4 copy, same guide)
+TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 --pmc summaries, newest first
 
 
 def synthetic_batch(B, shape, rank, device):
@@ -39,37 +47,168 @@ def synthetic_batch(B, shape, rank, device):
     return x.to(device), idx.to(device)
 
 
-def cpu_baseline(model_sd, cfg, t, sample_B=6):
-    """The CPU oracle (a port of the reference algorithm, pinned to it by tests/golden) timed on
-    this box's host cores: one full train step (fwd + CE + bwd + AdamW) of the same network at
-    batch `sample_B` and the same t."""
-    from oracle import mebt_oracle as orc
-    p = cfg.model.params
-    ocfg = orc.OracleConfig(p.n_layer, p.n_head, p.n_embd, p.block_size, p.sos_emb, p.mode, shape=cfg.model.mask.params.shape,
-                            schedule=cfg.model.mask.params.schedule, budget=cfg.model.mask.params.budget, avg_loss=1.0)
-    cores = min(os.cpu_count(), 16)        # more threads than this only oversubscribes these op sizes
-    torch.set_num_threads(cores)
-    st = orc.TrainState({k: v.float().cpu() for k, v in model_sd.items()}, lr=cfg.exp.exact_lr)
-    x, idx = synthetic_batch(sample_B, cfg.model.mask.params.shape, 0, "cpu")
-    orc.train_step(st, ocfg, x, idx, t)                      # untimed warm-up step (allocator, thread pool)
-    dts = []
-    for _ in range(3):                                       # ~12-15 s of CPU work in all
-        t0 = time.perf_counter()
-        r = orc.train_step(st, ocfg, x, idx, t)
-        dts.append(time.perf_counter() - t0)
-    dt = sorted(dts)[1]                                      # median of three
-    model = ""
+def cpu_model_name():
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
                 if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
+                    return line.split(":", 1)[1].strip()
     except OSError:
         pass
-    return {"value": r["n_targets"] / dt, "unit": "masked tokens/s", "cores": cores, "kind": "port",
-            "sample": f"median of 3 timed train steps (fwd+CE+bwd+AdamW, after 1 warm-up) at batch {sample_B}, NC=NT={r['n_targets'] // sample_B}, fp32, "
-                      f"torch {torch.__version__} CPU, {torch.get_num_threads()} threads, {model}; {dt:.1f} s per step"}
+    return ""
+
+
+def cpu_baseline(model_sd, cfg, t, sample_B=6):
+    """The CPU oracle (a port of the reference algorithm, pinned to it by tests/golden) timed on this box's host
+    cores: full train steps (fwd + CE + bwd + AdamW) of the same network at batch `sample_B` and the same t, with
+    every core torch sees and with 16 threads (beyond which these op sizes stop scaling on most hosts); `value` is
+    the faster of the two."""
+    from oracle import mebt_oracle as orc
+    p = cfg.model.params
+    ocfg = orc.OracleConfig(p.n_layer, p.n_head, p.n_embd, p.block_size, p.sos_emb, p.mode, shape=cfg.model.mask.params.shape,
+                            schedule=cfg.model.mask.params.schedule, budget=cfg.model.mask.params.budget, avg_loss=1.0)
+    ncpu = os.cpu_count() or 1
+    st = orc.TrainState({k: v.float().cpu() for k, v in model_sd.items()}, lr=cfg.exp.exact_lr)
+    x, idx = synthetic_batch(sample_B, cfg.model.mask.params.shape, 0, "cpu")
+    runs = {}
+    for threads in sorted({min(16, ncpu), ncpu}):
+        torch.set_num_threads(threads)
+        orc.train_step(st, ocfg, x, idx, t)                      # untimed warm-up step (allocator, thread pool)
+        dts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = orc.train_step(st, ocfg, x, idx, t)
+            dts.append(time.perf_counter() - t0)
+        runs[threads] = (min(dts), r["n_targets"])
+    best = min(runs, key=lambda k: runs[k][0])
+    dt, ntg = runs[best]
+    return {"value": ntg / dt, "unit": "masked tokens/s", "cores": best, "kind": "port", "os_cpu_count": ncpu,
+            "by_threads": {str(k): round(v[1] / v[0], 1) for k, v in runs.items()},
+            "sample": f"best of 2 timed train steps (fwd+CE+bwd+AdamW, after 1 warm-up) per thread count at batch {sample_B}, "
+                      f"NC=NT={ntg // sample_B}, fp32, torch {torch.__version__} CPU, {cpu_model_name()}; {dt:.1f} s per step at {best} threads"}
+
+
+def timed(fn, n, sync):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / n
+
+
+def secondary_metrics(args, cfg, model, loop, x, idx, device, lib, level):
+    """SURVEY.md §8(d) secondary metrics, one GPU, outside the headline's timed region."""
+    from mebt_amd import presets, _lib
+    from mebt_amd.trainer import TrainLoop
+    from oracle.mebt_oracle import forward_flops_per_sample, OracleConfig
+    sync = torch.cuda.synchronize
+    B = args.batch
+    out = {}
+    p = cfg.model.params
+    ocfg = OracleConfig(p.n_layer, p.n_head, p.n_embd, p.block_size, p.sos_emb, p.mode, shape=cfg.model.mask.params.shape)
+
+    # (1) the step as a data-parallel rank runs it (gradients stored, separate AdamW): the honest weak-scaling denominator
+    sep = TrainLoop(model, fused_optimizer=False)
+    sep.step_count = loop.step_count
+    for _ in range(3):
+        sep.step(x, idx, t=args.t)
+    dt = timed(lambda: sep.step(x, idx, t=args.t), 10, sync)
+    out["separate_optimizer"] = {"ms_per_step": round(dt * 1e3, 3), "masked_tokens_per_s": round(B * 512 / dt, 1),
+                                 "note": "fwd + CE + bwd (fp32 gradients stored) + streaming AdamW: the N = 1 equivalent of the per-rank work under data parallelism"}
+
+    # (2) embedding gather forward / scatter-add backward: HBM rate from HIP events and algorithmic bytes
+    lib.mebt_profile_enable(1)
+    for _ in range(6):
+        sep.step(x, idx, t=args.t)
+    sync()
+    emb = {}
+    for fam, name in ((2, "fwd"), (3, "bwd")):
+        n, ms, by = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(lib.mebt_profile_read(fam, C.byref(n), C.byref(ms), C.byref(by)))
+        if n.value and ms.value:
+            gbs = by.value / (ms.value * 1e-3) / 1e9
+            emb[name] = {"us_per_launch": round(ms.value / n.value * 1e3, 2), "algorithmic_MB": round(by.value / n.value / 1e6, 2),
+                         "GB_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4)}
+    lib.mebt_profile_enable(0)
+    out["embed_gather"] = emb
+
+    # (3) eval forward (reconstruct_mask path) at the headline shape
+    model.eval()
+    ci, ti = idx[:, :512].contiguous(), idx[:, 512:].contiguous()
+    with torch.no_grad():
+        for _ in range(3):
+            model.reconstruct_mask(x, ci, ti)
+        dt = timed(lambda: model.reconstruct_mask(x, ci, ti), 20, sync)
+    fl = forward_flops_per_sample(ocfg, 512, 512) * B
+    out["eval_forward"] = {"ms": round(dt * 1e3, 3), "masked_tokens_per_s": round(B * 512 / dt, 1), "tflops": round(fl / dt / 1e12, 1)}
+    model.train()
+    if level == "light":
+        return out
+
+    # (4) t sweep of the train step (fused optimizer, as the headline)
+    sweep = {}
+    for t in (0.1, 0.25, 0.5, 0.75, 0.9):
+        for _ in range(2):
+            st = loop.step(x, idx, t=t)
+        dt = timed(lambda: loop.step(x, idx, t=t), 8, sync)
+        nt = int(st[3].cpu()) // B                   # targets per sample: ceil((1 - t) * N) under the linear schedule
+        fl = 3 * forward_flops_per_sample(ocfg, 1024 - nt, nt) * B
+        sweep[str(t)] = {"NT": nt, "ms_per_step": round(dt * 1e3, 3), "masked_tokens_per_s": round(B * nt / dt, 1), "tflops": round(fl / dt / 1e12, 1)}
+    out["t_sweep"] = sweep
+
+    # (5) t ~ U(0,1) as in real training (SURVEY.md §8d: random.seed(42), E[NT] = 513): first pass pays the GEMM tuner
+    # for the (bucketed) signatures it has not seen, the second pass is the steady state
+    rng = random.Random(42)
+    ts = [rng.random() for _ in range(60)]
+    passes = []
+    for _ in range(2):
+        sync()
+        t0 = time.perf_counter()
+        rows = torch.zeros((), device=device, dtype=torch.float64)
+        for t in ts:
+            rows += loop.step(x, idx, t=t)[3]
+        sync()
+        el = time.perf_counter() - t0
+        tot = float(rows.cpu())
+        passes.append({"s": round(el, 3), "ms_per_step": round(el / len(ts) * 1e3, 3), "masked_tokens_per_s": round(tot / el, 1)})
+    out["variable_t"] = {"steps": len(ts), "first_pass_incl_tuning": passes[0], "steady_state": passes[1]}
+
+    # (6) samplers at C2 (cosine schedule as the sampling script sets it), batch 4
+    model.eval()
+    model.mask_sampler.schedule = "cosine"            # sample_vqgan_transformer_videos.py:189,219
+    Bs = 4
+    x0 = torch.zeros(Bs, *cfg.model.mask.params.shape, dtype=torch.long, device=device)
+    with torch.no_grad():
+        f = lambda: model.sample(x0, None, 1.0, None, None, 32, None, None, context_temperature=4.5, skips=False)
+        f()
+        dt = timed(f, 2, sync)
+        out["sample_32_steps_c2"] = {"batch": Bs, "s": round(dt, 4), "sampler_steps_per_s": round(32 / dt, 1), "tokens_per_s": round(Bs * 1024 / dt, 1)}
+        xr = torch.randint(0, 16384, (Bs, *cfg.model.mask.params.shape), device=device)
+        f = lambda: model.draft_and_revise(xr, None, 8, 1.0, None, None, 2, 1.0, None, None, 2, True)
+        f()
+        dt = timed(f, 3, sync)
+        out["revise_2x2_c2"] = {"batch": Bs, "s": round(dt, 4), "forwards": 4, "forwards_per_s": round(4 / dt, 1)}
+    model.mask_sampler.schedule = cfg.model.mask.params.schedule
+    model.train()
+
+    # (7) C4: UCF-101 128f geometry (block 8192), the revise schedule of the shipped script: M = 2 x 32 revise forwards at
+    # (NC, NT) = (7936, 256), batch 4
+    del sep
+    ucfg = presets.ucf_128f()
+    torch.manual_seed(1)
+    um = presets.build_model(ucfg, compute_dtype=args.dtype).to(device).eval()
+    xu = torch.randint(0, 16384, (4, 32, 16, 16), device=device)
+    up = ucfg.model.params
+    uo = OracleConfig(up.n_layer, up.n_head, up.n_embd, up.block_size, up.sos_emb, up.mode, shape=ucfg.model.mask.params.shape)
+    with torch.no_grad():
+        f = lambda: um.draft_and_revise(xu, None, 8, 1.0, None, None, 32, 1.0, None, None, 2, True)
+        f()
+        dt = timed(f, 1, sync)
+    fl = 64 * 4 * forward_flops_per_sample(uo, 7936, 256)
+    out["c4_revise_64_forwards"] = {"batch": 4, "s": round(dt, 3), "forwards_per_s": round(64 / dt, 1), "tflops": round(fl / dt / 1e12, 1),
+                                    "note": "64 forwards at (NC, NT) = (7936, 256) + sampling + scatter, block 8192"}
+    return out
 
 
 def main():
@@ -82,6 +221,7 @@ def main():
     ap.add_argument("--t", type=float, default=0.5)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--secondary", default="full", choices=["none", "light", "full"])
     ap.add_argument("--preset", default="sky_16f", choices=["sky_16f", "tiny"])
     args = ap.parse_args()
 
@@ -109,7 +249,8 @@ def main():
     cfg = presets.sky_16f(vtokens=True, dropout=args.dropout) if args.preset == "sky_16f" else presets.tiny()
     torch.manual_seed(0)                       # identical random-init weights on every rank
     model = presets.build_model(cfg, compute_dtype=args.dtype).to(device).train()
-    loop = TrainLoop(model, GradReducer(world_size=world))
+    reducer = GradReducer(world_size=world)
+    loop = TrainLoop(model, reducer)
     shape = cfg.model.mask.params.shape
     x, idx = synthetic_batch(args.batch, shape, rank, device)
 
@@ -145,44 +286,33 @@ def main():
         loop.step(x, idx, t=args.t)
     sync()
     roof = None
-    import ctypes as C
     n, tms, fl = C.c_double(), C.c_double(), C.c_double()
     if rank == 0:
         _lib.check(lib.mebt_profile_read(0, C.byref(n), C.byref(tms), C.byref(fl)))
         nb, tb, by = C.c_double(), C.c_double(), C.c_double()
         _lib.check(lib.mebt_profile_read(1, C.byref(nb), C.byref(tb), C.byref(by)))
         lib.mebt_profile_enable(0)
-    # the same two steps with every launch on one stream (identical to the above unless MEBT_SIDE_STREAM=1)
-    ser = None
-    lib.mebt_debug_side_stream(loop.native.h, 0)
-    if rank == 0:
-        lib.mebt_profile_enable(1)
-    for _ in range(2):
-        loop.step(x, idx, t=args.t)
-    sync()
-    if rank == 0:
-        n2, t2, f2 = C.c_double(), C.c_double(), C.c_double()
-        _lib.check(lib.mebt_profile_read(0, C.byref(n2), C.byref(t2), C.byref(f2)))
-        lib.mebt_profile_enable(0)
-        ser = round(f2.value / (t2.value * 1e-3) / 1e12, 2) if t2.value > 0 else None
-    lib.mebt_debug_side_stream(loop.native.h, 1 if loop.native.side_stream else 0)
-    if rank == 0:
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        # HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
-        # (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction): tools/pmc_traffic.py
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = round(json.load(f)["gemm_bf16"]["hbm_bytes_per_launch"]) if args.dtype == "bf16" else None
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (separate
+        # FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction: tools/pmc_traffic.py).  PMC counters cannot be
+        # collected inside this process; the source file is named so that a stale figure is visible.
+        traffic, traffic_src = None, None
+        if args.dtype == "bf16" and world == 1:
+            for fn in TRAFFIC_FILES:
+                try:
+                    with open(os.path.join(ROOT, "profiles", fn)) as f:
+                        traffic = round(json.load(f)["gemm_bf16"]["hbm_bytes_per_launch"])
+                    traffic_src = "profiles/" + fn
+                    break
+                except (OSError, KeyError, ValueError):
+                    continue
         achieved = fl.value / (tms.value * 1e-3) / 1e12 if tms.value > 0 else 0.0
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(by.value / max(1.0, nb.value)),
                 "kernel": "bf16 MFMA GEMM family (gemm_bf16_dma[_ks2] / gemm_pair / wgrad_grouped incl. its fused AdamW epilogue)" if args.dtype == "bf16" else "gemm_f32_kernel",
                 "launches_per_step": n.value / 2, "gemm_ms_per_step": round(tms.value / 2, 3),
-                "gemm_gflop_per_step": round(fl.value / 2 / 1e9, 1), "achieved_single_stream": ser}
+                "gemm_gflop_per_step": round(fl.value / 2 / 1e9, 1)}
 
     if rank == 0:
         out = {"metric": "masked video tokens/sec/GPU (train step, 24L d=1024, 1024+256 tok)",
@@ -192,10 +322,14 @@ def main():
                "per_gpu": round(value / world, 1),
                "config": {"workload": "Sky-Timelapse 16f MeBT train step: 24L/1024d/16h, 1024 VQ tokens + 256 latents, "
                                       f"batch {args.batch}/GPU, t={args.t} (NC=NT={n_targets // args.batch}), "
-                                      "fwd + masked CE + bwd + AdamW" + (" + RCCL all-reduce" if world > 1 else ""),
+                                      "fwd + masked CE + bwd + AdamW" + (f" + reduce-scatter / sharded AdamW / all-gather ({reducer.mode}, {reducer.wire} wire)" if world > 1 else ""),
                           "global_batch": args.batch * world, "parallelism": f"dp{world}", "dropout": args.dropout,
+                          "optimizer": "in-backward (fused into the weight-gradient launches)" if loop.fused_optimizer else
+                                       ("sharded over ranks" if world > 1 and reducer.mode == "sharded" else "separate"),
                           "loss": round(float(stats[4]), 4)},
                "roofline": roof}
+        if world == 1 and args.secondary != "none" and args.preset == "sky_16f":
+            out["secondary"] = secondary_metrics(args, cfg, model, loop, x, idx, device, lib, args.secondary)
         if not args.no_cpu_baseline and world == 1:
             sd = {k: v.detach() for k, v in model.state_dict().items()}
             out["cpu_baseline"] = cpu_baseline(sd, cfg, args.t)

@@ -122,6 +122,14 @@ int mebt_adamw_range(mebt_model* m, float* mW, float* vW, float* mP, float* vP, 
                      float eps, float weight_decay, int32_t step, float grad_scale, int32_t kind, int32_t layer_hi,
                      int32_t layer_lo, mebt_stream_t stream);
 
+/* The same update on an arbitrary slice [off, off + n) of W (which = 0) or P (which = 1) with the gradient passed
+ * separately (`grad` = gradient of element `off`; bf16 when grad_bf16): what a data-parallel rank applies to its shard
+ * of a gradient bucket after the reduce-scatter — optimizer state and fp32 masters are only touched by the owner
+ * (reference: the DDP all-reduce + replicated optimizer of train_transformer.py:39-41). */
+int mebt_adamw_slice(mebt_model* m, int32_t which, int64_t off, int64_t n, const void* grad, int32_t grad_bf16, float* mW,
+                     float* vW, float* mP, float* vP, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int32_t step, float grad_scale, mebt_stream_t stream);
+
 /* Optimizer-in-backward (single-process training): armed with step >= 1, the next mebt_backward_layers applies
  * AdamW to every block's Linear weights INSIDE the weight-gradient launch (the gradient tile is consumed from
  * registers; it is not stored in gW, and W / the bf16 mirror / mW / vW are updated in place), which removes
@@ -187,7 +195,8 @@ void mebt_gemm_autotune(int32_t mode);
 /* ---- instrumentation ----------------------------------------------------------------------------- */
 /* Per-kernel-family timing with HIP events on the launch stream (bench.py roofline): enable, run,
  * then read {launches, total ms, total algorithmic flops} of the GEMM family (family 0), or the
- * algorithmic operand + result bytes in place of the flops (family 1). */
+ * algorithmic operand + result bytes in place of the flops (family 1); family 2 / 3: the embedding gather forward /
+ * its scatter-add backward with their algorithmic bytes. */
 int mebt_profile_enable(int32_t on);
 int mebt_profile_read(int32_t family, double* launches, double* total_ms, double* total_flops);
 /* Tests only: multiplies out[0..n) (fp32, n % 4 == 0) in place by the dropout keep-scales (0 or 1/(1-p))

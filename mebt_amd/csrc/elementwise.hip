@@ -618,13 +618,14 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const CeBwdParams p) {
 // ------------------------------------------------------------------------------------------------
 // AdamW (decoupled weight decay, torch.optim.AdamW semantics) + bf16 mirror of the updated weights
 // ------------------------------------------------------------------------------------------------
+template <typename TG>
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
     // (nontemporal loads/stores and grids of 2048..16384 workgroups were tried: all within noise, 4.5-5.4 TB/s
     //  depending on the box, of the ~6.3 TB/s a float4 copy reaches)
     const AdamWHyper h = {a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.bc1, a.bc2, a.grad_scale};
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (size_t)gridDim.x * 1024) {
         f32x4 p = *reinterpret_cast<const f32x4*>(a.p + i);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i);
+        const f32x4 g = load4<TG>(reinterpret_cast<const TG*>(a.g) + i);
         f32x4 m = *reinterpret_cast<const f32x4*>(a.m + i);
         f32x4 v = *reinterpret_cast<const f32x4*>(a.v + i);
         adamw_update4(p, g, m, v, h);
@@ -862,7 +863,8 @@ int launch_adamw(const AdamWParams& p, hipStream_t stream) {
     if (p.n == 0) return MEBT_OK;
     if (p.n % 4) { mebt_set_error("adamw: flat buffer length must be a multiple of 4"); return MEBT_ESHAPE; }
     const size_t blocks = (p.n / 4 + 255) / 256;
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, p);
+    if (p.g_bf16) hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(adamw_kernel<float>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, p);
     CHECK_LAUNCH();
     return MEBT_OK;
 }

@@ -109,7 +109,7 @@ static int join_side(mebt_model* m, hipStream_t st);
 // profiling of the GEMM family with HIP events on the launch stream
 // ---------------------------------------------------------------------------------------------------
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; double flops, bytes; int kind = 0; };    // kind 0: GEMM family, 2: embed forward, 3: embed backward
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_ev_pool;
@@ -169,14 +169,17 @@ extern "C" int mebt_profile_enable(int32_t on) {
     return MEBT_OK;
 }
 extern "C" int mebt_profile_read(int32_t family, double* launches, double* total_ms, double* total_flops) {
-    double ms = 0, fl = 0;
+    double ms = 0, fl = 0, n = 0;
+    const int kind = family >= 2 ? family : 0;
     for (auto& r : g_prof) {
+        if (r.kind != kind) continue;
         MEBT_HIP_CHECK(hipEventSynchronize(r.b));
         float t = 0;
         MEBT_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
-        ms += t; fl += family == 1 ? r.bytes : r.flops;    // family 1: algorithmic operand+result bytes instead of FLOPs
+        ms += t; fl += family >= 1 ? r.bytes : r.flops;    // family 1: algorithmic operand+result bytes instead of FLOPs
+        n += 1;
     }
-    *launches = (double)g_prof.size(); *total_ms = ms; *total_flops = fl;
+    *launches = n; *total_ms = ms; *total_flops = fl;
     return MEBT_OK;
 }
 
@@ -462,7 +465,14 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         ep.sos = x.sos0; ep.ctx = x.ctx; ep.tgt = x.tgt0;
         ep.B = B; ep.N = N; ep.NC = NC; ep.NT = NT; ep.NS = NS; ep.d = d; ep.vocab = V; ep.block_size = m->d.block_size;
         ep.drop = make_drop(dropout_seed, 0, p_emb);       // gpt.py:238-240
+        ProfRec r;
+        if (g_prof_on) {     // algorithmic bytes: rows read once (fp32 tables), rows written once, the index vectors
+            r.a = get_event(); r.b = get_event(); r.kind = 2; r.flops = 0;
+            r.bytes = (double)B * (((double)2 * NC + NT + NS) * d * 4 + ((double)NC + NT + NS) * d * m->esz() + 8.0 * (NC + NT) + 8.0 * NC);
+            (void)hipEventRecord(r.a, st);
+        }
         RC(launch_embed_fwd(ep, dt, st));
+        if (g_prof_on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
     }
 
     const void* Sv = x.sos0;
@@ -981,7 +991,16 @@ extern "C" int mebt_backward_embed(mebt_model* m, void* ws, mebt_stream_t stream
         mebt_set_error("backward_embed: contexts without a live latent_enc block are not supported");
         return MEBT_EINVAL;
     }
-    return launch_embed_bwd(p, m->d.dtype, S(stream));
+    ProfRec r;
+    if (g_prof_on) {         // stream gradients read once; fp32 atomic adds: 2 table rows per context row, 1 per target row; mask / sos column sums
+        r.a = get_event(); r.b = get_event(); r.kind = 3; r.flops = 0;
+        const double dd = p.d;
+        r.bytes = (double)p.B * ((double)p.NC * dd * 4 + ((double)p.NT + p.NS) * dd * m->esz() + ((double)2 * p.NC + p.NT) * dd * 4);
+        (void)hipEventRecord(r.a, S(stream));
+    }
+    const int rc = launch_embed_bwd(p, m->d.dtype, S(stream));
+    if (g_prof_on) { (void)hipEventRecord(r.b, S(stream)); g_prof.push_back(r); }
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1024,6 +1043,44 @@ extern "C" int mebt_adamw_range(mebt_model* m, float* mW, float* vW, float* mP, 
         const int64_t tail_n = (m->tok_live ? m->n_p : m->tok_emb) - m->lnf_w;
         RC(run(m->P, m->gP, mP, vP, nullptr, m->lnf_w, tail_n, 0.f));
     }
+    return MEBT_OK;
+}
+
+// AdamW on an arbitrary slice [off, off + n) of the flat W (which = 0: decayed, bf16 mirror refreshed) or P (which = 1)
+// buffer, with the gradient given separately: `grad` points at the gradient of element `off` (fp32, or bf16 when
+// grad_bf16).  This is the update a data-parallel rank applies to ITS shard of a gradient bucket after the
+// reduce-scatter (ZeRO-1 style: m, v and the fp32 master are only ever touched on the owning rank).  Elements of blocks
+// the loss cannot reach are skipped, exactly like mebt_adamw_range.
+extern "C" int mebt_adamw_slice(mebt_model* m, int32_t which, int64_t off, int64_t n, const void* grad, int32_t grad_bf16, float* mW,
+                                float* vW, float* mP, float* vP, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int32_t step, float grad_scale, mebt_stream_t stream) {
+    if (!m || !m->W || !grad) { mebt_set_error("adamw_slice: model not bound / null gradient"); return MEBT_EINVAL; }
+    if (step < 1) { mebt_set_error("adamw: step must be >= 1"); return MEBT_EINVAL; }
+    const int64_t total = which == 0 ? m->n_w : m->n_p;
+    if (off < 0 || n < 0 || off + n > total || (off % 4) || (n % 4)) { mebt_set_error("adamw_slice: bad range (multiples of 4 inside the buffer)"); return MEBT_EINVAL; }
+    hipStream_t st = S(stream);
+    AdamWParams a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale; a.g_bf16 = grad_bf16 ? 1 : 0;
+    a.bc1 = (float)(1.0 - pow((double)beta1, step)); a.bc2 = (float)(1.0 - pow((double)beta2, step));
+    a.weight_decay = which == 0 ? weight_decay : 0.f;
+    const int d = m->d.n_embd;
+    const int64_t gsz = grad_bf16 ? 2 : 4;
+    auto run = [&](int64_t lo, int64_t hi) -> int {          // intersection of [lo, hi) (a live range) with the slice
+        const int64_t a0 = lo > off ? lo : off, a1 = hi < off + n ? hi : off + n;
+        if (a1 <= a0) return MEBT_OK;
+        float* pb = which == 0 ? m->W : m->P;
+        a.p = pb + a0; a.m = (which == 0 ? mW : mP) + a0; a.v = (which == 0 ? vW : vP) + a0; a.n = (size_t)(a1 - a0);
+        a.g = reinterpret_cast<const float*>(reinterpret_cast<const char*>(grad) + (a0 - off) * gsz);
+        a.p_bf16 = (which == 0 && m->Wlp) ? (void*)((char*)m->Wlp + a0 * 2) : nullptr;
+        return launch_adamw(a, st);
+    };
+    for (int i = 0; i < m->d.n_layer; ++i) {
+        if (!m->live[i]) continue;
+        if (which == 0) RC(run(m->lo[i].wq, m->lo[i].wq + (int64_t)12 * d * d));
+        else RC(run(m->lo[i].ln1w, m->lo[i].ln1w + (int64_t)13 * d));
+    }
+    if (which == 0) RC(run(m->head_w, m->n_w));
+    else RC(run(m->lnf_w, m->tok_live ? m->n_p : m->tok_emb));
     return MEBT_OK;
 }
 

@@ -200,7 +200,7 @@ class NativeModel:
     def backward_embed(self):
         check(self.lib.mebt_backward_embed(self.h, ptr(self.ws), cur_stream()))
 
-    def backward(self, logits, loss_scale, upstream=None, between=None, dlogits=None):
+    def backward(self, logits, loss_scale, upstream=None, between=None, dlogits=None, bucket_layers=4):
         """Full backward.  `between(stage, hi, lo)` is called after each finished gradient bucket
         ('head', 'layers', 'embed') so a data-parallel reducer can launch its all-reduce.
         `dlogits` (fp32 [B,NT,V]) replaces the fused cross-entropy backward by an explicit upstream."""
@@ -212,7 +212,7 @@ class NativeModel:
             self.backward_head(logits, loss_scale, upstream)
         if between:
             between("head", None, None)
-        step = 4
+        step = max(1, int(bucket_layers))
         hi = self.n_layer - 1
         while hi >= 0:
             lo = max(0, hi - step + 1)
@@ -236,6 +236,17 @@ class NativeModel:
         check(self.lib.mebt_adamw_range(self.h, ptr(mW), ptr(vW), ptr(mP), ptr(vP), float(lr), float(betas[0]), float(betas[1]),
                                         float(eps), float(weight_decay), int(step), float(grad_scale), k, int(hi or 0), int(lo or 0),
                                         stream if stream is not None else cur_stream()))
+
+    def adamw_slice(self, which, off, n, grad, lr, weight_decay, step, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0, stream=None):
+        """AdamW on elements [off, off+n) of W (which = 0) or P (1) with `grad` (fp32 or bf16, n elements) as gradient"""
+        mW, vW, mP, vP = self._adam_state()
+        check(self.lib.mebt_adamw_slice(self.h, int(which), int(off), int(n), ptr(grad), 1 if grad.dtype == torch.bfloat16 else 0,
+                                        ptr(mW), ptr(vW), ptr(mP), ptr(vP), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                        float(weight_decay), int(step), float(grad_scale), stream if stream is not None else cur_stream()))
+
+    def cast_bf16(self, src, dst):
+        """dst (bf16) = src (fp32), flat, on the current stream (gradient bucket -> wire format)"""
+        check(self.lib.mebt_op_cast_bf16(ptr(src), ptr(dst), src.numel(), cur_stream()))
 
     def set_fused_adamw(self, lr=0.0, weight_decay=0.0, step=0, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0):
         """Arm (step >= 1) / disarm (step = 0) the optimizer-in-backward for the blocks' Linear weights; after the

@@ -1,58 +1,188 @@
-"""Single-node data parallelism: one process per GPU, full replica, gradient all-reduce over
-RCCL/xGMI (torch.distributed backend "nccl" is RCCL on ROCm).  Counterpart of the reference's only
-multi-GPU mechanism, Lightning's DDPStrategy (train_transformer.py:39-41).
+"""Single-node data parallelism: one process per GPU, full replica of the network, RCCL over xGMI
+(torch.distributed backend "nccl" is RCCL on ROCm).  Counterpart of the reference's only multi-GPU mechanism,
+Lightning's DDPStrategy: all-reduce(mean) of 337 M gradients + a replicated optimizer (train_transformer.py:39-41).
 
-Design: gradients live in two flat fp32 buffers laid out in layer order, so a
-bucket is a contiguous slice — no flatten/unflatten copies.  The HIP backward is split at bucket
-boundaries (mebt_backward_head / _layers / _embed); after each piece the reducer launches an
-asynchronous all-reduce of the slice that just became final.  RCCL runs it on its own stream after
-an event on the compute stream, so the collective overlaps the rest of backward; only the last
-bucket (P: LN/bias/embedding gradients, 19 M elements at C2) is exposed.  Gradients are summed; the
-1/world_size factor is folded into the fused AdamW kernel (`grad_scale`).  All ranks draw the same
-`t` (same python seed, train_transformer.py:11), hence identical NC/NT and no stragglers.
+Design.  Gradients live in two flat fp32 buffers laid out in layer order, so a bucket is a
+contiguous slice — no flatten / unflatten copies.  The HIP backward is split at bucket boundaries
+(mebt_backward_head / _layers / _embed); as soon as a bucket's gradients are final the reducer runs, per bucket,
+
+  mode "sharded" (default):   cast fp32 -> bf16 wire buffer            (HIP kernel, compute stream)
+                              reduce-scatter(sum) of the bf16 bucket   (RCCL, its own stream)     -> rank r holds shard r
+                              AdamW on shard r only                    (mebt_adamw_slice, optimizer stream; fp32 master,
+                                                                        m, v are touched by the owner alone: 1/N of the
+                                                                        10 GB the replicated optimizer streams per step)
+                              all-gather of the updated shard          (RCCL): the bf16 weight mirror for the Linear
+                                                                        weights, fp32 for the small non-Linear tail
+  mode "allreduce" (legacy):  all-reduce(sum) of the fp32 bucket, replicated bucket-wise AdamW (mebt_adamw_range)
+
+Everything after the cast overlaps the rest of backward; only the last bucket is exposed.  On the wire a step moves
+2 x 2 B per parameter (reduce-scatter + all-gather in bf16) instead of 2 x 4 B for the fp32 all-reduce; the gradient
+sum itself is taken in bf16 by RCCL (each rank's bucket was accumulated in fp32 locally and rounded once).  The
+1/world_size factor is folded into AdamW (`grad_scale`).  All ranks draw the same `t` (same python seed,
+train_transformer.py:11), hence identical NC/NT and no stragglers.
+
+In sharded bf16 mode the fp32 master copy of W is up to date only on the owning rank between steps (the compute path
+reads the bf16 mirror, which IS complete): `consolidate()` all-gathers the masters (and optionally the optimizer
+moments) before a checkpoint / state_dict.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
+class _Done:
+    """work handle of a collective that already completed (host-staged functional path)"""
+
+    def wait(self):
+        return True
+
+
 class GradReducer:
-    def __init__(self, world_size=None, group=None, layers_per_bucket=4):
+    def __init__(self, world_size=None, group=None, layers_per_bucket=4, mode=None, wire=None):
         self.group = group
         self.world_size = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = dist.get_rank(group) if (self.world_size > 1 and dist.is_initialized()) else 0
         self.grad_scale = 1.0 / self.world_size
         self.layers_per_bucket = layers_per_bucket
-        self.pending = []
-        self.bytes_reduced = 0
+        self.mode = mode or os.environ.get("MEBT_DP_MODE", "sharded")
+        self.wire = wire or os.environ.get("MEBT_DP_WIRE", "bf16")
+        assert self.mode in ("sharded", "allreduce") and self.wire in ("bf16", "fp32")
+        self.pending = []            # outstanding collectives the compute stream has to wait for
+        self.bytes_on_wire = 0       # payload bytes handed to collectives (per rank, per direction)
+        self.master_stale = False    # sharded + bf16 mirror: fp32 W is current only on the owner of each shard
+        self._wire_buf = {}
+        self._rs_out = {}
+        self._sharded_ranges = set()     # (which, start, end) of every bucket range that was cut into shards: what consolidate() gathers
+        self._inplace = not (self.world_size > 1 and dist.is_initialized() and dist.get_backend(group) != "nccl")
 
-    # called right after the kernels producing a bucket have been enqueued on the current stream
+    # ---- collectives -------------------------------------------------------------------------------------------------------
+    # RCCL: asynchronous, ordered after the current stream, in place where send and receive buffers alias.  A gloo group
+    # driving GPU tensors (functional runs of the N > 1 path with all ranks on one GPU: tests, MEBT_BENCH_SHARE_GPU) is
+    # staged through host memory synchronously — same arithmetic, no overlap.
+    def _staged(self, t):
+        return (not self._inplace) and t.is_cuda
+
+    def _reduce_scatter(self, out, inp):
+        if self._staged(inp):
+            ho = torch.empty(out.shape, dtype=out.dtype)
+            dist.reduce_scatter_tensor(ho, inp.cpu(), op=dist.ReduceOp.SUM, group=self.group)
+            out.copy_(ho)
+            return _Done()
+        return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _all_gather(self, full, mine):
+        if self._staged(full):
+            hf = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(hf, mine.cpu(), group=self.group)
+            full.copy_(hf)
+            return _Done()
+        return dist.all_gather_into_tensor(full, mine if self._inplace else mine.clone(), group=self.group, async_op=True)
+
+    # ---- bucket geometry ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def bucket_ranges(native, stage, hi, lo):
+        """[(which, start, end)] in the flat W (which = 0) / P (which = 1) buffers that `stage` finalised"""
+        if stage == "head":
+            a, b = native.head_w_range()
+            return [(0, a, b)]
+        if stage == "layers":
+            a, b = native.layer_w_range(hi, lo)
+            c, d = native.layer_p_range(hi, lo)
+            return [(0, a, b), (1, c, d)]
+        c, d = native.tail_p_range()            # 'embed': ln_f + embedding gradients are final
+        return [(1, c, d)]
+
+    # ---- legacy: bucketed fp32 all-reduce ---------------------------------------------------------------------------------
     def bucket_ready(self, native, stage, hi, lo):
         """Launch the asynchronous all-reduce(s) of the gradient slices that `stage` finalised; returns the
         list of work handles (empty when world_size == 1)."""
         if self.world_size == 1:
             return []
-        if stage == "head":
-            a, b = native.head_w_range()
-            views = [native.gW[a:b]]
-        elif stage == "layers":
-            a, b = native.layer_w_range(hi, lo)
-            c, d = native.layer_p_range(hi, lo)
-            views = [native.gW[a:b], native.gP[c:d]]
-        else:                       # 'embed': ln_f + embedding gradients are final
-            c, d = native.tail_p_range()
-            views = [native.gP[c:d]]
         works = []
-        for v in views:
+        for which, a, b in self.bucket_ranges(native, stage, hi, lo):
+            v = (native.gW if which == 0 else native.gP)[a:b]
             works.append(dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            self.bytes_reduced += v.numel() * v.element_size()
+            self.bytes_on_wire += v.numel() * v.element_size()
         self.pending += works
         return works
 
-    def wait(self):
-        """make the compute stream wait for every outstanding bucket (no host synchronisation on GPU)"""
+    # ---- sharded: reduce-scatter -> shard AdamW -> all-gather ----------------------------------------------------------------
+    def _buf(self, table, key, n, dtype, device):
+        t = table.get(key)
+        if t is None or t.numel() != n or t.dtype != dtype:
+            t = table[key] = torch.empty(n, dtype=dtype, device=device)
+        return t
+
+    def reduce_update(self, native, stage, hi, lo, lr, weight_decay, step, opt_stream=None, betas=(0.9, 0.95), eps=1e-8):
+        """One gradient bucket, start to finish (see the module docstring).  Call on the compute stream right after the
+        bucket's backward was enqueued; the optimizer and the all-gather run on `opt_stream`."""
+        world, rank = self.world_size, self.rank
+        gpu = native.gW.is_cuda
+        main = torch.cuda.current_stream() if gpu else None
+        for which, a, b in self.bucket_ranges(native, stage, hi, lo):
+            n = b - a
+            if n == 0:
+                continue
+            g = (native.gW if which == 0 else native.gP)[a:b]
+            if n % (4 * world):      # cannot be cut into aligned shards: replicate (all-reduce + full-range update)
+                w = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.bytes_on_wire += 2 * n * 4
+                self._on_opt(opt_stream, main, lambda: (w.wait(), native.adamw_slice(which, a, n, g, lr, weight_decay, step, betas=betas,
+                                                                                      eps=eps, grad_scale=self.grad_scale,
+                                                                                      stream=self._sid(opt_stream))))
+                continue
+            shard = n // world
+            sa = a + rank * shard
+            self._sharded_ranges.add((which, a, b))
+            if self.wire == "bf16":
+                wire = self._buf(self._wire_buf, (which, a, b), n, torch.bfloat16, g.device)
+                native.cast_bf16(g, wire)                                       # compute stream
+            else:
+                wire = g
+            out = self._buf(self._rs_out, (which, a, b), shard, wire.dtype, g.device)
+            w = self._reduce_scatter(out, wire)
+            self.bytes_on_wire += n * wire.element_size()
+            lowp = native.Wlp if which == 0 else None
+
+            def tail(w=w, which=which, a=a, b=b, sa=sa, shard=shard, out=out, lowp=lowp):
+                w.wait()                                                       # the optimizer stream waits for the reduce-scatter
+                native.adamw_slice(which, sa, shard, out, lr, weight_decay, step, betas=betas, eps=eps, grad_scale=self.grad_scale,
+                                   stream=self._sid(opt_stream))
+                full_t = lowp if lowp is not None else (native.W if which == 0 else native.P)
+                full, mine = full_t[a:b], full_t[sa:sa + shard]
+                self.pending.append(self._all_gather(full, mine))
+                self.bytes_on_wire += full.numel() * full.element_size()
+                if lowp is not None:
+                    self.master_stale = True
+
+            self._on_opt(opt_stream, main, tail)
+
+    @staticmethod
+    def _sid(stream):
+        return stream.cuda_stream if stream is not None else None
+
+    @staticmethod
+    def _on_opt(opt_stream, main, fn):
+        if opt_stream is None:
+            fn()
+            return
+        opt_stream.wait_stream(main)            # the bucket's gradients (and the cast) are enqueued on the compute stream
+        with torch.cuda.stream(opt_stream):
+            fn()
+
+    def finish(self, opt_stream=None):
+        """the compute stream waits for every outstanding collective and for the optimizer stream (no host sync on GPU)"""
         for w in self.pending:
             w.wait()
         self.pending = []
+        if opt_stream is not None:
+            torch.cuda.current_stream().wait_stream(opt_stream)
 
+    def wait(self):
+        self.finish()
+
+    # ---- parameters ----------------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, native, src=0):
         """DDP's start-up broadcast rank0 -> all"""
         if self.world_size == 1:
@@ -61,6 +191,24 @@ class GradReducer:
         dist.broadcast(native.P, src=src, group=self.group)
         if getattr(native, "Wlp", None) is not None:
             native.sync_lowp(force=True)
+
+    def consolidate(self, native, optimizer_state=False):
+        """Make the fp32 masters (and, on request, the AdamW moments) complete on every rank: after sharded steps each rank
+        holds the current values of its own shards only.  A collective: call on ALL ranks (before state_dict / a checkpoint)."""
+        if self.world_size == 1 or self.mode != "sharded":
+            return
+        world, rank = self.world_size, self.rank
+        tensors = [(0, native.W)] if self.master_stale else []
+        if optimizer_state and native.adam is not None:
+            mW, vW, mP, vP = native.adam
+            tensors += [(0, mW), (0, vW), (1, mP), (1, vP)]
+        for which_t, t in tensors:
+            for which, a, b in sorted(self._sharded_ranges):        # the same cuts the optimizer used (replicated buckets are complete)
+                if which != which_t:
+                    continue
+                shard = (b - a) // world
+                self._all_gather(t[a:b], t[a + rank * shard:a + (rank + 1) * shard]).wait()
+        self.master_stale = False
 
     def mean_scalars(self, t):
         """one small all-reduce for the logged scalars (the reference issues four: loss, acc1, acc5, lr)"""

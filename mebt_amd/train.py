@@ -105,6 +105,8 @@ def main():
                 dt = time.perf_counter() - t0
                 print(f"step {step + 1}: train/loss {s[0]:.4f} acc1 {s[1]:.2f} acc5 {s[2]:.2f} "
                       f"lr {model.learning_rate * model.lr_scale():.3e}  {dt / (step + 1 - start_step) * 1e3:.1f} ms/step", flush=True)
+        if args.ckpt_every and (step + 1) % args.ckpt_every == 0:
+            loop.consolidate()           # sharded optimizer: a collective on all ranks, then rank 0 writes
         if args.ckpt_every and rank == 0 and (step + 1) % args.ckpt_every == 0:
             os.makedirs(args.default_root_dir, exist_ok=True)
             torch.save({"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},

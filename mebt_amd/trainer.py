@@ -31,6 +31,8 @@ class TrainLoop:
         # (after its all-reduce when data-parallel): AdamW streams 30 B/parameter through HBM while the rest
         # of backward is latency/compute-bound, so the two overlap almost perfectly
         self.opt_stream = torch.cuda.Stream(device=self.native.device) if overlap_optimizer else None
+        if self.reducer.world_size > 1 and self.reducer.mode == "sharded":
+            self.native._adam_state()           # allocated up front: the first sharded update runs on the optimizer stream
         # one process, bf16: AdamW of the blocks' Linear weights is applied inside the weight-gradient launches of
         # backward (the gradient never goes to HBM and the optimizer traffic hides behind MFMA work); the all-reduce of a
         # data-parallel job needs the gradients first, so this is the single-GPU path only
@@ -83,6 +85,12 @@ class TrainLoop:
             nm.backward(logits, bwd_scale, between=lambda s, hi, lo: red.bucket_ready(nm, s, hi, lo))
             red.wait()
             nm.adamw_step(lr, m.weight_decay, self.step_count, grad_scale=red.grad_scale)
+        elif red.world_size > 1 and red.mode == "sharded":
+            # reduce-scatter -> AdamW on this rank's shard -> all-gather, bucket by bucket behind the backward (parallel.py)
+            opt = self.opt_stream
+            nm.backward(logits, bwd_scale, bucket_layers=red.layers_per_bucket,
+                        between=lambda s, hi, lo: red.reduce_update(nm, s, hi, lo, lr, m.weight_decay, self.step_count, opt_stream=opt))
+            red.finish(opt)                                         # the next forward reads the gathered weights
         else:
             main, opt = torch.cuda.current_stream(), self.opt_stream
 
@@ -102,6 +110,11 @@ class TrainLoop:
         m.trainer.global_step += 1
         m.global_step += 1
         return torch.cat([stats, (stats[0] * scale).reshape(1)])
+
+    def consolidate(self, optimizer_state=True):
+        """Data-parallel sharded optimizer: all-gather the fp32 masters (and moments) so that every rank — in particular
+        the one that writes the checkpoint — holds complete tensors.  A collective: call on all ranks."""
+        self.reducer.consolidate(self.native, optimizer_state=optimizer_state)
 
     # ---- resume (reference: trainer.fit(..., ckpt_path=...) restores optimizer, step counters and RNG) ---------------
     def state_dict(self):

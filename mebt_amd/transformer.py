@@ -367,6 +367,13 @@ class Net2NetTransformer(LightningModuleShim):
             return _GptFn.apply(self, sos_emb, contexts, targets)
         return nm.gpt_forward(sos_emb, contexts, targets)
 
+    def state_dict(self, *args, **kwargs):
+        red = self._reducer
+        if red is not None and getattr(red, "master_stale", False):
+            raise RuntimeError("data-parallel sharded optimizer: the fp32 master weights are complete only on their owning "
+                               "ranks; call TrainLoop.consolidate() on ALL ranks before state_dict() / saving a checkpoint")
+        return super().state_dict(*args, **kwargs)
+
     # ---- forward ----------------------------------------------------------------------------------------
     @torch.no_grad()
     def encode_to_z(self, x):

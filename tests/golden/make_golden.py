@@ -524,6 +524,90 @@ def gen_data_contract():
     save("data_contract", **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# 3D-VQGAN first stage: VQGAN.encode / VQGAN.decode of the real reference
+# ------------------------------------------------------------------------------------------------
+VQGAN_CONFIGS = {
+    # small: every layer kind at toy size ([1,3,4,16,16] -> [2,4,4]); channel counts 16/32/64 also exercise the kernels'
+    # non-MFMA path (Cin = 16)
+    "vq_micro": dict(n_hiddens=16, downsample=(2, 4, 4), embedding_dim=64, n_codes=512, video=(2, 3, 4, 16, 16)),
+    # BASELINE.json configs[4] geometry (TATS-style values recalled in SURVEY.md §8f: not in the reference repository, whose
+    # argparse defaults are 240 / (4,4,4) / 2048): [1,3,16,128,128] -> [1,4,16,16], 16384 codes of dimension 256
+    "vq_c5": dict(n_hiddens=32, downsample=(4, 8, 8), embedding_dim=256, n_codes=16384, video=(1, 3, 16, 128, 128)),
+}
+
+
+def vqgan_cfg(name):
+    from oracle import vqgan_oracle as vq
+    c = VQGAN_CONFIGS[name]
+    return vq.VQGANConfig(c["n_hiddens"], c["downsample"], 3, c["embedding_dim"], c["n_codes"])
+
+
+def vqgan_video(name):
+    """closed-form video in [-0.5, 0.5] (the reference's data range, data.py preprocess) with smooth structure + noise"""
+    B, C, T, H, W = VQGAN_CONFIGS[name]["video"]
+    u = cf.uniform01(f"vqgan-video/{name}", (B, C, T, H, W)).astype(np.float32)
+    t = np.linspace(0, 1, T, dtype=np.float32)[None, None, :, None, None]
+    y = np.linspace(0, 1, H, dtype=np.float32)[None, None, None, :, None]
+    xg = np.linspace(0, 1, W, dtype=np.float32)[None, None, None, None, :]
+    c = np.arange(C, dtype=np.float32)[None, :, None, None, None]
+    base = 0.3 * np.sin(6.0 * xg + 2.0 * c + 3.0 * t) * np.cos(5.0 * y - t)
+    return torch.from_numpy(np.clip(base + 0.4 * (u - 0.5), -0.5, 0.5).astype(np.float32))
+
+
+def build_reference_vqgan(name):
+    """the real mebt.vqgan.VQGAN with closed-form weights; LPIPS (torchvision VGG) is the only stand-in"""
+    import argparse
+    from oracle import vqgan_oracle as vq
+    mods = sys.modules["mebt.modules"]
+    if not hasattr(mods, "Codebook"):
+        import importlib
+        mods.Codebook = importlib.import_module("mebt.modules.codebook").Codebook
+
+        class LPIPS(nn.Module):            # perceptual loss network: training only, never touched by encode / decode
+            def forward(self, a, b):
+                raise RuntimeError("stub")
+        mods.LPIPS = LPIPS
+    from mebt.vqgan import VQGAN
+    c = VQGAN_CONFIGS[name]
+    args = argparse.Namespace(embedding_dim=c["embedding_dim"], n_codes=c["n_codes"], n_hiddens=c["n_hiddens"], downsample=c["downsample"],
+                              image_channels=3, norm_type="group", padding_type="replicate", no_random_restart=False, restart_thres=1.0,
+                              gan_feat_weight=0.0, disc_channels=64, disc_layers=3, disc_loss_type="hinge", image_gan_weight=1.0,
+                              video_gan_weight=1.0, perceptual_weight=0.0, l1_weight=4.0, sequence_length=c["video"][2],
+                              sample_every_n_frames=1, resolution=c["video"][3], lr=3e-4, discriminator_iter_start=50000)
+    model = VQGAN(args)
+    cfg = vqgan_cfg(name)
+    P = vq.closed_form_params(cfg)
+    missing, unexpected = model.load_state_dict(P, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith(("image_discriminator", "video_discriminator", "perceptual_model", "codebook.N", "codebook.z_avg")) for k in missing), missing
+    model.codebook._need_init = False      # transformer.py:186
+    return model.eval(), cfg, P
+
+
+def gen_vqgan():
+    """encode: token ids (complete) + the pre-quantisation z at fixed positions + the best / second-best distance of every
+    position (so that a consumer can tell an fp near-tie from a real mismatch); decode of fixed closed-form ids: the
+    video at fixed voxels + per-frame mean / mean-square."""
+    for name in VQGAN_CONFIGS:
+        model, cfg, P = build_reference_vqgan(name)
+        x = vqgan_video(name)
+        with torch.no_grad():
+            emb, ids = model.encode(x, include_embeddings=True)
+            z = model.pre_vq_conv(model.encoder(x))
+            flat = z.permute(0, 2, 3, 4, 1).reshape(-1, z.shape[1])
+            d = (flat ** 2).sum(1, keepdim=True) - 2 * flat @ model.codebook.embeddings.t() + (model.codebook.embeddings.t() ** 2).sum(0, keepdim=True)
+            best2 = torch.topk(d, 2, dim=1, largest=False).values
+            assert torch.equal(d.argmin(1).view(ids.shape), ids)
+            B, t_, h_, w_ = ids.shape
+            dec_ids = torch.from_numpy(cf.randint(f"vqgan-ids/{name}", (B, t_, h_, w_), cfg.n_codes))
+            rec = model.decode(dec_ids)
+        zi = cf.permutation(f"vqgan-zpos/{name}", flat.shape[0])[:64].copy()
+        vi = cf.permutation(f"vqgan-vox/{name}", rec.numel())[:4096].copy()
+        save(name, video_shape=np.array(x.shape), ids=ids, z_rows=zi, z_vals=flat[zi], best2=best2, emb_check=emb[0, :8, 0, 0, 0],
+             dec_ids=dec_ids, rec_idx=vi, rec_vals=rec.reshape(-1)[vi], rec_mean=rec.mean(dim=(0, 1, 3, 4)), rec_sq=(rec ** 2).mean(dim=(0, 1, 3, 4)))
+
+
 def _shared_step_with_t(model, x, idx, t):
     """shared_step (:717-732) with the python RNG draw `t` (:228) forced."""
     orig = random.random
@@ -545,6 +629,7 @@ def main():
     gen_train()
     gen_script_drivers()
     gen_data_contract()
+    gen_vqgan()
 
 
 if __name__ == "__main__":

@@ -342,7 +342,10 @@ def test_resume_equals_uninterrupted_training(tmp_path):
     for i in range(3, 6):
         lb.step(xs[i], idxs[i])
     for (k, p), (_, q) in zip(ref.state_dict().items(), b.state_dict().items()):
-        assert (p - q).abs().max().item() <= 1e-6 * (1 + p.abs().max().item()), k
+        # attn.key.bias has a mathematically zero gradient: AdamW normalises its rounding noise (atomic summation order)
+        # into +-lr steps, so it is only bounded, not reproduced
+        tol = 6 * 1e-3 if k.endswith("attn.key.bias") else 1e-6 * (1 + p.abs().max().item())
+        assert (p - q).abs().max().item() <= tol, k
     for u, v in zip(loop.native.adam, lb.native.adam):
         assert (u - v).abs().max().item() <= 1e-6 * (1e-3 + u.abs().max().item())
     # a run that restarts the counters (weights only) is NOT the same: the warm-up LR and bias correction restart
@@ -436,7 +439,7 @@ def test_gpt_forward_boundary_backward(dtype):
         sos, ctx, tgt = orc.embed(P, cfg, xx.reshape(2, -1), ci, ti)
     g = torch.Generator().manual_seed(4)
     w = torch.randn(2, ti.shape[1], 16384, generator=g) * 1e-2
-    ins = [t.clone().requires_grad_(True) for t in (sos, ctx, tgt)]
+    ins = [t.detach().clone().requires_grad_(True) for t in (sos, ctx, tgt)]
     ref = orc.gpt_forward(P, cfg, *ins)
     (ref * w).sum().backward()
     dev_ins = [t.detach().to(DEV).requires_grad_(True) for t in (sos, ctx, tgt)]

@@ -240,3 +240,118 @@ def test_sharded_sampler_equals_distributed_sampler():
     b = next(iter(dl))
     assert b["video"].shape == (3, 2, 4, 4) and b["indices"].shape == (3, 32) and b["video"].dtype == torch.int64
     assert sorted(b["indices"][0].tolist()) == list(range(32))
+
+
+def _dp_sharded_worker(rank, world, port, ret, wire):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mebt_amd.parallel import GradReducer
+        from mebt_amd.engine import flat_layout
+        torch.set_num_threads(1)
+        cfg = mg.oracle_cfg("micro")
+        P0 = orc.closed_form_params(cfg)
+        shapes = orc.param_shapes(cfg)
+        x, idx = mg.inputs("micro", 4, "dp")
+        per = 4 // world
+        xs, ids = x[rank * per:(rank + 1) * per], idx[rank * per:(rank + 1) * per]
+        Wn, Pn = flat_layout(cfg.n_layer)
+        lr, wd = 1e-3, 0.05
+
+        class FakeNative:            # the flat-buffer interface the reducer drives, with torch ops in place of the HIP kernels
+            n_layer, n_embd = cfg.n_layer, cfg.n_embd
+            def __init__(self):
+                self.W = torch.cat([P0[n].reshape(-1) for n in Wn]).clone()
+                self.P = torch.cat([P0[n].reshape(-1) for n in Pn]).clone()
+                self.Wlp = self.W.to(torch.bfloat16)
+                self.gW, self.gP = torch.zeros_like(self.W), torch.zeros_like(self.P)
+                self.adam = [torch.zeros_like(self.W), torch.zeros_like(self.W), torch.zeros_like(self.P), torch.zeros_like(self.P)]
+            def layer_w_range(self, hi, lo):
+                per_l = 12 * self.n_embd * self.n_embd
+                return lo * per_l, (hi + 1) * per_l
+            def head_w_range(self):
+                return self.n_layer * 12 * self.n_embd * self.n_embd, self.gW.numel()
+            def layer_p_range(self, hi, lo):
+                return lo * 13 * self.n_embd, (hi + 1) * 13 * self.n_embd
+            def tail_p_range(self):
+                return self.n_layer * 13 * self.n_embd, self.gP.numel()
+            def cast_bf16(self, src, dst):
+                dst.copy_(src)
+            def sync_lowp(self, force=False):
+                self.Wlp.copy_(self.W)
+            def adamw_slice(self, which, off, n, grad, lr, weight_decay, step, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0, stream=None):
+                p = (self.W if which == 0 else self.P)[off:off + n]
+                m_, v_ = self.adam[2 * which][off:off + n], self.adam[2 * which + 1][off:off + n]
+                orc.adamw_update(p, grad.float() * grad_scale, m_, v_, step, lr, weight_decay if which == 0 else 0.0, betas[0], betas[1], eps)
+                if which == 0:
+                    self.Wlp[off:off + n].copy_(p)
+        nat = FakeNative()
+        red = GradReducer(world_size=world, mode="sharded", wire=wire, layers_per_bucket=2)
+        red.broadcast_parameters(nat)
+        Pg = {k: v.clone().requires_grad_(True) for k, v in P0.items()}
+        logits, z_t, ntw, seq_len = orc.forward(Pg, cfg, xs, ids, 0.4, training=True)
+        _, _, loss = orc.loss_and_acc(logits, z_t, ntw, seq_len, cfg)
+        loss.backward()
+        nat.gW = torch.cat([Pg[n].grad.reshape(-1) for n in Wn])
+        nat.gP = torch.cat([Pg[n].grad.reshape(-1) for n in Pn])
+        red.reduce_update(nat, "head", None, None, lr, wd, 1)
+        hi = cfg.n_layer - 1
+        while hi >= 0:
+            lo = max(0, hi - 1)
+            red.reduce_update(nat, "layers", hi, lo, lr, wd, 1)
+            hi = lo - 1
+        red.reduce_update(nat, "embed", None, None, lr, wd, 1)
+        red.finish()
+        # between steps: the bf16 mirror and P are complete everywhere, the fp32 master of W only on its owners
+        mirror_ok = bool(torch.isfinite(nat.Wlp.float()).all())
+        stale = red.master_stale
+        W_before = nat.W.clone()
+        red.consolidate(nat, optimizer_state=True)
+        changed = int((nat.W != W_before).sum())
+        assert (nat.Wlp.float() - nat.W).abs().max() <= 8e-3 * nat.W.abs().max()      # mirror == bf16(master) after the gather
+        if rank == 1:
+            ret.put((nat.W.numpy().copy(), nat.P.numpy().copy(), nat.adam[0].numpy().copy(), nat.adam[3].numpy().copy(), stale,
+                     changed, mirror_ok, red.bytes_on_wire))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_data_parallel_sharded_optimizer_gloo_world2(wire):
+    """reduce-scatter -> AdamW on the owned shard -> all-gather (the default data-parallel path, parallel.py) on 2 ranks x
+    half batch == 1 process x full batch with the replicated optimizer: parameters and moments after one step, read on the
+    NON-zero rank after consolidate().  fp32 wire: to rounding; bf16 wire: every parameter within the +-lr step AdamW takes
+    at step 1, moments to bf16 resolution."""
+    import torch.multiprocessing as mp
+    from mebt_amd.engine import flat_layout
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + (7 if wire == "bf16" else 0)
+    procs = [ctx.Process(target=_dp_sharded_worker, args=(r, 2, port, ret, wire)) for r in range(2)]
+    for p in procs:
+        p.start()
+    W2, P2, mW2, vP2, stale, changed, mirror_ok, wire_bytes = ret.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = mg.oracle_cfg("micro")
+    x, idx = mg.inputs("micro", 4, "dp")
+    st = orc.TrainState(orc.closed_form_params(cfg), lr=1e-3, weight_decay=0.05)
+    r = orc.train_step(st, cfg, x, idx, 0.4)
+    Wn, Pn = flat_layout(cfg.n_layer)
+    Wref = np.concatenate([st.P[n].detach().numpy().reshape(-1) for n in Wn])
+    Pref = np.concatenate([st.P[n].detach().numpy().reshape(-1) for n in Pn])
+    mWref = np.concatenate([st.m[n].numpy().reshape(-1) for n in Wn])
+    vPref = np.concatenate([st.v[n].numpy().reshape(-1) for n in Pn])
+    assert stale and changed > 0 and mirror_ok            # rank 1 did NOT hold rank 0's shards of the fp32 master before consolidate
+    n_all = W2.size + P2.size
+    assert wire_bytes == (2 if wire == "bf16" else 4) * n_all + 2 * W2.size + 4 * P2.size    # reduce-scatter + all-gather payloads
+    if wire == "fp32":
+        assert np.allclose(W2, Wref, rtol=2e-4, atol=2e-6) and np.allclose(P2, Pref, rtol=2e-4, atol=2e-6)
+        assert np.allclose(mW2, mWref, rtol=1e-4, atol=1e-9) and np.allclose(vP2, vPref, rtol=1e-4, atol=1e-12)
+    else:
+        assert np.abs(W2 - Wref).max() <= 2.2e-3 and np.abs(P2 - Pref).max() <= 2.2e-3
+        assert (np.abs(W2 - Wref) > 2e-5).mean() < 0.02                     # sign flips of ~0 gradients only
+        assert np.abs(mW2 - mWref).max() <= 1.2e-2 * np.abs(mWref).max()

@@ -186,3 +186,32 @@ def test_flop_model_matches_survey():
     cfg = orc.OracleConfig(24, 16, 1024, 1024, 256,
                            ["latent_enc", "latent_self"] * 6 + ["latent_enc"] + ["latent_dec", "lt2l"] * 5 + ["latent_dec"])
     assert abs(orc.forward_flops_per_sample(cfg, 512, 512) / 1e9 - 234.881) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["vq_micro", "vq_c5"])
+def test_vqgan_oracle_matches_reference_golden(name):
+    """oracle/vqgan_oracle.py (encode / decode of the 3D-VQGAN first stage) against vectors produced by the real reference
+    `mebt.vqgan.VQGAN` (tests/golden/make_golden.py:gen_vqgan): token ids identical, pre-quantisation z and decoded video to
+    fp32 rounding."""
+    from oracle import vqgan_oracle as vq
+    from tests.golden import make_golden as mg
+    g = np.load(os.path.join(G, name + ".npz"))
+    cfg = mg.vqgan_cfg(name)
+    P = vq.closed_form_params(cfg)
+    x = mg.vqgan_video(name)
+    assert tuple(g["video_shape"]) == tuple(x.shape)
+    with torch.no_grad():
+        ids, z, d = vq.encode(P, cfg, x, return_all=True)
+        flat = z.permute(0, 2, 3, 4, 1).reshape(-1, z.shape[1])
+        rec = vq.decode(P, cfg, torch.from_numpy(g["dec_ids"]))
+    np.testing.assert_allclose(flat[g["z_rows"]].numpy(), g["z_vals"], rtol=1e-4, atol=2e-5)
+    best2 = torch.topk(d, 2, dim=1, largest=False).values.numpy()
+    np.testing.assert_allclose(best2, g["best2"], rtol=1e-5, atol=1e-3)
+    mism = (ids.numpy() != g["ids"])
+    gap = (g["best2"][:, 1] - g["best2"][:, 0]).reshape(ids.shape)
+    assert (gap[mism] < 1e-3).all() and mism.sum() <= 2                      # same code everywhere but at fp ties
+    assert ids.dtype == torch.int64 and tuple(ids.shape) == tuple(g["ids"].shape)
+    np.testing.assert_allclose(rec.reshape(-1)[g["rec_idx"]].numpy(), g["rec_vals"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(rec.mean(dim=(0, 1, 3, 4)).numpy(), g["rec_mean"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose((rec ** 2).mean(dim=(0, 1, 3, 4)).numpy(), g["rec_sq"], rtol=1e-4)
+    assert tuple(rec.shape) == tuple(g["video_shape"][:1]) + (3,) + tuple(g["video_shape"][2:])
