@@ -38,7 +38,7 @@ typedef struct mebt_model mebt_model;    /* opaque */
 
 enum mebt_status { MEBT_STATUS_OK = 0, MEBT_STATUS_EINVAL = 1, MEBT_STATUS_ESHAPE = 2, MEBT_STATUS_EHIP = 3,
                    MEBT_STATUS_EWORKSPACE = 4, MEBT_STATUS_EDTYPE = 5 };
-enum mebt_dtype { MEBT_DTYPE_F32 = 0, MEBT_DTYPE_BF16 = 1 };
+enum mebt_dtype { MEBT_DTYPE_F32 = 0, MEBT_DTYPE_BF16 = 1, MEBT_DTYPE_F16 = 2 /* 3D-VQGAN operators only */ };
 /* Block routing modes, reference mebt/modules/gpt.py:164-179 */
 enum mebt_mode { MEBT_MODE_LATENT_ENC = 0, MEBT_MODE_LATENT_SELF = 1, MEBT_MODE_LATENT_DEC = 2, MEBT_MODE_LT2L = 3,
                  MEBT_MODE_MASKGIT = 4 /* full attention over cat[contexts, targets]: the padding mode of gpt.py:176-178,191-192,208-209 */ };
@@ -176,6 +176,11 @@ int mebt_op_embed_fwd(int32_t dtype, const int64_t* x_ids, const int64_t* ci, co
  * as an explicit input: ids = argmax(p/noise), score = p[ids]; probs optional [rows,V]. */
 int mebt_op_sample(const float* logits, const float* noise, float temperature, int32_t top_k, float top_p, int64_t* ids,
                    float* score, float* probs, int32_t rows, int32_t V, mebt_stream_t stream);
+/* The same with q drawn INSIDE the kernel from a counter-based generator (element (row, e) of the step keyed by `seed`; CPU twin
+ * oracle/closed_form.py:exp1_counter): only the logits move through HBM.  The explicit-noise entry above stays the bit-exact
+ * interface for golden tests. */
+int mebt_op_sample_seeded(const float* logits, uint64_t seed, float temperature, int32_t top_k, float top_p, int64_t* ids,
+                          float* score, float* probs, int32_t rows, int32_t V, mebt_stream_t stream);
 /* x[b, ti[b,j]] = ids[b,j]  (the sparse_coo/to_dense/where scatter of transformer.py:413-439). */
 int mebt_op_scatter_ids(int64_t* x, const int64_t* ti, const int64_t* ids, int32_t B, int32_t N, int32_t NT,
                         mebt_stream_t stream);
@@ -191,6 +196,39 @@ int mebt_op_cast_bf16(const float* src, void* dst, int64_t n, mebt_stream_t stre
 /* 0: never time GEMM candidates (measured heuristic or cached choices only: no host synchronisation anywhere);
  * 1: tune unseen signatures at their first launch (default; environment MEBT_GEMM_AUTOTUNE). */
 void mebt_gemm_autotune(int32_t mode);
+
+/* ---- 3D-VQGAN first stage (reference mebt/vqgan.py:82-93,255-424, modules/codebook.py:52-62) ------------
+ * Activations are channels-last [B, T, H, W, C] of `dtype` (MEBT_DTYPE_F16: MFMA fast mode, MEBT_DTYPE_F32: parity mode); the
+ * video at the network boundary stays the reference's fp32 [B, C, T, H, W]. */
+#define MEBT_CONV_MAX_TAPS 64
+/* One (sub-lattice) convolution as an implicit GEMM.  Output voxel o = o' * os + pi for o' < (cT, cH, cW) reads, for tap j, the
+ * input voxel clamp(o' * sm + tap[j]) (replicate padding, SamePadConv3d vqgan.py:374-398).  A stride-2 transposed convolution
+ * (SamePadConvTranspose3d :401-424) is issued once per output parity class with the taps of that class.  w: [Cout][ntaps][Cin]
+ * of `dtype`; bias fp32 [Cout] or NULL; resid (optional) is added to the result (ResBlock x + h, :370), laid out like `out`. */
+typedef struct mebt_conv3d_desc {
+    const void* in; void* out; const void* w; const float* bias; const void* resid;
+    int32_t B, Ti, Hi, Wi, Cin, To, Ho, Wo, Cout;
+    int32_t cT, cH, cW;
+    int32_t os[3], pi[3], sm[3];
+    int32_t ntaps;
+    int8_t tap[MEBT_CONV_MAX_TAPS][4];
+    int32_t in_mode;    /* 0: channels-last `dtype`; 1: fp32 [B, C, T, H, W] */
+    int32_t out_mode;   /* 0: channels-last `dtype`; 1: channels-last fp32; 2: fp32 [B, C, T, H, W] */
+} mebt_conv3d_desc;
+/* allow_mfma = 0 forces the direct fp32-FMA kernel (the on-GPU reference of the MFMA kernel). */
+int mebt_op_conv3d(int32_t dtype, const mebt_conv3d_desc* d, int32_t allow_mfma, mebt_stream_t stream);
+/* y = silu(GroupNorm_32(x)), eps 1e-6 (vqgan.py:255-258,17-18); stats: scratch [B, 32, 2] fp32. */
+int mebt_op_groupnorm_silu(int32_t dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats, int32_t B,
+                           int64_t vox_per_sample, int32_t C, mebt_stream_t stream);
+/* ids[m] = argmin_j |z_m - e_j|^2 in the reference's evaluation order (codebook.py:54-58); z fp32 [M, d], embeddings fp32
+ * [n_codes, d]; score (scratch [M, n_codes] fp32) receives z E^T from the exact-fp32 MFMA GEMM, esq scratch [n_codes]. */
+int mebt_op_codebook_argmin(const float* z, const float* embeddings, float* score, float* esq, int64_t* ids, int32_t M,
+                            int32_t n_codes, int32_t d, mebt_stream_t stream);
+/* out[m, :] = embeddings[ids[m], :] (F.embedding of VQGAN.decode, vqgan.py:91), out of `dtype`. */
+int mebt_op_embedding_rows(int32_t dtype, const int64_t* ids, const float* embeddings, void* out, int64_t rows, int32_t d,
+                           int32_t n_codes, mebt_stream_t stream);
+/* fp32 -> fp16 cast of a flat buffer (n multiple of 4). */
+int mebt_op_cast_f16(const float* src, void* dst, int64_t n, mebt_stream_t stream);
 
 /* ---- instrumentation ----------------------------------------------------------------------------- */
 /* Per-kernel-family timing with HIP events on the launch stream (bench.py roofline): enable, run,

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmebt_hip.so")
 
 MEBT_MAX_LAYERS = 128
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_GELU_BWD = 0, 1, 2, 3
 MODE_IDS = {"latent_enc": 0, "latent_self": 1, "latent_dec": 2, "lt2l": 3, "maskgit": 4}
 
@@ -55,9 +55,15 @@ PROTOTYPES = {
     "mebt_op_attention_bwd": (c_i32, [c_i32] + [c_vp] * 10 + [c_i32] * 10 + [c_vp]),
     "mebt_op_embed_fwd": (c_i32, [c_i32] + [c_vp] * 10 + [c_i32] * 8 + [c_vp]),
     "mebt_op_sample": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "mebt_op_sample_seeded": (c_i32, [c_vp, C.c_uint64, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "mebt_op_scatter_ids": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "mebt_op_next_mask": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "mebt_op_cast_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "mebt_op_conv3d": (c_i32, [c_i32, c_vp, c_i32, c_vp]),
+    "mebt_op_groupnorm_silu": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "mebt_op_codebook_argmin": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "mebt_op_embedding_rows": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "mebt_op_cast_f16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "mebt_debug_dropout_mask": (c_i32, [C.c_uint64, C.c_uint32, c_f32, c_i64, c_vp, c_vp]),
     "mebt_debug_side_stream": (None, [c_vp, c_i32]),
     "mebt_debug_gemm_tile": (None, [c_i32, c_i32]),

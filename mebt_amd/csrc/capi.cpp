@@ -108,6 +108,17 @@ extern "C" int mebt_op_sample(const float* logits, const float* noise, float tem
     return launch_sample(p, S(stream));
 }
 
+// the same draw with the Exp(1) noise generated inside the kernel (counter-based, keyed by `seed`): the logits are the only
+// [rows, V] tensor that moves
+extern "C" int mebt_op_sample_seeded(const float* logits, uint64_t seed, float temperature, int32_t top_k, float top_p, int64_t* ids,
+                                     float* score, float* probs, int32_t rows, int32_t V, mebt_stream_t stream) {
+    if (!logits || !ids) { mebt_set_error("sample: null pointer"); return MEBT_EINVAL; }
+    SampleParams p;
+    p.logits = logits; p.noise = nullptr; p.noise_seed = seed; p.temperature = temperature; p.top_k = top_k; p.top_p = top_p; p.ids = ids;
+    p.score = score; p.probs = probs; p.rows = rows; p.V = V;
+    return launch_sample(p, S(stream));
+}
+
 extern "C" int mebt_op_scatter_ids(int64_t* x, const int64_t* ti, const int64_t* ids, int32_t B, int32_t N, int32_t NT, mebt_stream_t stream) {
     if (!x || !ti || !ids) { mebt_set_error("scatter_ids: null pointer"); return MEBT_EINVAL; }
     return launch_scatter_ids(x, ti, ids, B, N, NT, S(stream));

@@ -24,6 +24,16 @@ __device__ __forceinline__ float blk_max(float v, float* sh) {
     __syncthreads();
     return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
+// Counter-based Exp(1) draw for element `idx` of the step keyed by `seed`: 24 uniform bits of a 3-round multiply / xor-shift
+// hash -> u in (0, 1) -> -log(u).  Generated where it is consumed: the [rows, V] noise tensor of the explicit-noise entry
+// (written by a torch RNG kernel, then re-read) doubled the sampler's HBM bytes.  CPU twin: oracle/closed_form.py:exp1_counter.
+__device__ __forceinline__ float exp1_counter(uint64_t seed, uint64_t idx) {
+    uint32_t h = pair_hash(seed, 0x5A3B1Eu, idx);
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return -logf(u);
+}
 __device__ __forceinline__ uint32_t fkey(float f) {   // monotone float -> uint map
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -39,6 +49,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
     __shared__ unsigned int hist[256];
     __shared__ unsigned int sel_prefix, sel_k;
     __shared__ int sJ;
+    __shared__ double chunk_sum[256];
     const int tid = threadIdx.x, V = p.V, row = blockIdx.x;
     const float* lg = p.logits + (size_t)row * V;
     const float inv_t = 1.0f / (p.temperature + 1e-8f);
@@ -113,14 +124,27 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
                 }
                 __syncthreads();
             }
-        if (tid == 0) {   // sequential cumulative sum, same order as torch.cumsum over the sorted row
-            float c = 0.f;
+        // J = first j > 0 whose exclusive prefix sum of the sorted probabilities reaches top_p (everything from J on is
+        // dropped, :904-908).  Block scan: thread t owns the contiguous chunk [t c, (t+1) c) of the sorted order, chunk totals
+        // are prefixed in LDS, then every thread walks its chunk.  Accumulated in double and compared as float, like
+        // torch.cumsum on the CPU (acc_type<float> = double, result rounded to float); a one-thread loop over up to 16384
+        // dependent LDS reads took ~1 ms per row.
+        {
+            const int c = (nnz + 255) / 256;
+            const int j0 = min(tid * c, nnz), j1 = min(j0 + c, nnz);
+            double t = 0.0;
+            for (int j = j0; j < j1; ++j) t += (double)sv[si[j]];
+            chunk_sum[tid] = t;
+            if (tid == 0) sJ = nnz;
+            __syncthreads();
+            double acc = 0.0;
+            for (int k = 0; k < tid; ++k) acc += chunk_sum[k];            // exclusive prefix of the chunk totals (256 LDS reads, broadcast)
             int J = nnz;
-            for (int j = 0; j < nnz; ++j) {
-                if (j > 0 && c >= p.top_p) { J = j; break; }
-                c += sv[si[j]];
+            for (int j = j0; j < j1; ++j) {
+                if (j > 0 && (float)acc >= p.top_p) { J = j; break; }
+                acc += (double)sv[si[j]];
             }
-            sJ = J;
+            if (J < nnz) atomicMin(&sJ, J);
         }
         __syncthreads();
         for (int j = sJ + tid; j < nnz; j += 256) sv[si[j]] = 0.f;
@@ -136,12 +160,13 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
     float tot = 0.f;
     for (int e = tid; e < V; e += 256) tot += sv[e];
     tot = blk_sum(tot, sh);
-    const float* nz = p.noise + (size_t)row * V;
+    const float* nz = p.noise ? p.noise + (size_t)row * V : nullptr;
     float best = -1.f;
     int bi = V;
     for (int e = tid; e < V; e += 256) {
         const float pe = sv[e];
-        const float key = pe > 0.f ? (pe / tot) / nz[e] : 0.f;
+        const float q = nz ? nz[e] : exp1_counter(p.noise_seed, (uint64_t)row * V + e);
+        const float key = pe > 0.f ? (pe / tot) / q : 0.f;
         if (key > best || (key == best && e < bi)) { best = key; bi = e; }
     }
 #pragma unroll

@@ -1,0 +1,417 @@
+// 3D-VQGAN first stage on gfx950 (BASELINE.json configs[4]): the inference path of reference
+// mebt/vqgan.py:82-93 (VQGAN.encode / decode) — SamePadConv3d / SamePadConvTranspose3d (:374-424), GroupNorm(32, eps 1e-6) +
+// SiLU (:255-258, :17-18), ResBlock (:338-370), the nearest-codebook-entry search (modules/codebook.py:52-58) and the
+// embedding lookup of decode (:91).
+//
+// Layout: activations are channels-last [B, T, H, W, C] (fp16 in the fast mode, fp32 in the parity mode); the network
+// boundary (video in, video out) is the reference's fp32 [B, C, T, H, W], read / written directly by the first / last
+// convolution.  A convolution is an implicit GEMM: M = output voxels, N = Cout, K = taps x Cin, weights pre-arranged as
+// [Cout][tap][Cin] so that a K-slice of one tap is contiguous for both operands (an input row of Cin channels, a weight
+// row).  Replicate padding = clamping the gathered input coordinate.  A transposed convolution with stride 2 is run as
+// 2^k ordinary "sub-lattice" convolutions: the outputs of one parity class o = 2 o' + pi use a fixed subset of the taps
+// (k == (pi + 1) mod 2), so each class is an implicit GEMM with 1/8 (or 1/4) of the taps and no zero-stuffing.
+//
+// Kernels: conv3d_mfma_f16 (v_mfma_f32_16x16x32_f16, 128 x 64 x 32 tiles, register-staged double buffer; Cin % 32 == 0,
+// Cout % 64 == 0), conv3d_direct (any shape / dtype, fp32 FMA: the parity mode, the 3-channel first / last layers and odd
+// channel counts), group-norm statistics + normalise/SiLU, codebook distance arg-min on an exact-fp32 MFMA score matrix,
+// embedding rows.
+#include "common.h"
+#include "kernels.h"
+#include "../../include/mebt_hip.h"
+#include <string.h>
+
+namespace {
+
+typedef _Float16 f16_t;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld4<f16_t>(const f16_t* p) {
+    const f16x4 v = *reinterpret_cast<const f16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<f16_t>(f16_t* p, f32x4 v) {
+    const f16x4 o = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+    *reinterpret_cast<f16x4*>(p) = o;
+}
+
+__device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+// class-local voxel index -> (b, t', h', w')
+struct Vox { int b, t, h, w; };
+__device__ __forceinline__ Vox decode_vox(const mebt_conv3d_desc& p, long m) {
+    Vox v;
+    v.w = (int)(m % p.cW); m /= p.cW;
+    v.h = (int)(m % p.cH); m /= p.cH;
+    v.t = (int)(m % p.cT); v.b = (int)(m / p.cT);
+    return v;
+}
+// channels-last element offset of the input voxel tap `j` of output voxel v reads (replicate padding = clamp)
+__device__ __forceinline__ size_t in_voxel(const mebt_conv3d_desc& p, const Vox& v, int j) {
+    const int ti = clampi(v.t * p.sm[0] + p.tap[j][0], p.Ti - 1);
+    const int hi = clampi(v.h * p.sm[1] + p.tap[j][1], p.Hi - 1);
+    const int wi = clampi(v.w * p.sm[2] + p.tap[j][2], p.Wi - 1);
+    return (((size_t)v.b * p.Ti + ti) * p.Hi + hi) * p.Wi + wi;
+}
+__device__ __forceinline__ size_t out_voxel(const mebt_conv3d_desc& p, const Vox& v) {
+    const int t = v.t * p.os[0] + p.pi[0], h = v.h * p.os[1] + p.pi[1], w = v.w * p.os[2] + p.pi[2];
+    return (((size_t)v.b * p.To + t) * p.Ho + h) * p.Wo + w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct convolution: one thread per (output voxel, output channel), fp32 FMA chain over taps x Cin
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv3d_direct_kernel(const mebt_conv3d_desc p) {
+    const long total = (long)p.B * p.cT * p.cH * p.cW * p.Cout;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int co = (int)(idx % p.Cout);
+    const Vox v = decode_vox(p, idx / p.Cout);
+    float acc = p.bias ? p.bias[co] : 0.f;
+    const T* wrow = reinterpret_cast<const T*>(p.w) + (size_t)co * p.ntaps * p.Cin;
+    for (int j = 0; j < p.ntaps; ++j) {
+        if (p.in_mode == 1) {            // fp32 [B, C, T, H, W] (the video)
+            const int ti = clampi(v.t * p.sm[0] + p.tap[j][0], p.Ti - 1);
+            const int hi = clampi(v.h * p.sm[1] + p.tap[j][1], p.Hi - 1);
+            const int wi = clampi(v.w * p.sm[2] + p.tap[j][2], p.Wi - 1);
+            const size_t plane = (size_t)p.Ti * p.Hi * p.Wi;
+            const float* x = reinterpret_cast<const float*>(p.in) + (size_t)v.b * p.Cin * plane + ((size_t)ti * p.Hi + hi) * p.Wi + wi;
+            for (int ci = 0; ci < p.Cin; ++ci) acc += x[ci * plane] * (float)wrow[j * p.Cin + ci];
+        } else {
+            const T* x = reinterpret_cast<const T*>(p.in) + in_voxel(p, v, j) * p.Cin;
+            const T* wj = wrow + (size_t)j * p.Cin;
+            if ((p.Cin & 3) == 0) {
+                for (int ci = 0; ci < p.Cin; ci += 4) {
+                    const f32x4 a = ld4<T>(x + ci), b = ld4<T>(wj + ci);
+                    acc += a[0] * b[0]; acc += a[1] * b[1]; acc += a[2] * b[2]; acc += a[3] * b[3];
+                }
+            } else {
+                for (int ci = 0; ci < p.Cin; ++ci) acc += (float)x[ci] * (float)wj[ci];
+            }
+        }
+    }
+    const size_t ov = out_voxel(p, v);
+    if (p.resid) acc += (float)reinterpret_cast<const T*>(p.resid)[ov * p.Cout + co];
+    if (p.out_mode == 0) reinterpret_cast<T*>(p.out)[ov * p.Cout + co] = (T)acc;
+    else if (p.out_mode == 1) reinterpret_cast<float*>(p.out)[ov * p.Cout + co] = acc;
+    else {                                  // fp32 [B, C, T, H, W]
+        const size_t plane = (size_t)p.To * p.Ho * p.Wo;
+        const size_t bv = ov / plane, sp = ov % plane;
+        reinterpret_cast<float*>(p.out)[(bv * p.Cout + co) * plane + sp] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA implicit GEMM, fp16: C[m, n] = sum_{tap, ci} in[vox(m, tap), ci] * w[n][tap][ci]
+// ------------------------------------------------------------------------------------------------
+constexpr int CBM = 128, CBN = 64, CBK = 32, CLD = 40;      // LDS rows of 32 halfs padded to 40 (80 B): conflict-free b128 reads
+
+__global__ __launch_bounds__(256) void conv3d_mfma_f16_kernel(const mebt_conv3d_desc p) {
+    __shared__ __attribute__((aligned(16))) f16_t sA[2][CBM * CLD];
+    __shared__ __attribute__((aligned(16))) f16_t sB[2][CBN * CLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long Mcls = (long)p.B * p.cT * p.cH * p.cW;
+    const long m0 = (long)blockIdx.x * CBM;
+    const int n0 = blockIdx.y * CBN;
+    const f16_t* in = reinterpret_cast<const f16_t*>(p.in);
+    const f16_t* w = reinterpret_cast<const f16_t*>(p.w);
+    // loader roles: A chunks id = tid + 256 i (i < 2): row id >> 2, 16-byte chunk id & 3; B chunk: row tid >> 2, chunk tid & 3
+    Vox va[2];
+    int arow[2], ach[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 256 * i;
+        arow[i] = id >> 2; ach[i] = id & 3;
+        long m = m0 + arow[i];
+        if (m >= Mcls) m = Mcls - 1;
+        va[i] = decode_vox(p, m);
+    }
+    const int brow = tid >> 2, bch = tid & 3;
+    const f16_t* wrow = w + (size_t)(n0 + brow) * p.ntaps * p.Cin + bch * 8;
+    const int kc = p.Cin / CBK;                     // channel chunks per tap
+    const int nk = p.ntaps * kc;
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[2], rb;
+    size_t abase[2] = {0, 0};
+    auto gload = [&](int kk) {
+        const int j = kk / kc, c0 = (kk % kc) * CBK;
+        if (kk % kc == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) abase[i] = in_voxel(p, va[i], j) * p.Cin;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const u32x4*>(in + abase[i] + c0 + ach[i] * 8);
+        rb = *reinterpret_cast<const u32x4*>(wrow + (size_t)j * p.Cin + c0);
+    };
+    auto lstore = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&sA[s][arow[i] * CLD + ach[i] * 8]) = ra[i];
+        *reinterpret_cast<u32x4*>(&sB[s][brow * CLD + bch * 8]) = rb;
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int fr = lane & 15, fc = (lane >> 4) * 8;
+    for (int kk = 0; kk < nk; ++kk) {
+        const int s = kk & 1;
+        if (kk + 1 < nk) gload(kk + 1);
+        f16x8 af[2], bf[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f16x8*>(&sA[s][(32 * wave + 16 * i + fr) * CLD + fc]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8*>(&sB[s][(16 * j + fr) * CLD + fc]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        if (kk + 1 < nk) lstore(s ^ 1);
+        __syncthreads();
+    }
+    // D^T = B A^T: lane holds row (lane & 15) of row block i, columns 16 j + 4 (lane >> 4) .. + 3
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long m = m0 + 32 * wave + 16 * i + fr;
+        if (m >= Mcls) continue;
+        const size_t ov = out_voxel(p, decode_vox(p, m));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 16 * j + 4 * (lane >> 4);
+            f32x4 v = acc[i][j];
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.resid) v += ld4<f16_t>(reinterpret_cast<const f16_t*>(p.resid) + ov * p.Cout + n);
+            if (p.out_mode == 1) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + ov * p.Cout + n) = v;
+            else st4<f16_t>(reinterpret_cast<f16_t*>(p.out) + ov * p.Cout + n, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm (32 groups, eps 1e-6) + SiLU, channels-last
+// ------------------------------------------------------------------------------------------------
+// pass 1: stats[b][g] = {sum, sum of squares}.  A workgroup takes a slab of voxels of one sample: thread = 4 consecutive
+// channels of every (256 / (C/4))-th row, per-channel partial sums in registers -> LDS -> one atomic pair per group.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* x, float* stats, long vox_per_sample, int C, int rows_per_block) {
+    __shared__ float red[2][256 * 4];
+    const int b = blockIdx.y;
+    const int lanes_per_row = C / 4, rows_par = 256 / lanes_per_row;
+    const int cl = threadIdx.x % lanes_per_row, rl = threadIdx.x / lanes_per_row;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < vox_per_sample ? r0 + rows_per_block : vox_per_sample;
+    f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+    if (rl < rows_par)
+        for (long r = r0 + rl; r < r1; r += rows_par) {
+            const f32x4 v = ld4<T>(x + ((size_t)b * vox_per_sample + r) * C + cl * 4);
+            s += v; q += v * v;
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][threadIdx.x * 4 + j] = s[j]; red[1][threadIdx.x * 4 + j] = q[j]; }
+    __syncthreads();
+    // thread c < C: total of channel c over the row lanes, then per group (C/32 consecutive channels)
+    const int cpg = C / 32;
+    if ((int)threadIdx.x < 32) {
+        const int g = threadIdx.x;
+        float gs = 0.f, gq = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const int lane_c = c / 4, j = c % 4;
+            for (int r = 0; r < rows_par; ++r) {
+                gs += red[0][(r * lanes_per_row + lane_c) * 4 + j];
+                gq += red[1][(r * lanes_per_row + lane_c) * 4 + j];
+            }
+        }
+        atomicAdd(stats + ((size_t)b * 32 + g) * 2, gs);
+        atomicAdd(stats + ((size_t)b * 32 + g) * 2 + 1, gq);
+    }
+}
+// pass 2: y = silu((x - mean_g) * rstd_g * gamma_c + beta_c)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_silu_kernel(const T* x, T* y, const float* stats, const float* gamma, const float* beta,
+                                                            long vox_per_sample, int C, long total4) {
+    const int cpg = C / 32;
+    const float inv_n = 1.0f / ((float)vox_per_sample * cpg);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long e = i * 4;
+        const int c = (int)(e % C);
+        const long b = e / ((long)vox_per_sample * C);
+        const f32x4 v = ld4<T>(x + e);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + c), b4 = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (c + j) / cpg;
+            const float sum = stats[((size_t)b * 32 + g) * 2], sq = stats[((size_t)b * 32 + g) * 2 + 1];
+            const float mean = sum * inv_n;
+            const float var = fmaxf(sq * inv_n - mean * mean, 0.f);
+            const float h = (v[j] - mean) * rsqrtf(var + 1e-6f) * g4[j] + b4[j];
+            o[j] = h / (1.0f + __expf(-h));
+        }
+        st4<T>(y + e, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// codebook: ids[m] = argmin_j (|z_m|^2 - 2 z_m . e_j) + |e_j|^2, evaluated in the reference's order (codebook.py:54-58)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* e, float* out, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int k = lane; k < d; k += 64) { const float v = e[(size_t)row * d + k]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+__global__ __launch_bounds__(256) void codebook_argmin_kernel(const float* score /*[M, n_codes] = z E^T*/, const float* z, const float* esq,
+                                                              int64_t* ids, int n_codes, int d) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ float szz;
+    const int m = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (wv == 0) {
+        float s = 0.f;
+        for (int k = lane; k < d; k += 64) { const float v = z[(size_t)m * d + k]; s += v * v; }
+        s = wave_sum(s);
+        if (lane == 0) szz = s;
+    }
+    __syncthreads();
+    const float zz = szz;
+    float best = INFINITY;
+    int bi = 0x7FFFFFFF;
+    for (int j = threadIdx.x; j < n_codes; j += 256) {
+        const float dist = (zz - 2.0f * score[(size_t)m * n_codes + j]) + esq[j];
+        if (dist < best) { best = dist; bi = j; }          // ascending j per thread: the first minimum is kept
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { sv[wv] = best; si[wv] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k)
+            if (sv[k] < best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        ids[m] = bi;
+    }
+}
+
+// decode: out[m, :] = E[ids[m], :]  (F.embedding, vqgan.py:91), channels-last
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_rows_kernel(const int64_t* ids, const float* e, T* out, long rows, int d, int n_codes) {
+    const int d4 = d / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * d4; i += (long)gridDim.x * 256) {
+        const long r = i / d4;
+        const int c = (int)(i % d4) * 4;
+        long id = ids[r];
+        id = id < 0 ? 0 : (id >= n_codes ? n_codes - 1 : id);
+        st4<T>(out + (size_t)r * d + c, *reinterpret_cast<const f32x4*>(e + (size_t)id * d + c));
+    }
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* src, TD* dst, size_t n) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) st4<TD>(dst + i, ld4<TS>(src + i));
+}
+
+}  // namespace
+
+static hipStream_t S(mebt_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static bool is_f16(int dtype) { return dtype == MEBT_DTYPE_F16; }
+
+extern "C" int mebt_op_conv3d(int32_t dtype, const mebt_conv3d_desc* d, int32_t allow_mfma, mebt_stream_t stream) {
+    if (!d || !d->in || !d->out || !d->w) { mebt_set_error("conv3d: null pointer"); return MEBT_EINVAL; }
+    if (dtype != MEBT_DTYPE_F32 && dtype != MEBT_DTYPE_F16) { mebt_set_error("conv3d: dtype must be f32 or f16"); return MEBT_EDTYPE; }
+    const mebt_conv3d_desc& p = *d;
+    if (p.ntaps < 1 || p.ntaps > MEBT_CONV_MAX_TAPS || p.Cin < 1 || p.Cout < 1) { mebt_set_error("conv3d: bad tap / channel count"); return MEBT_ESHAPE; }
+    const long mcls = (long)p.B * p.cT * p.cH * p.cW;
+    if (mcls <= 0) return MEBT_OK;
+    const bool mfma = allow_mfma && is_f16(dtype) && p.in_mode == 0 && p.out_mode != 2 && p.Cin % CBK == 0 && p.Cout % CBN == 0;
+    if (mfma) {
+        const dim3 grid((unsigned)((mcls + CBM - 1) / CBM), p.Cout / CBN);
+        hipLaunchKernelGGL(conv3d_mfma_f16_kernel, grid, dim3(256), 0, S(stream), p);
+    } else {
+        const long total = mcls * p.Cout;
+        const dim3 grid((unsigned)((total + 255) / 256));
+        if (is_f16(dtype)) hipLaunchKernelGGL(conv3d_direct_kernel<f16_t>, grid, dim3(256), 0, S(stream), p);
+        else hipLaunchKernelGGL(conv3d_direct_kernel<float>, grid, dim3(256), 0, S(stream), p);
+    }
+    MEBT_HIP_CHECK(hipGetLastError());
+    return MEBT_OK;
+}
+
+extern "C" int mebt_op_groupnorm_silu(int32_t dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats,
+                                      int32_t B, int64_t vox_per_sample, int32_t C, mebt_stream_t stream) {
+    if (!x || !y || !gamma || !beta || !stats) { mebt_set_error("groupnorm: null pointer"); return MEBT_EINVAL; }
+    if (C % 32 || C > 1024 || (C / 4) > 256) { mebt_set_error("groupnorm: channels must be a multiple of 32 (32 groups) and <= 1024"); return MEBT_ESHAPE; }
+    if (dtype != MEBT_DTYPE_F32 && dtype != MEBT_DTYPE_F16) { mebt_set_error("groupnorm: dtype must be f32 or f16"); return MEBT_EDTYPE; }
+    if (B <= 0 || vox_per_sample <= 0) return MEBT_OK;
+    MEBT_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)B * 32 * 2 * 4, S(stream)));
+    int rpb = 64;
+    while ((vox_per_sample + rpb - 1) / rpb > 512) rpb *= 2;               // <= 512 adders per statistic
+    const dim3 grid((unsigned)((vox_per_sample + rpb - 1) / rpb), B);
+    const long total4 = (long)B * vox_per_sample * C / 4;
+    const unsigned ablocks = (unsigned)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+    if (is_f16(dtype)) {
+        hipLaunchKernelGGL(gn_stats_kernel<f16_t>, grid, dim3(256), 0, S(stream), (const f16_t*)x, stats, (long)vox_per_sample, C, rpb);
+        hipLaunchKernelGGL(gn_apply_silu_kernel<f16_t>, dim3(ablocks), dim3(256), 0, S(stream), (const f16_t*)x, (f16_t*)y, stats, gamma, beta, (long)vox_per_sample, C, total4);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, S(stream), (const float*)x, stats, (long)vox_per_sample, C, rpb);
+        hipLaunchKernelGGL(gn_apply_silu_kernel<float>, dim3(ablocks), dim3(256), 0, S(stream), (const float*)x, (float*)y, stats, gamma, beta, (long)vox_per_sample, C, total4);
+    }
+    MEBT_HIP_CHECK(hipGetLastError());
+    return MEBT_OK;
+}
+
+// ids[m] = nearest codebook entry of z[m, :] (fp32 [M, d]).  `score` is caller-provided scratch [M, n_codes] fp32 for
+// z E^T (exact-fp32 MFMA: the search is never run at reduced precision), `esq` scratch [n_codes].
+extern "C" int mebt_op_codebook_argmin(const float* z, const float* embeddings, float* score, float* esq, int64_t* ids, int32_t M,
+                                       int32_t n_codes, int32_t d, mebt_stream_t stream) {
+    if (!z || !embeddings || !score || !esq || !ids) { mebt_set_error("codebook: null pointer"); return MEBT_EINVAL; }
+    if (M <= 0) return MEBT_OK;
+    if (d % 16 || n_codes % 4) { mebt_set_error("codebook: embedding_dim must be a multiple of 16 and n_codes of 4"); return MEBT_ESHAPE; }
+    if (int rc = gemm_init_attributes()) return rc;
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.A = z; g.B = embeddings; g.C = score; g.M = M; g.N = n_codes; g.K = d; g.lda = d; g.ldb = d; g.ldc = n_codes;
+    g.a_kc = 1; g.b_kc = 1; g.c_f32 = 1; g.split_k = 1;
+    if (int rc = launch_gemm(g, MEBT_F32, S(stream))) return rc;
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n_codes + 3) / 4), dim3(256), 0, S(stream), embeddings, esq, n_codes, d);
+    hipLaunchKernelGGL(codebook_argmin_kernel, dim3(M), dim3(256), 0, S(stream), score, z, esq, ids, n_codes, d);
+    MEBT_HIP_CHECK(hipGetLastError());
+    return MEBT_OK;
+}
+
+extern "C" int mebt_op_embedding_rows(int32_t dtype, const int64_t* ids, const float* embeddings, void* out, int64_t rows, int32_t d,
+                                      int32_t n_codes, mebt_stream_t stream) {
+    if (!ids || !embeddings || !out) { mebt_set_error("embedding_rows: null pointer"); return MEBT_EINVAL; }
+    if (d % 4) { mebt_set_error("embedding_rows: d must be a multiple of 4"); return MEBT_ESHAPE; }
+    if (rows <= 0) return MEBT_OK;
+    const long n4 = rows * (d / 4);
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    if (is_f16(dtype)) hipLaunchKernelGGL(embedding_rows_kernel<f16_t>, dim3(blocks), dim3(256), 0, S(stream), ids, embeddings, (f16_t*)out, (long)rows, d, n_codes);
+    else if (dtype == MEBT_DTYPE_F32) hipLaunchKernelGGL(embedding_rows_kernel<float>, dim3(blocks), dim3(256), 0, S(stream), ids, embeddings, (float*)out, (long)rows, d, n_codes);
+    else { mebt_set_error("embedding_rows: dtype must be f32 or f16"); return MEBT_EDTYPE; }
+    MEBT_HIP_CHECK(hipGetLastError());
+    return MEBT_OK;
+}
+
+// fp32 -> fp16 of a flat buffer (weights of the fast mode), n % 4 == 0
+extern "C" int mebt_op_cast_f16(const float* src, void* dst, int64_t n, mebt_stream_t stream) {
+    if (!src || !dst || n < 0 || (n % 4)) { mebt_set_error("cast_f16: bad arguments"); return MEBT_EINVAL; }
+    if (!n) return MEBT_OK;
+    const size_t blocks = ((size_t)n / 4 + 255) / 256;
+    hipLaunchKernelGGL((cast_kernel<float, f16_t>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, S(stream), src, (f16_t*)dst, (size_t)n);
+    MEBT_HIP_CHECK(hipGetLastError());
+    return MEBT_OK;
+}

@@ -35,11 +35,36 @@ class LightningModuleShim(nn.Module):
         return torch.device("cpu")
 
     @classmethod
-    def load_from_checkpoint(cls, path, map_location="cpu", **overrides):
-        """Lightning checkpoint format: {'state_dict', 'hyper_parameters', ...} (download.py:56-61)."""
-        ckpt = torch.load(path, map_location=map_location, weights_only=False)
-        hp = dict(ckpt.get("hyper_parameters", {}))
+    def load_from_checkpoint(cls, path, map_location="cpu", strict=False, **overrides):
+        """Lightning checkpoint format (download.py:56-61): {'state_dict', 'hyper_parameters', 'global_step', 'epoch',
+        'pytorch-lightning_version', ...}.  `hyper_parameters` holds the constructor arguments `save_hyperparameters()`
+        recorded (transformer.py:146): config nodes arrive as plain nested dicts (or anything dict-like) and are wrapped
+        into attribute-access configs; Lightning's bookkeeping keys are ignored.  A checkpoint that pickles OmegaConf
+        objects needs `omegaconf` importable to be unpickled at all — that failure is reported as such."""
+        from .config import AttrDict
+        try:
+            ckpt = torch.load(path, map_location=map_location, weights_only=False)
+        except ModuleNotFoundError as e:
+            raise RuntimeError(f"{path} pickles objects of the module '{e.name}', which is not installed here: install it, or "
+                               "re-save the checkpoint with `hyper_parameters` as plain nested dicts") from e
+
+        def wrap(v):
+            if isinstance(v, AttrDict):
+                return v
+            if isinstance(v, dict) or (hasattr(v, "keys") and hasattr(v, "__getitem__")):
+                return AttrDict({k: wrap(v[k]) for k in v.keys()})
+            if isinstance(v, (list, tuple)) and not isinstance(v, str):
+                return [wrap(i) for i in v]
+            return v
+
+        import inspect
+        accepted = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        hp = {k: wrap(v) for k, v in dict(ckpt.get("hyper_parameters", {})).items() if k in accepted}
         hp.update(overrides)
+        hp.pop("ckpt_path", None)                  # the weights come from THIS file, not from a path recorded at training time
         model = cls(**hp)
-        model.load_state_dict(ckpt["state_dict"], strict=False)
+        model.load_state_dict(ckpt["state_dict"], strict=strict)
+        model.global_step = int(ckpt.get("global_step", 0))
+        model.current_epoch = int(ckpt.get("epoch", 0))
+        model.trainer.global_step = model.global_step
         return model

@@ -292,13 +292,24 @@ class Net2NetTransformer(LightningModuleShim):
         print(f"Restored from {path}")
 
     def init_first_stage_from_ckpt(self, config):
-        """reference :180-192.  The 3D-VQGAN first stage is outside this hot path:
-        with `vtokens: True` the batch carries token grids and no first stage exists; with `vtokens:
-        False` the model is still constructible (so the shipped YAMLs load unchanged) but only accepts
-        int64 token grids — pixel videos raise in encode_to_z."""
+        """reference :180-192.  `vtokens: True`: the batch carries token grids, no first stage, vocabulary forced to 16384.
+        `vtokens: False`: the 3D-VQGAN first stage (mebt_amd/vqgan.py on the HIP operators) is loaded from
+        `config.params.ckpt_path`, frozen, and its codebook size is the vocabulary; without a checkpoint path the model is
+        still constructible (token grids only) and a first stage can be attached later (`model.first_stage_model = VQGAN(...)`)."""
         self.first_stage_model = None
         if self.vtokens:
             self.first_stage_vocab_size = 16384                                    # reference :192
+            return
+        ckpt = config.params.ckpt_path if (_cfg_has(config, "params") and _cfg_has(config.params, "ckpt_path")) else None
+        if ckpt is not None:
+            from .vqgan import load_vqgan
+            fs = load_vqgan(ckpt)
+            for p in fs.parameters():
+                p.requires_grad = False
+            fs.eval()
+            fs.train = disabled_train.__get__(fs)                                  # reference :188
+            self.first_stage_model = fs
+            self.first_stage_vocab_size = fs.codebook.n_codes                      # reference :189
         else:
             self.first_stage_vocab_size = self.config.first_stage_vocab_size if _cfg_has(self.config, "first_stage_vocab_size") else self.config.vocab_size
 
@@ -313,7 +324,8 @@ class Net2NetTransformer(LightningModuleShim):
 
     # ---- engine plumbing ------------------------------------------------------------------------------
     def _param_dict(self):
-        return dict(self.named_parameters())
+        """the transformer's own parameters (the frozen first stage, when present, is a separate engine: mebt_amd/vqgan.py)"""
+        return {k: v for k, v in self.named_parameters() if not k.startswith("first_stage_model.")}
 
     def _ensure_native(self):
         dev = self.tok_emb.weight.device
@@ -377,11 +389,19 @@ class Net2NetTransformer(LightningModuleShim):
     # ---- forward ----------------------------------------------------------------------------------------
     @torch.no_grad()
     def encode_to_z(self, x):
-        """reference :683-694; only the token-grid branch exists here"""
-        if x.dtype != torch.long:
-            raise NotImplementedError("pixel-space input needs the 3D-VQGAN first stage, which is outside this "
-                                      "hot path; pass int64 token grids [B,T,H,W] (config vtokens: True)")
-        return x, x.reshape(x.shape[0], -1)
+        """reference :683-694: token grids pass through (`vtokens`); pixel videos [B,C,T,H,W] go through the first stage's
+        encoder + codebook search -> (quantised embeddings [B,t,h,w,c], token ids [B, t*h*w])"""
+        if x.dtype == torch.long:
+            return x, x.reshape(x.shape[0], -1)
+        if self.first_stage_model is None:
+            raise NotImplementedError("pixel-space input needs the 3D-VQGAN first stage: build the model with vtokens: False and "
+                                      "a first-stage checkpoint (or attach model.first_stage_model = mebt_amd.vqgan.VQGAN(args)), "
+                                      "or pass int64 token grids [B,T,H,W]")
+        emb, targets = self.first_stage_model.encode(x, include_embeddings=True)
+        if self.sample_every_n_latent_frames > 0:
+            emb = emb[:, :, ::self.sample_every_n_latent_frames]
+            targets = targets[:, ::self.sample_every_n_latent_frames]
+        return emb.permute(0, 2, 3, 4, 1), targets.reshape(targets.shape[0], -1).contiguous()
 
     def _draw_t(self, debug):
         """reference :225-241: ONE scalar t per step from the python RNG (or the beta schedule)"""
@@ -532,6 +552,9 @@ class Net2NetTransformer(LightningModuleShim):
     def _sample_tokens(self, logits, temperature, top_k, top_p, want_probs=False):
         """sample_from_logits (:843-889) + score gather (:409) in one kernel -> (ids, scores, probs?)"""
         B, NT, V = logits.shape
+        if self.noise_hook is None:      # production: Exp(1) generated inside the kernel, seeded from torch's default generator
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            return sample_from_logits_scored(logits, temperature, top_k, top_p, None, want_probs, seed=seed)
         noise = self._noise("exp", (B, NT, V), logits.device)
         return sample_from_logits_scored(logits, temperature, top_k, top_p, noise, want_probs)
 
@@ -651,14 +674,22 @@ class Net2NetTransformer(LightningModuleShim):
 
 
 # ---- module-level sampler helpers (reference :826-910) -----------------------------------------------------
-def sample_from_logits_scored(logits, temperature, top_k, top_p, noise, want_probs=False):
+def sample_from_logits_scored(logits, temperature, top_k, top_p, noise, want_probs=False, seed=None):
     """ids = argmax(p/noise), scores = p[ids] (and optionally p) in ONE kernel; p is the distribution
-    after temperature / top-k / top-p (reference :859-874)."""
+    after temperature / top-k / top-p (reference :859-874).  noise = None: q ~ Exp(1) is drawn inside the kernel from the
+    counter-based generator keyed by `seed` (no [rows, V] noise tensor through HBM)."""
     shape = logits.shape[:-1]
     V = logits.shape[-1]
     lg = logits.to(torch.float32).contiguous().view(-1, V)
-    nz = noise.to(torch.float32).contiguous().view(-1, V)
     R = lg.shape[0]
+    if noise is None:
+        ids = torch.empty(R, dtype=torch.long, device=lg.device)
+        score = torch.empty(R, dtype=torch.float32, device=lg.device)
+        probs = torch.empty(R, V, dtype=torch.float32, device=lg.device) if want_probs else None
+        _lib.check(_lib.load().mebt_op_sample_seeded(_lib.ptr(lg), int(seed or 0), float(temperature), int(top_k or 0), float(top_p or 0.0),
+                                                     _lib.ptr(ids), _lib.ptr(score), _lib.ptr(probs), R, V, _lib.cur_stream()))
+        return ids.view(shape), score.view(shape), (probs.view(*shape, V) if want_probs else None)
+    nz = noise.to(torch.float32).contiguous().view(-1, V)
     ids = torch.empty(R, dtype=torch.long, device=lg.device)
     score = torch.empty(R, dtype=torch.float32, device=lg.device)
     probs = torch.empty(R, V, dtype=torch.float32, device=lg.device) if want_probs else None
@@ -670,9 +701,8 @@ def sample_from_logits_scored(logits, temperature, top_k, top_p, noise, want_pro
 
 def sample_from_logits(logits, temperature=1.0, top_k=None, top_p=None, return_probs=False, noise=None):
     """reference :843-889 (same signature + an optional explicit `noise` tensor of Exp(1) draws)"""
-    if noise is None:
-        noise = torch.empty_like(logits, dtype=torch.float32).exponential_()
-    ids, _, probs = sample_from_logits_scored(logits, temperature, top_k, top_p, noise, want_probs=return_probs)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else None
+    ids, _, probs = sample_from_logits_scored(logits, temperature, top_k, top_p, noise, want_probs=return_probs, seed=seed)
     return (ids, probs) if return_probs else ids
 
 

@@ -106,3 +106,22 @@ def param_value(name, shape):
 def state_dict_numpy(shapes):
     """shapes: {name: shape} -> {name: float32 array}."""
     return {k: param_value(k, tuple(v)) for k, v in shapes.items()}
+
+
+def exp1_counter(seed, rows, V):
+    """CPU twin of the in-kernel Exp(1) generator of the sampler (mebt_amd/csrc/sampler.hip:exp1_counter): element (row, e)
+    hashes the 64-bit counter row * V + e with the 64-bit seed (3 multiply / xor-shift rounds on 32 bits), 24 bits -> u in
+    (0, 1) -> -log(u).  The uniform bits are reproduced exactly; the logarithm to float32 rounding."""
+    idx = np.arange(rows * V, dtype=np.uint64)
+    seed = np.uint64(seed)
+    M = np.uint64(0xFFFFFFFF)
+    lo, hi = idx & M, idx >> np.uint64(32)
+    h = ((lo ^ (seed & M)) + ((hi + np.uint64(0x5A3B1E)) & M) * np.uint64(0x632BE5AB) + (seed >> np.uint64(32))) & M
+    h = (h * np.uint64(0x9E3779B1)) & M
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x85EBCA77)) & M
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & M
+    h ^= h >> np.uint64(16)
+    u = ((h >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    return (-np.log(u.astype(np.float64))).astype(np.float32).reshape(rows, V)

@@ -156,11 +156,14 @@ def test_gemm_splitk_slabs_with_epilogues(tile, variant, b_kc):
     bias = rnd(N, seed=8)
     aux = q(rnd(M, N, seed=9), _lib.BF16)
     lin = A.double() @ Bm.double().t() + bias.double()
+    scratch = torch.empty(496 << 20, dtype=torch.uint8, device=DEV)      # caller-owned tuner / split-K scratch of the operator-level entry
+    lib().mebt_debug_gemm_scratch(ptr(scratch), scratch.numel())
     lib().mebt_debug_gemm_tile(*tile)
     lib().mebt_debug_gemm_variant(variant)
     try:
         out, _ = run_gemm(_lib.BF16, A, B, M, N, K, 1, b_kc, bias=bias)
         assert (out.double() - lin).abs().max() < tol * max(1, lin.abs().max())
+        assert scratch[384 << 20:(384 << 20) + 4 * M * N].view(torch.float32).abs().sum().item() > 0     # the slabs were really used
         out, g = run_gemm(_lib.BF16, A, B, M, N, K, 1, b_kc, bias=bias, epilogue=_lib.EPI_GELU)
         assert (out.double() - lin).abs().max() < tol * max(1, lin.abs().max())
         assert (g.double() - F.gelu(lin)).abs().max() < tol * max(1, lin.abs().max())
@@ -169,6 +172,8 @@ def test_gemm_splitk_slabs_with_epilogues(tile, variant, b_kc):
     finally:
         lib().mebt_debug_gemm_tile(0, 0)
         lib().mebt_debug_gemm_variant(-1)
+        torch.cuda.synchronize()
+        lib().mebt_debug_gemm_scratch(None, 0)
 
 
 @pytest.mark.parametrize("dtype,tol", [(_lib.BF16, 2e-2), (_lib.F32, 1e-5)])
@@ -339,3 +344,36 @@ def test_sampler_full_vocab_row():
         assert torch.equal(ids.cpu(), ids_r), (temp, k, p)
         assert ((probs.cpu() > 0) == (probs_r > 0)).all()
         np.testing.assert_allclose(probs.cpu().numpy(), probs_r.numpy(), rtol=3e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("top_k,top_p", [(0, 0.0), (64, 0.0), (0, 0.9), (256, 0.8)])
+def test_sampler_seeded_noise_matches_cpu_twin(top_k, top_p):
+    """mebt_op_sample_seeded: the Exp(1) noise is generated inside the kernel (counter-based); with the CPU twin of the
+    generator (oracle/closed_form.py:exp1_counter) the oracle must draw the same ids, except where its two best keys p/q are
+    within 1e-4 of each other (the kernel's logf and the twin's float64 log differ in the last bit)."""
+    from oracle import closed_form as cf
+    from oracle import mebt_oracle as orc
+    g = torch.Generator().manual_seed(11)
+    R, V = 96, 16384
+    logits = torch.randn(R, V, generator=g) * 2.0
+    seed = 0x1234_5678_9ABC
+    ids = torch.empty(R, dtype=torch.long, device=DEV)
+    score = torch.empty(R, device=DEV)
+    probs = torch.empty(R, V, device=DEV)
+    check(lib().mebt_op_sample_seeded(ptr(logits.to(DEV)), seed, 0.9, top_k, top_p, ptr(ids), ptr(score), ptr(probs), R, V, cur_stream()))
+    noise = torch.from_numpy(cf.exp1_counter(seed, R, V))
+    assert abs(float(noise.mean()) - 1.0) < 0.01 and float(noise.min()) > 0
+    ref_ids, ref_p = orc.sample_from_logits(logits, 0.9, top_k or None, top_p or None, noise)
+    np.testing.assert_allclose(probs.cpu().numpy(), ref_p.numpy(), rtol=2e-4, atol=1e-9)
+    mism = (ids.cpu() != ref_ids).nonzero().flatten().tolist()
+    for r in mism:
+        key = ref_p[r].double() / noise[r].double()
+        top2 = key.topk(2).values
+        assert top2[0] / top2[1] < 1 + 1e-4, (r, float(top2[0] / top2[1]))
+    assert len(mism) <= 2
+    # a different seed gives different draws; the same seed the same
+    ids2 = torch.empty_like(ids)
+    check(lib().mebt_op_sample_seeded(ptr(logits.to(DEV)), seed + 1, 0.9, top_k, top_p, ptr(ids2), None, None, R, V, cur_stream()))
+    assert (ids2 != ids).float().mean().item() > 0.5
+    check(lib().mebt_op_sample_seeded(ptr(logits.to(DEV)), seed, 0.9, top_k, top_p, ptr(ids2), None, None, R, V, cur_stream()))
+    assert torch.equal(ids2, ids)

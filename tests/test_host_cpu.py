@@ -355,3 +355,41 @@ def test_data_parallel_sharded_optimizer_gloo_world2(wire):
         assert np.abs(W2 - Wref).max() <= 2.2e-3 and np.abs(P2 - Pref).max() <= 2.2e-3
         assert (np.abs(W2 - Wref) > 2e-5).mean() < 0.02                     # sign flips of ~0 gradients only
         assert np.abs(mW2 - mWref).max() <= 1.2e-2 * np.abs(mWref).max()
+
+
+def test_load_from_lightning_format_checkpoint(tmp_path):
+    """A checkpoint laid out as pytorch_lightning writes it for the reference module (download.py:56-61): `state_dict` with the
+    reference's parameter names, `hyper_parameters` = the constructor arguments recorded by save_hyperparameters()
+    (transformer.py:146) as PLAIN nested dicts, plus Lightning's bookkeeping keys.  load_from_checkpoint rebuilds the module
+    (mode list, vocabulary, mask sampler) and loads every tensor."""
+    import torch
+    from mebt.transformer import Net2NetTransformer
+    from oracle import closed_form as cf
+    cfg = mg.oracle_cfg("micro")
+    sd = {k: torch.from_numpy(v) for k, v in cf.state_dict_numpy(orc.param_shapes(cfg)).items()}
+    c = mg.CONFIGS["micro"]
+    hp = {"transformer_config": {"unconditional": True, "vocab_size": 16384, "first_stage_vocab_size": 16384, "block_size": c["block_size"],
+                                 "n_layer": c["n_layer"], "n_head": c["n_head"], "n_embd": c["n_embd"], "n_unmasked": 0, "embd_pdrop": 0.0,
+                                 "resid_pdrop": 0.1, "attn_pdrop": 0.0, "sample_every_n_latent_frames": 0, "first_stage_key": "video",
+                                 "cond_stage_key": "label", "vtokens": True, "vtokens_pos": False, "vis_epoch": 100, "sos_emb": c["sos_emb"],
+                                 "avg_loss": True, "mode": list(c["mode"]), "class_cond_dim": None},
+          "first_stage_config": {"params": {"ckpt_path": None, "ignore_keys": ["loss"]}},
+          "mask_config": {"target": "mebt.mask_sampler.MaskGen",
+                          "params": {"iid": False, "schedule": "linear", "max_token": c["block_size"], "method": "mlm", "shape": c["shape"],
+                                     "t_range": [0.0, 1.0], "budget": c["budget"]}},
+          "ckpt_path": None, "ignore_keys": [], "first_stage_key": "video", "cond_stage_key": "label", "pkeep": 1.0, "sos_token": 0}
+    path = str(tmp_path / "epoch=3-step=1200.ckpt")
+    torch.save({"epoch": 3, "global_step": 1200, "pytorch-lightning_version": "1.5.4", "state_dict": sd, "hyper_parameters": hp,
+                "optimizer_states": [], "lr_schedulers": [], "callbacks": {}, "loops": {}}, path)
+    m = Net2NetTransformer.load_from_checkpoint(path)
+    assert [b.mode for b in m.transformer.blocks] == list(c["mode"]) and m.config.resid_pdrop == 0.1
+    assert m.global_step == 1200 and m.current_epoch == 3 and m.mask_sampler.budget == c["budget"]
+    got = m.state_dict()
+    assert set(got) == set(sd)
+    for k, v in sd.items():
+        assert torch.equal(got[k], v), k
+    # a checkpoint our own launcher writes round-trips through the same entry point
+    path2 = str(tmp_path / "ours.ckpt")
+    torch.save({"state_dict": m.state_dict(), "hyper_parameters": m.hparams, "global_step": 7}, path2)
+    m2 = Net2NetTransformer.load_from_checkpoint(path2)
+    assert m2.global_step == 7 and all(torch.equal(m2.state_dict()[k], v) for k, v in sd.items())
