@@ -59,10 +59,12 @@ def cpu_model_name():
 
 
 def cpu_baseline(model_sd, cfg, t, sample_B=6):
-    """The CPU oracle (a port of the reference algorithm, pinned to it by tests/golden) timed on this box's host
-    cores: full train steps (fwd + CE + bwd + AdamW) of the same network at batch `sample_B` and the same t, with
-    every core torch sees and with 16 threads (beyond which these op sizes stop scaling on most hosts); `value` is
-    the faster of the two."""
+    """The CPU oracle (a port of the reference algorithm, pinned to it by tests/golden) timed on this box's host cores: full
+    train steps (fwd + CE + bwd + AdamW) of the same network at batch `sample_B` and the same t.  Thread counts 16 and 64 are
+    timed (`value` = the faster); a count whose first step is already > 3x slower than the best so far is recorded from that
+    one step and not repeated.  Counts above 64 are not run: on the 2 x 64-core / 256-thread EPYC 9575F hosts of this pool
+    torch's CPU kernels at 256 threads measured 6.9 masked tokens/s against 700 at 16 (445 s per step, round-2 run
+    gpurun_out/r2e) — it only burns the bounded budget of this leg."""
     from oracle import mebt_oracle as orc
     p = cfg.model.params
     ocfg = orc.OracleConfig(p.n_layer, p.n_head, p.n_embd, p.block_size, p.sos_emb, p.mode, shape=cfg.model.mask.params.shape,
@@ -71,9 +73,14 @@ def cpu_baseline(model_sd, cfg, t, sample_B=6):
     st = orc.TrainState({k: v.float().cpu() for k, v in model_sd.items()}, lr=cfg.exp.exact_lr)
     x, idx = synthetic_batch(sample_B, cfg.model.mask.params.shape, 0, "cpu")
     runs = {}
-    for threads in sorted({min(16, ncpu), ncpu}):
+    for threads in sorted({min(16, ncpu), min(64, ncpu)}):
         torch.set_num_threads(threads)
-        orc.train_step(st, ocfg, x, idx, t)                      # untimed warm-up step (allocator, thread pool)
+        t0 = time.perf_counter()
+        r = orc.train_step(st, ocfg, x, idx, t)                  # warm-up step (allocator, thread pool); timed only as a guard
+        warm = time.perf_counter() - t0
+        if runs and warm > 3.0 * min(v[0] for v in runs.values()):
+            runs[threads] = (warm, r["n_targets"])              # oversubscribed: one step is enough to show it
+            continue
         dts = []
         for _ in range(2):
             t0 = time.perf_counter()
@@ -85,7 +92,8 @@ def cpu_baseline(model_sd, cfg, t, sample_B=6):
     return {"value": ntg / dt, "unit": "masked tokens/s", "cores": best, "kind": "port", "os_cpu_count": ncpu,
             "by_threads": {str(k): round(v[1] / v[0], 1) for k, v in runs.items()},
             "sample": f"best of 2 timed train steps (fwd+CE+bwd+AdamW, after 1 warm-up) per thread count at batch {sample_B}, "
-                      f"NC=NT={ntg // sample_B}, fp32, torch {torch.__version__} CPU, {cpu_model_name()}; {dt:.1f} s per step at {best} threads"}
+                      f"NC=NT={ntg // sample_B}, fp32, torch {torch.__version__} CPU, {cpu_model_name()} (os.cpu_count() = {ncpu}); "
+                      f"{dt:.1f} s per step at {best} threads"}
 
 
 def timed(fn, n, sync):

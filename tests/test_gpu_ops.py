@@ -360,7 +360,8 @@ def test_sampler_seeded_noise_matches_cpu_twin(top_k, top_p):
     ids = torch.empty(R, dtype=torch.long, device=DEV)
     score = torch.empty(R, device=DEV)
     probs = torch.empty(R, V, device=DEV)
-    check(lib().mebt_op_sample_seeded(ptr(logits.to(DEV)), seed, 0.9, top_k, top_p, ptr(ids), ptr(score), ptr(probs), R, V, cur_stream()))
+    lgd = logits.to(DEV)
+    check(lib().mebt_op_sample_seeded(ptr(lgd), seed, 0.9, top_k, top_p, ptr(ids), ptr(score), ptr(probs), R, V, cur_stream()))
     noise = torch.from_numpy(cf.exp1_counter(seed, R, V))
     assert abs(float(noise.mean()) - 1.0) < 0.01 and float(noise.min()) > 0
     ref_ids, ref_p = orc.sample_from_logits(logits, 0.9, top_k or None, top_p or None, noise)
@@ -373,7 +374,7 @@ def test_sampler_seeded_noise_matches_cpu_twin(top_k, top_p):
     assert len(mism) <= 2
     # a different seed gives different draws; the same seed the same
     ids2 = torch.empty_like(ids)
-    check(lib().mebt_op_sample_seeded(ptr(logits.to(DEV)), seed + 1, 0.9, top_k, top_p, ptr(ids2), None, None, R, V, cur_stream()))
+    check(lib().mebt_op_sample_seeded(ptr(lgd), seed + 1, 0.9, top_k, top_p, ptr(ids2), None, None, R, V, cur_stream()))
     assert (ids2 != ids).float().mean().item() > 0.5
-    check(lib().mebt_op_sample_seeded(ptr(logits.to(DEV)), seed, 0.9, top_k, top_p, ptr(ids2), None, None, R, V, cur_stream()))
+    check(lib().mebt_op_sample_seeded(ptr(lgd), seed, 0.9, top_k, top_p, ptr(ids2), None, None, R, V, cur_stream()))
     assert torch.equal(ids2, ids)

@@ -92,7 +92,8 @@ def test_groupnorm_silu_operator(C):
         xc = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, tdt)
         y = torch.empty_like(xc)
         stats = torch.empty(B * 64, device=DEV)
-        _lib.check(_lib.load().mebt_op_groupnorm_silu(code, _lib.ptr(xc), _lib.ptr(y), _lib.ptr(w.to(DEV)), _lib.ptr(b.to(DEV)), _lib.ptr(stats),
+        wd, bd = w.to(DEV), b.to(DEV)                 # named: a temporary would be freed (and its memory reused) before the launch
+        _lib.check(_lib.load().mebt_op_groupnorm_silu(code, _lib.ptr(xc), _lib.ptr(y), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(stats),
                                                      B, int(np.prod(dims)), C, _lib.cur_stream()))
         assert (y.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
 
@@ -116,7 +117,8 @@ def test_codebook_argmin_operator():
     e2 = e.clone()
     e2[77] = e2[5]
     z2 = e2[5:6].clone()
-    _lib.check(_lib.load().mebt_op_codebook_argmin(_lib.ptr(z2.to(DEV)), _lib.ptr(e2.to(DEV)), _lib.ptr(score), _lib.ptr(esq), _lib.ptr(ids), 1,
+    z2d, e2d = z2.to(DEV), e2.to(DEV)
+    _lib.check(_lib.load().mebt_op_codebook_argmin(_lib.ptr(z2d), _lib.ptr(e2d), _lib.ptr(score), _lib.ptr(esq), _lib.ptr(ids), 1,
                                                   n_codes, d, _lib.cur_stream()))
     assert int(ids[0]) == 5
 
@@ -139,9 +141,9 @@ def test_vqgan_encode_decode_vs_reference_golden(name, dtype):
     if dtype == "f32":
         assert zerr < 1e-4
         assert (gap[mism] < 1e-3).all() and mism.sum() <= 2           # identical up to fp32 ties of the reference itself
-    else:
-        assert zerr < 2e-2
-        assert mism.mean() < 0.10 and (gap[mism] < 0.05 * np.abs(g["best2"][:, 0]).max()).all()
+    else:                       # fp16 activations, fp32 search: measured z error 1.2e-3, 1 of 1024 ids (a reference gap of 4e-2 on distances ~ 300)
+        assert zerr < 2.5e-3
+        assert mism.mean() < 0.01 and (gap[mism] < 1e-3 * np.abs(g["best2"][:, 0]).max()).all()
     # embeddings returned with the ids are the codebook rows of those ids (straight-through value, codebook.py:60-63,94)
     e_ref = P["codebook.embeddings"][ids.cpu().reshape(-1)].view(*ids.shape, -1).permute(0, 4, 1, 2, 3)
     assert torch.equal(emb.cpu(), e_ref)
@@ -151,7 +153,7 @@ def test_vqgan_encode_decode_vs_reference_golden(name, dtype):
     rv = rec.reshape(-1).cpu().numpy()[g["rec_idx"]]
     rerr = np.abs(rv - g["rec_vals"]).max() / np.abs(g["rec_vals"]).max()
     print(f"[vqgan {name} {dtype}] decode rel err {rerr:.2e}")
-    assert rerr < (2e-4 if dtype == "f32" else 3e-2)
+    assert rerr < (2e-5 if dtype == "f32" else 3e-3)          # measured 3.5e-6 / 1.4e-3
     np.testing.assert_allclose(rec.mean(dim=(0, 1, 3, 4)).cpu().numpy(), g["rec_mean"], rtol=0, atol=(1e-5 if dtype == "f32" else 3e-3))
     # MFMA implicit GEMM == direct kernel (same fp16 operands, different summation order)
     if dtype == "f16":
