@@ -216,6 +216,42 @@ def secondary_metrics(args, cfg, model, loop, x, idx, device, lib, level):
     fl = 64 * 4 * forward_flops_per_sample(uo, 7936, 256)
     out["c4_revise_64_forwards"] = {"batch": 4, "s": round(dt, 3), "forwards_per_s": round(64 / dt, 1), "tflops": round(fl / dt / 1e12, 1),
                                     "note": "64 forwards at (NC, NT) = (7936, 256) + sampling + scatter, block 8192"}
+    del um
+
+    # (8) C5 (BASELINE.json configs[4]): Taichi 16f end to end — pixels -> 3D-VQGAN encode (fp16 MFMA, fp32 codebook search) ->
+    # MeBT sampling as the shipped script runs it (64-step MaskGIT draft, then M = 8 x 2 revise forwards at T = 0.3) ->
+    # 3D-VQGAN decode, batch 4, random-init weights
+    from mebt_amd.vqgan import VQGAN
+    tcfg = presets.taichi_16f(vtokens=False)
+    torch.manual_seed(2)
+    tm = presets.build_model(tcfg, compute_dtype=args.dtype)
+    tm.first_stage_model = VQGAN(presets.vqgan_args())
+    tm.first_stage_model.compute_dtype = "f16"
+    tm = tm.to(device).eval()
+    tm.mask_sampler.schedule = "cosine"
+    vid = torch.rand(4, 3, 16, 128, 128, device=device) - 0.5
+    with torch.no_grad():
+        stages = {}
+        enc = lambda: tm.encode_to_z(vid)[1]
+        toks = enc()
+        stages["vqgan_encode_ms"] = round(timed(enc, 3, sync) * 1e3, 3)
+        x0 = torch.zeros(4, 4, 16, 16, dtype=torch.long, device=device)
+        draft = lambda: tm.sample(x0, None, 1.0, None, None, 64, None, None, context_temperature=2.0, skips=False)[0]
+        code = draft()
+        stages["sample_64_steps_ms"] = round(timed(draft, 1, sync) * 1e3, 3)
+        rev = lambda: tm.draft_and_revise(code.view(4, 4, 16, 16), None, 8, 0.0, None, None, 2, 0.3, None, None, 8, True)
+        code2 = rev()
+        stages["revise_8x2_ms"] = round(timed(rev, 1, sync) * 1e3, 3)
+        dec = lambda: tm.first_stage_model.decode(code2.view(4, 4, 16, 16))
+        rec = dec()
+        stages["vqgan_decode_ms"] = round(timed(dec, 3, sync) * 1e3, 3)
+    assert tuple(rec.shape) == (4, 3, 16, 128, 128) and tuple(toks.shape) == (4, 1024)
+    total = sum(stages.values())
+    stages.update({"batch": 4, "total_ms": round(total, 2), "videos_per_s": round(4 / (total * 1e-3), 2),
+                   "vqgan_encode_tflops": round(4 * 2 * 23.83e9 / (stages["vqgan_encode_ms"] * 1e-3) / 1e12, 1),
+                   "vqgan_decode_tflops": round(4 * 2 * 347.17e9 / (stages["vqgan_decode_ms"] * 1e-3) / 1e12, 1),
+                   "note": "16 frames x 128 x 128 per video; VQGAN fp16 (conv3d implicit GEMM on v_mfma_f32_16x16x32_f16), transformer " + args.dtype})
+    out["c5_taichi_end_to_end"] = stages
     return out
 
 

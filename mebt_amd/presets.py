@@ -35,6 +35,24 @@ def ucf_128f(vtokens=True):
     return c
 
 
+def taichi_16f(vtokens=True):
+    """configs/taichi/mebt_16f.yaml — the Sky network without dropout, t_prior longest, lr 3e-5 / wd 1e-4, batch 32"""
+    c = sky_16f(vtokens, dropout=0.0)
+    c.model.params.t_prior = "longest"
+    c.data.batch_size, c.data.sample_every_n_frames = 32, 4
+    c.exp = AttrDict(exact_lr=0.00003, weight_decay=0.0001)
+    return c
+
+
+def vqgan_args(n_hiddens=32, downsample=(4, 8, 8), embedding_dim=256, n_codes=16384, sequence_length=16, resolution=128):
+    """first-stage hyper-parameters for BASELINE config 5 (TATS-style values, SURVEY.md §8f: they live in the first-stage
+    checkpoint's hyper_parameters, not in this repository's YAMLs): [B,3,16,128,128] -> [B,4,16,16] tokens of 16384 codes"""
+    import argparse
+    return argparse.Namespace(n_hiddens=n_hiddens, downsample=tuple(downsample), image_channels=3, embedding_dim=embedding_dim,
+                              n_codes=n_codes, norm_type="group", padding_type="replicate", sequence_length=sequence_length,
+                              sample_every_n_frames=1, resolution=resolution)
+
+
 def tiny(vtokens=True):
     """BASELINE.json configs[0]: n_layer=4, n_embd=256, block=256, sos_emb=64 on [B,2,8,8] tokens"""
     c = sky_16f(vtokens, dropout=0.0)

@@ -25,7 +25,7 @@ def per_kernel(d, counter):
 ft, fn = per_kernel(sys.argv[1], "FETCH_SIZE")
 wt, wn = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {}
-for k in sorted(ft, key=lambda k: -ft[k])[:12]:
+for k in sorted(ft, key=lambda k: -ft[k]):        # every kernel (the embed gather / scatter rows are small but asked for)
     fetch = 2.0 * ft[k] * 1024 / fn[k]          # gfx950 correction: x2
     write = wt.get(k, 0.0) * 1024 / max(1, wn.get(k, 1))
     out[k] = {"launches": fn[k], "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
