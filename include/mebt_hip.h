@@ -140,6 +140,10 @@ int mebt_adamw_slice(mebt_model* m, int32_t which, int64_t off, int64_t n, const
 int mebt_model_set_fused_adamw(mebt_model* m, float* mW, float* vW, float lr, float beta1, float beta2, float eps,
                                float weight_decay, int32_t step, float grad_scale);
 
+/* Data-parallel wire format: gWb = bf16 buffer of n_w elements laid out like gW (NULL: off).  While bound (bf16 compute mode, no
+ * gradient accumulation, fused optimizer disarmed) mebt_backward_* store the Linear weight gradients THERE, rounded once from
+ * the fp32 MFMA accumulators, and leave gW untouched: the reduce-scatter of SURVEY.md §5.8 sends the buffer as is. */
+int mebt_model_bind_wire_grads(mebt_model* m, void* gWb);
 /* Gradient accumulation over micro-batches (reference train_transformer.py:46-49, Lightning's accumulate_grad_batches):
  * on = 1: the following mebt_backward_* calls ADD to gW / gP; on = 0 (default): they overwrite.  Not together with
  * mebt_model_set_fused_adamw. */

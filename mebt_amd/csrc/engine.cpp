@@ -77,6 +77,9 @@ struct mebt_model {
     int64_t head_w = 0, lnf_w = 0, lnf_b = 0, mask_emb = 0, sos_emb = 0, pos_emb = 0, tok_emb = 0;
     float *W = nullptr, *gW = nullptr, *P = nullptr, *gP = nullptr;
     void* Wlp = nullptr;
+    void* gWb = nullptr;       // mebt_model_bind_wire_grads: bf16 gradient buffer laid out like gW; when set, the Linear weight
+                               // gradients are stored there (and ONLY there) straight from the MFMA accumulators
+
     std::vector<char> live;   // per layer: does the loss depend on this block?
     bool tok_live = false;
     bool has_maskgit = false;
@@ -94,6 +97,7 @@ struct mebt_model {
     bool grad_acc = false;     // mebt_model_set_grad_accumulate: backward adds to gW / gP instead of overwriting them
     float *fused_mW = nullptr, *fused_vW = nullptr;
     AdamWHyper fused_h = {0, 0, 0, 0, 0, 1, 1, 1};
+    bool wire() const { return gWb && d.dtype == MEBT_BF16 && !grad_acc && !fused_on; }
     int esz() const { return d.dtype == MEBT_BF16 ? 2 : 4; }
     // weight operand for GEMMs (bf16 mirror in bf16 mode)
     const void* Wop(int64_t off) const {
@@ -626,6 +630,7 @@ static int ln_bwd(const mebt_model* m, const void* x, const void* dy, const void
 static int wgrad(const mebt_model* m, const void* dY, int ld_dy, const void* X, int ld_x, int64_t w_off, int n_out, int k_in, int tokens, hipStream_t st) {
     GemmParams p = gp(dY, X, m->gW + w_off, n_out, k_in, tokens, ld_dy, ld_x, k_in, 0, 0);
     p.c_f32 = 1; p.split_k = 0; p.beta = m->grad_acc ? 1 : 0;
+    if (m->wire()) { p.C = (char*)m->gWb + (size_t)w_off * 2; p.c_f32 = 0; p.split_k = 1; }     // bf16 wire format, no fp32 copy
     return gemm(m, p, st);
 }
 // dX[tokens,k_in] = dY W  (+aux)
@@ -665,7 +670,10 @@ static int backward_prologue(mebt_model* m, void* ws, hipStream_t st) {
     // P-side gradients are accumulated with atomics (LN affine, biases, embeddings): zero them first
     MEBT_HIP_CHECK(hipMemsetAsync(m->gP, 0, (size_t)m->n_p * 4, st));
     for (int i = 0; i < m->d.n_layer; ++i)
-        if (!m->live[i]) MEBT_HIP_CHECK(hipMemsetAsync(m->gW + m->lo[i].wq, 0, (size_t)12 * d * d * 4, st));
+        if (!m->live[i]) {
+            MEBT_HIP_CHECK(hipMemsetAsync(m->gW + m->lo[i].wq, 0, (size_t)12 * d * d * 4, st));
+            if (m->wire()) MEBT_HIP_CHECK(hipMemsetAsync((char*)m->gWb + (size_t)m->lo[i].wq * 2, 0, (size_t)12 * d * d * 2, st));
+        }
     return MEBT_OK;
 }
 
@@ -744,7 +752,10 @@ static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd, bool with_col
     if (with_colsum) RC(launch_colsum_grouped(lv.c, dt, sd));
     for (int i = 0; i < lv.w.n; ++i) {      // empty reductions (NC = 0): the gradient is zero
         const GroupedWgrad::Item& it = lv.w.g[i];
-        if (it.K <= 0 && it.M > 0 && it.N > 0 && !m->grad_acc) MEBT_HIP_CHECK(hipMemset2DAsync(it.C, (size_t)it.ldc * 4, 0, (size_t)it.N * 4, it.M, sd));
+        if (it.K <= 0 && it.M > 0 && it.N > 0 && !m->grad_acc) {
+            MEBT_HIP_CHECK(hipMemset2DAsync(it.C, (size_t)it.ldc * 4, 0, (size_t)it.N * 4, it.M, sd));
+            if (m->wire()) MEBT_HIP_CHECK(hipMemset2DAsync((char*)m->gWb + (size_t)(it.C - m->gW) * 2, (size_t)it.ldc * 2, 0, (size_t)it.N * 2, it.M, sd));
+        }
     }
     if (dt == MEBT_BF16) {
         ProfRec r;
@@ -762,6 +773,8 @@ static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd, bool with_col
         }
         lv.w.scratch = m->ctx.tune.flush ? &m->ctx.tune : nullptr;
         lv.w.beta = m->grad_acc ? 1 : 0;
+        lv.w.gW = m->gW;
+        lv.w.Cb = m->wire() ? m->gWb : nullptr;
         if (m->fused_on) {
             lv.w.fused = 1; lv.w.W = m->W; lv.w.gW = m->gW; lv.w.mW = m->fused_mW; lv.w.vW = m->fused_vW; lv.w.Wlp = m->Wlp;
             lv.w.opt = m->fused_h;
@@ -1081,6 +1094,15 @@ extern "C" int mebt_adamw_slice(mebt_model* m, int32_t which, int64_t off, int64
     }
     if (which == 0) RC(run(m->head_w, m->n_w));
     else RC(run(m->lnf_w, m->tok_live ? m->n_p : m->tok_emb));
+    return MEBT_OK;
+}
+
+// bf16 wire-format gradients for the data-parallel path: with a buffer bound (bf16 compute mode, no accumulation, no fused
+// optimizer) the weight-gradient launches round their fp32 accumulators once and store bf16 there instead of fp32 in gW —
+// the reduce-scatter reads it as is (no fp32 store, no cast pass: 6 bytes per parameter less HBM traffic per step).
+extern "C" int mebt_model_bind_wire_grads(mebt_model* m, void* gWb) {
+    if (!m) { mebt_set_error("bind_wire_grads: null model"); return MEBT_EINVAL; }
+    m->gWb = gWb;
     return MEBT_OK;
 }
 

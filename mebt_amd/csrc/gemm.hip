@@ -398,7 +398,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
     }
     c.n = n;
     if (!n) return MEBT_OK;
-    c.beta = w.beta; c.scratch = w.scratch;
+    c.beta = w.beta; c.scratch = w.scratch; c.Cb = w.Cb; c.gW = w.gW;
     c.fused = w.fused; c.W = w.W; c.gW = w.gW; c.mW = w.mW; c.vW = w.vW; c.Wlp = w.Wlp; c.opt = w.opt;
     for (int i = 1; i < n; ++i)              // insertion sort, K descending
         for (int j = i; j > 0 && c.g[j].K > c.g[j - 1].K; --j) { const GroupedWgrad::Item t = c.g[j]; c.g[j] = c.g[j - 1]; c.g[j - 1] = t; }
@@ -406,7 +406,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
     {
         std::lock_guard<std::mutex> lk(g_tune_mutex);
         tune_init();
-        TuneKey key{0x40000000 | n | (c.fused ? 0x100 : 0) | (c.beta ? 0x200 : 0)};
+        TuneKey key{0x40000000 | n | (c.fused ? 0x100 : 0) | (c.beta ? 0x200 : 0) | (c.Cb ? 0x400 : 0)};
         for (int i = 0; i < n; ++i) { key.push_back(c.g[i].M); key.push_back(c.g[i].N); key.push_back(tune_bucket(c.g[i].K)); }
         auto it = g_tuned.find(key);
         if (it == g_tuned.end() && g_autotune && !c.beta && scratch_of(w.scratch)) {

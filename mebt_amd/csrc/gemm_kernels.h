@@ -695,6 +695,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w
     p.A = it.A; p.B = it.B; p.C = it.C; p.C2 = nullptr; p.bias = nullptr; p.aux = nullptr;
     p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb; p.ldc = it.ldc; p.ld_aux = 0;
     p.a_kc = 0; p.b_kc = 0; p.epilogue = EPI_NONE; p.c_f32 = 1; p.beta = w.beta; p.split_k = 1; p.drop.thresh = 0;
+    if (w.Cb) { p.C = reinterpret_cast<bf16_t*>(w.Cb) + (it.C - w.gW); p.c_f32 = 0; }
     if (w.fused) {
         const ptrdiff_t off = it.C - w.gW;
         p.epilogue = EPI_ADAMW; p.opt = w.opt;

@@ -61,6 +61,7 @@ struct GroupedWgrad {
     float* W = nullptr; float* gW = nullptr; float* mW = nullptr; float* vW = nullptr; void* Wlp = nullptr;
     AdamWHyper opt = {0, 0, 0, 0, 0, 1, 1, 1};
     int beta = 0;                           // C += result (gradient accumulation over micro-batches); not with `fused`
+    void* Cb = nullptr;                     // bf16 gradient buffer laid out like gW: item i is stored (rounded once) at Cb + (C - gW) instead of fp32 C
     const GemmScratch* scratch = nullptr;   // host side only, see GemmParams
 };
 int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream);   // fills tile_start / ntx

@@ -72,6 +72,7 @@ class NativeModel:
         self.lib.mebt_debug_side_stream(self.h, 1 if self.side_stream else 0)
         self.n_layer, self.n_embd, self.vocab, self.n_latent = n_layer, n_embd, vocab, n_latent
         self.W = self.P = self.gW = self.gP = self.Wlp = None
+        self.gWb = None             # bf16 wire-format weight gradients (data-parallel sharded path)
         self.ws = None
         self.ws_key = None
         self._w_version = None
@@ -254,6 +255,17 @@ class NativeModel:
         mW, vW, _, _ = self._adam_state()
         check(self.lib.mebt_model_set_fused_adamw(self.h, ptr(mW), ptr(vW), float(lr), float(betas[0]), float(betas[1]), float(eps),
                                                   float(weight_decay), int(step), float(grad_scale)))
+
+    def enable_wire_grads(self, on=True):
+        """bf16 compute mode: store the Linear weight gradients as bf16 in `gWb` (same layout as gW) instead of fp32 in gW —
+        the wire format of the data-parallel reduce-scatter, written once from the fp32 accumulators"""
+        if on and self.dtype == "bf16":
+            if self.gWb is None:
+                self.gWb = torch.zeros(self.n_w, device=self.device, dtype=torch.bfloat16)
+            check(self.lib.mebt_model_bind_wire_grads(self.h, ptr(self.gWb)))
+        else:
+            self.gWb = None
+            check(self.lib.mebt_model_bind_wire_grads(self.h, None))
 
     def set_grad_accumulate(self, on):
         """on: the next backward adds to the gradient buffers (a further micro-batch); off: it overwrites them"""

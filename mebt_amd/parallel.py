@@ -6,7 +6,9 @@ Design.  Gradients live in two flat fp32 buffers laid out in l
 contiguous slice — no flatten / unflatten copies.  The HIP backward is split at bucket boundaries
 (mebt_backward_head / _layers / _embed); as soon as a bucket's gradients are final the reducer runs, per bucket,
 
-  mode "sharded" (default):   cast fp32 -> bf16 wire buffer            (HIP kernel, compute stream)
+  mode "sharded" (default):   bf16 wire buffer                         (Linear weight gradients: stored as bf16 by the
+                                                                        weight-gradient launches themselves; the small
+                                                                        non-Linear tail: cast kernel on the compute stream)
                               reduce-scatter(sum) of the bf16 bucket   (RCCL, its own stream)     -> rank r holds shard r
                               AdamW on shard r only                    (mebt_adamw_slice, optimizer stream; fp32 master,
                                                                         m, v are touched by the owner alone: 1/N of the
@@ -135,7 +137,10 @@ class GradReducer:
             shard = n // world
             sa = a + rank * shard
             self._sharded_ranges.add((which, a, b))
-            if self.wire == "bf16":
+            gWb = getattr(native, "gWb", None) if which == 0 else None
+            if self.wire == "bf16" and gWb is not None:
+                wire = gWb[a:b]                                                 # the backward already stored bf16 (no fp32 copy, no cast)
+            elif self.wire == "bf16":
                 wire = self._buf(self._wire_buf, (which, a, b), n, torch.bfloat16, g.device)
                 native.cast_bf16(g, wire)                                       # compute stream
             else:

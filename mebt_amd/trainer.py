@@ -20,6 +20,8 @@ class TrainLoop:
         """model: mebt_amd.transformer.Net2NetTransformer on its GPU, with learning_rate /
         warmup_steps / weight_decay / cosine_lr set (train_transformer.py:54-66)."""
         self.model = model
+        self.accum = max(1, int(accumulate_grad_batches))
+        self._micro = 0
         self.native = model._ensure_native()
         self.native.ensure_grads()
         self.reducer = reducer or GradReducer(world_size=1)
@@ -33,6 +35,8 @@ class TrainLoop:
         self.opt_stream = torch.cuda.Stream(device=self.native.device) if overlap_optimizer else None
         if self.reducer.world_size > 1 and self.reducer.mode == "sharded":
             self.native._adam_state()           # allocated up front: the first sharded update runs on the optimizer stream
+            if self.reducer.wire == "bf16" and self.accum == 1 and os.environ.get("MEBT_DP_WIRE_GRADS", "1") != "0":
+                self.native.enable_wire_grads()     # weight gradients leave the MFMA epilogue in the wire format
         # one process, bf16: AdamW of the blocks' Linear weights is applied inside the weight-gradient launches of
         # backward (the gradient never goes to HBM and the optimizer traffic hides behind MFMA work); the all-reduce of a
         # data-parallel job needs the gradients first, so this is the single-GPU path only
@@ -43,8 +47,6 @@ class TrainLoop:
         # micro-batch; gradients of k consecutive calls are averaged (loss / k, as Lightning scales it), the all-reduce, the
         # optimizer and the step counters run on the k-th.  The optimizer-in-backward needs the whole gradient in one
         # backward, so accumulation uses the separate optimizer.
-        self.accum = max(1, int(accumulate_grad_batches))
-        self._micro = 0
         if self.accum > 1:
             self.fused_optimizer = False
 

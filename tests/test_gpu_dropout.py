@@ -121,3 +121,32 @@ np.savez(sys.argv[1], gW=nm.gW.cpu().numpy(), gP=nm.gP.cpu().numpy())
     assert np.array_equal(outs[0]["gW"], outs[1]["gW"])
     scale = np.abs(outs[0]["gP"]).max()
     assert np.abs(outs[0]["gP"] - outs[1]["gP"]).max() <= 1e-5 * scale
+
+
+def test_dropout_mask_statistics():
+    """The counter-based masks (one 32-bit hash per PAIR of elements, 16 bits each, csrc/common.h) as a random source:
+    keep rate within 4 sigma of 1 - p, and no linear dependence between (i) the two halves of a hash (elements 2k, 2k+1),
+    (ii) neighbours at lags 1, 2, 64, 1024, (iii) the same element at different sites / layers, (iv) consecutive seeds —
+    every correlation within 5 / sqrt(N) of zero (N = 4 M elements)."""
+    n = 1 << 22
+    p = 0.1
+
+    def keep(seed, site):
+        return (kernel_mask(seed, site, p, (n,)) > 0).float()
+
+    base = keep(0xABCDEF0123, 16 * 3 + SITE["mlp"])
+    sd = np.sqrt(p * (1 - p) / n)
+    assert abs(base.mean().item() - (1 - p)) < 4 * sd
+    lim = 5.0 / np.sqrt(n)
+
+    def corr(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return float((a * b).mean() / (a.std() * b.std() + 1e-12))
+
+    assert abs(corr(base[0::2], base[1::2])) < lim * np.sqrt(2)               # the two 16-bit halves of one hash
+    for lag in (1, 2, 64, 1024):
+        assert abs(corr(base[:-lag], base[lag:])) < lim, lag
+    for other in (16 * 3 + SITE["proj"], 16 * 3 + SITE["attn"], 16 * 4 + SITE["mlp"], SITE["emb_tgt"]):
+        assert abs(corr(base, keep(0xABCDEF0123, other))) < lim, other
+    assert abs(corr(base, keep(0xABCDEF0124, 16 * 3 + SITE["mlp"]))) < lim
+    assert abs(corr(base, keep(0xABCDEF0123 + (1 << 20), 16 * 3 + SITE["mlp"]))) < lim     # the next global step's seed (transformer.py _next_seed)
