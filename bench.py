@@ -109,12 +109,11 @@ def secondary_metrics(args, cfg, model, loop, x, idx, device, lib, level):
     """SURVEY.md §8(d) secondary metrics, one GPU, outside the headline's timed region."""
     from mebt_amd import presets, _lib
     from mebt_amd.trainer import TrainLoop
-    from oracle.mebt_oracle import forward_flops_per_sample, OracleConfig
     sync = torch.cuda.synchronize
     B = args.batch
     out = {}
-    p = cfg.model.params
-    ocfg = OracleConfig(p.n_layer, p.n_head, p.n_embd, p.block_size, p.sos_emb, p.mode, shape=cfg.model.mask.params.shape)
+    ocfg = cfg.model.params
+    forward_flops_per_sample = presets.forward_flops_per_sample
 
     # (1) the step as a data-parallel rank runs it (gradients stored, separate AdamW): the honest weak-scaling denominator
     sep = TrainLoop(model, fused_optimizer=False)
@@ -207,8 +206,7 @@ def secondary_metrics(args, cfg, model, loop, x, idx, device, lib, level):
     torch.manual_seed(1)
     um = presets.build_model(ucfg, compute_dtype=args.dtype).to(device).eval()
     xu = torch.randint(0, 16384, (4, 32, 16, 16), device=device)
-    up = ucfg.model.params
-    uo = OracleConfig(up.n_layer, up.n_head, up.n_embd, up.block_size, up.sos_emb, up.mode, shape=ucfg.model.mask.params.shape)
+    uo = ucfg.model.params
     with torch.no_grad():
         f = lambda: um.draft_and_revise(xu, None, 8, 1.0, None, None, 32, 1.0, None, None, 2, True)
         f()

@@ -64,6 +64,19 @@ def tiny(vtokens=True):
     return c
 
 
+def forward_flops_per_sample(params, NC, NT, vocab=16384):
+    """Algorithmic forward FLOPs of one sample (matmuls only, 2 FLOP/MAC): SURVEY.md §8d formula
+    2 * [ sum_blocks ((2 NQ + 2 NK) d^2 + 2 NQ NK d + 8 NQ d^2) + NT d V ], (NQ, NK) per routing mode (gpt.py:164-179).
+    `params` = the transformer config node (n_embd, sos_emb, mode)."""
+    d, NS = params.n_embd, params.sos_emb
+    total = 0
+    for mode in params.mode:
+        NQ, NK = {"latent_enc": (NS, NC), "latent_self": (NS, NS), "latent_dec": (NT, NS), "lt2l": (NS, NS + NT),
+                  "maskgit": (NC + NT, NC + NT)}[mode]
+        total += (2 * NQ + 2 * NK) * d * d + 2 * NQ * NK * d + 8 * NQ * d * d
+    return 2 * (total + NT * d * vocab)
+
+
 def build_model(cfg, compute_dtype="bf16", device=None):
     from .transformer import Net2NetTransformer
     model = Net2NetTransformer(cfg.model.params, cfg.model.vqvae, cfg.model.mask,
