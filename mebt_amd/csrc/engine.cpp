@@ -429,6 +429,15 @@ static int ln_fwd(const mebt_model* m, const void* x, void* y, int64_t gw, int64
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+// Weight prefetch along the dependency chain (GemmParams::pf): product g asks its workgroups to pull the bf16 weights of
+// product g + 1 into the Infinity Cache.  MEBT_GEMM_PREFETCH=0 switches it off.
+static void set_pf(const mebt_model* m, GemmParams& p, int64_t w_off, int64_t n_elems) {
+    static const int on = [] { const char* e = getenv("MEBT_GEMM_PREFETCH"); return e ? atoi(e) : 1; }();
+    if (!on || m->d.dtype != MEBT_BF16 || w_off < 0 || n_elems <= 0) return;
+    p.pf = m->Wop(w_off);
+    p.pf_bytes = (unsigned)(n_elems * 2 > 0x7FFFFFFF ? 0x7FFFFFFF : n_elems * 2);
+}
+
 static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
                         const int64_t* x_ids, const int64_t* ci, const int64_t* ti, const float* const* embedded,
                         float* logits, int32_t training, uint64_t dropout_seed, mebt_stream_t stream) {
@@ -524,12 +533,15 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         if (mode == MEBT_MODE_LATENT_SELF || mode == MEBT_MODE_MASKGIT) {
             GemmParams p = gp(a.qn, m->Wop(o.wq), a.q, Mq, 3 * d, d, d, d, 3 * d, 1, 1);
             p.bias = m->P + o.bq;
+            set_pf(m, p, o.wp, (int64_t)d * d);
             RC(gemm(m, p, st));
         } else {
             GemmParams pk = gp(a.kn, m->Wop(o.wk), a.k, Mk, 2 * d, d, d, d, 2 * d, 1, 1);
             pk.bias = m->P + o.bk;
+            set_pf(m, pk, o.wp, (int64_t)d * d);
             GemmParams p = gp(a.qn, m->Wop(o.wq), a.q, Mq, d, d, d, d, d, 1, 1);
             p.bias = m->P + o.bq;
+            if (Mk <= 0) set_pf(m, p, o.wp, (int64_t)d * d);
             RC(gemm_pair(m, pk, p, st));         // key/value and query projections in one launch
         }
         // softmax(q k^T / sqrt(hd)) v  (gpt.py:131-137)
@@ -545,6 +557,7 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
             GemmParams p = gp(a.att, m->Wop(o.wp), a.x, Mq, d, d, d, d, d, 1, 1);
             p.bias = m->P + o.bp; p.epilogue = EPI_RESID; p.aux = a.qn; p.ld_aux = d;
             p.drop = make_drop(dropout_seed, 16 * i + SITE_PROJ, p_res);    // gpt.py:140
+            set_pf(m, p, o.w1, (int64_t)4 * d * d);
             RC(gemm(m, p, st));
         }
         // x = x + mlp(LN2(x))  (gpt.py:185, 150-155)
@@ -552,12 +565,15 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         {
             GemmParams p = gp(a.hn, m->Wop(o.w1), a.pre, Mq, 4 * d, d, d, d, 4 * d, 1, 1);
             p.bias = m->P + o.b1; p.epilogue = EPI_GELU; p.C2 = a.u;
+            set_pf(m, p, o.w2, (int64_t)4 * d * d);
             RC(gemm(m, p, st));
         }
         {
             GemmParams p = gp(a.u, m->Wop(o.w2), a.out, Mq, d, 4 * d, 4 * d, 4 * d, d, 1, 1);
             p.bias = m->P + o.b2; p.epilogue = EPI_RESID; p.aux = a.x; p.ld_aux = d;
             p.drop = make_drop(dropout_seed, 16 * i + SITE_MLP, p_res);     // gpt.py:154
+            if (i + 1 < m->d.n_layer) set_pf(m, p, m->lo[i + 1].wq, (int64_t)3 * d * d);
+            else set_pf(m, p, m->head_w, (int64_t)V * d);
             RC(gemm(m, p, st));
         }
         if (mode == MEBT_MODE_LATENT_DEC) Tv = a.out;                    // gpt.py:187-192
@@ -634,9 +650,11 @@ static int wgrad(const mebt_model* m, const void* dY, int ld_dy, const void* X, 
     return gemm(m, p, st);
 }
 // dX[tokens,k_in] = dY W  (+aux)
-static int dgrad(const mebt_model* m, const void* dY, int ld_dy, int64_t w_off, void* dX, int tokens, int n_out, int k_in, int epilogue, const void* aux, int ld_aux, hipStream_t st) {
+static int dgrad(const mebt_model* m, const void* dY, int ld_dy, int64_t w_off, void* dX, int tokens, int n_out, int k_in, int epilogue, const void* aux, int ld_aux, hipStream_t st,
+                 int64_t pf_off = -1, int64_t pf_elems = 0) {
     GemmParams p = gp(dY, m->Wop(w_off), dX, tokens, k_in, n_out, ld_dy, k_in, k_in, 1, 0);
     p.epilogue = epilogue; p.aux = aux; p.ld_aux = ld_aux;
+    set_pf(m, p, pf_off, pf_elems);
     return gemm(m, p, st);
 }
 
@@ -653,7 +671,7 @@ static int head_backward_common(mebt_model* m, hipStream_t st) {
         MEBT_HIP_CHECK(hipEventRecord(m->ev_layer[1], sd));
     }
     RC(wgrad(m, x.dlogits, V, x.hf, d, m->head_w, V, d, R, sd));
-    RC(dgrad(m, x.dlogits, V, m->head_w, x.dhf, R, V, d, EPI_NONE, nullptr, 0, st));
+    RC(dgrad(m, x.dlogits, V, m->head_w, x.dhf, R, V, d, EPI_NONE, nullptr, 0, st, m->lo[m->d.n_layer - 1].w2, (int64_t)4 * d * d));
     RC(ln_bwd(m, x.T_final, x.dhf, nullptr, m->lnf_w, m->lnf_b, x.meanf, x.rstdf, x.g_T, 0, 0, R, 0, 0, 0, st));
     x.gT_defined = true; x.gS_defined = false; x.gC_defined = false; x.doutm_ready = -1; x.last_bwd_lo = m->d.n_layer;
     return join_side(m, st);
@@ -834,10 +852,11 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     const void* dmlp = sc.dout_m;
     lv.colsum(dmlp, Mq, d, d, m->gP + o.b2);
     lv.wgrad(dmlp, d, a.u, 4 * d, m->gW + o.w2, d, 4 * d, Mq);
-    RC(dgrad(m, dmlp, d, o.w2, sc.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, st));   // d(pre) = (dmlp W2) * gelu'(pre)
+    const int64_t dd = (int64_t)d * d;
+    RC(dgrad(m, dmlp, d, o.w2, sc.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, st, o.w1, 4 * dd));   // d(pre) = (dmlp W2) * gelu'(pre)
     lv.colsum(sc.d4, Mq, 4 * d, 4 * d, m->gP + o.b1);
     lv.wgrad(sc.d4, 4 * d, a.hn, d, m->gW + o.w1, 4 * d, d, Mq);
-    RC(dgrad(m, sc.d4, 4 * d, o.w1, sc.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st));
+    RC(dgrad(m, sc.d4, 4 * d, o.w1, sc.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st, o.wp, dd));
     // dx = dout + LN2'(dh); the same kernel reduces dgamma/dbeta and writes the dropout-masked copy the
     // projection branch reads (x = qn + dropout(att Wp^T + bp))
     const void* dproj = sc.dx;
@@ -855,7 +874,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     }
     lv.colsum(dproj, Mq, d, d, m->gP + o.bp);
     lv.wgrad(dproj, d, a.att, d, m->gW + o.wp, d, d, Mq);
-    RC(dgrad(m, dproj, d, o.wp, x.datt, Mq, d, d, EPI_NONE, nullptr, 0, st));
+    RC(dgrad(m, dproj, d, o.wp, x.datt, Mq, d, d, EPI_NONE, nullptr, 0, st, o.wq, 3 * dd));
     // attention backward
     AttnParams ap;
     memset(&ap, 0, sizeof(ap));
@@ -884,7 +903,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     if (mode == MEBT_MODE_LATENT_SELF || ismg) {
         lv.colsum(sc.dqkv_q, Mq, 3 * d, 3 * d, m->gP + o.bq);
         lv.wgrad(sc.dqkv_q, 3 * d, a.qn, d, m->gW + o.wq, 3 * d, d, Mq);
-        RC(dgrad(m, sc.dqkv_q, 3 * d, o.wq, sc.dqn, Mq, 3 * d, d, EPI_RESID, sc.dx, d, st));   // + dx (residual on qn)
+        RC(dgrad(m, sc.dqkv_q, 3 * d, o.wq, sc.dqn, Mq, 3 * d, d, EPI_RESID, sc.dx, d, st, i > 0 ? m->lo[i - 1].w2 : -1, 4 * dd));   // + dx (residual on qn)
         if (side) RC(fork_side(m, st));
         RC(flush_leaves(m, lv, sd));
         if (ismg) {      // LN1 rows [0,NC) of each sample came from the contexts stream, the rest from the targets stream
@@ -904,6 +923,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
             GemmParams pq = gp(sc.dqkv_q, m->Wop(o.wq), sc.dqn, Mq, d, d, d, d, d, 1, 0);
             pq.epilogue = EPI_RESID; pq.aux = sc.dx; pq.ld_aux = d;
             GemmParams pk = gp(sc.dqkv_k, m->Wop(o.wk), sc.dkn, Mk, d, 2 * d, 2 * d, d, d, 1, 0);
+            if (i > 0) { set_pf(m, pk, m->lo[i - 1].w2, 4 * dd); if (Mk <= 0) set_pf(m, pq, m->lo[i - 1].w2, 4 * dd); }
             if (Mk > 0) RC(gemm_pair(m, pk, pq, st)); else RC(gemm(m, pq, st));
         }
         if (side) RC(fork_side(m, st));

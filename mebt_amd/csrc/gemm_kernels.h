@@ -269,6 +269,28 @@ __device__ __forceinline__ void xcd_tile(int t, int ntx, int nty, int M, int N, 
     tc = (xcd % xc) * lc + idx % lc;
 }
 
+// Weight prefetch for the next product of the chain (GemmParams::pf): thread t of workgroup w touches line (w * T + t) and
+// line (W * T + w * T + t) — one dword per 128-byte line, 2 VGPRs, issued before the workgroup's own loads so that the
+// counted waits of the main loop (which only assume "older operations finish first") are unaffected.  The values are only
+// consumed behind `pf_sink` (null at run time).
+struct PrefetchRegs { uint32_t v[2]; };
+__device__ __forceinline__ PrefetchRegs prefetch_next(const GemmParams& p, int wg, int nwg, int nthreads) {
+    PrefetchRegs r;
+    r.v[0] = r.v[1] = 0;
+    if (!p.pf) return r;
+    const size_t nlines = p.pf_bytes >> 7;
+    const char* base = reinterpret_cast<const char*>(p.pf);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const size_t l = (size_t)i * nwg * nthreads + (size_t)wg * nthreads + threadIdx.x;
+        if (l < nlines) r.v[i] = *reinterpret_cast<const uint32_t*>(base + (l << 7));
+    }
+    return r;
+}
+__device__ __forceinline__ void prefetch_sink(const GemmParams& p, const PrefetchRegs& r) {
+    if (p.pf_sink) *p.pf_sink = r.v[0] | r.v[1];
+}
+
 template <bool KC, int ROWS>
 struct TileLoader {
     // per-thread 16-byte chunks of a [ROWS x 64] (KC) or [64 x ROWS] (RC) bf16 tile
@@ -564,6 +586,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_w8_kernel(const GemmParams p) {
     constexpr int TM = 8, TN = 4;                       // 16x16 MFMA tiles per wave
     constexpr int LPT = (TBM + TBN) / (8 * NW);         // DMA instructions per wave per tile
     const int ntx = gridDim.x, nty = gridDim.y;
+    const PrefetchRegs pfr = prefetch_next(p, blockIdx.y * ntx + blockIdx.x, ntx * nty, 512);
     int tr, tc;
     xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
     const int m0 = tr * TBM, n0 = tc * TBN;
@@ -617,6 +640,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_w8_kernel(const GemmParams p) {
         if (++st == NSTAGE) st = 0;
     }
     epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 4), true, false);
+    prefetch_sink(p, pfr);
 }
 
 // two pipelines per workgroup (KS = 2): whole reduction in one workgroup, K a multiple of 128
@@ -624,15 +648,18 @@ template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
 __global__ __launch_bounds__(512) void gemm_bf16_dma_ks2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ntx = gridDim.x, nty = gridDim.y;
+    const PrefetchRegs pfr = prefetch_next(p, blockIdx.y * ntx + blockIdx.x, ntx * nty, 512);
     int tr, tc;
     xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
     gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE, 2>(p, tr * TBM, tc * TBN, 0, p.K / BK, smem, false, true);
+    prefetch_sink(p, pfr);
 }
 
 template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ntx = gridDim.x, nty = gridDim.y;
+    const PrefetchRegs pfr = prefetch_next(p, (blockIdx.z * nty + blockIdx.y) * ntx + blockIdx.x, ntx * nty * gridDim.z, 256);
     int tr, tc;
     xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
     const int m0 = tr * TBM, n0 = tc * TBN;
@@ -640,14 +667,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_dma_kernel(const GemmParams p) 
     const int per = (nkt + gridDim.z - 1) / gridDim.z;
     const int kt0 = blockIdx.z * per;
     const int kt1 = min(nkt, kt0 + per);
-    if (kt0 >= kt1) return;
+    if (kt0 >= kt1) { prefetch_sink(p, pfr); return; }
     if (p.slab) {                 // partial product of this k-range into its own fp32 slab (reduced by splitk_reduce_kernel)
         GemmParams q = p;
         q.C = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.z * p.slab;
         gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE>(q, m0, n0, kt0, kt1, smem, false, false);
+        prefetch_sink(p, pfr);
         return;
     }
     gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE>(p, m0, n0, kt0, kt1, smem, gridDim.z > 1, blockIdx.z == 0);
+    prefetch_sink(p, pfr);
 }
 
 // Split-K for small outputs with a deep reduction: S workgroups per LARGE tile each reduce K/S and store fp32
@@ -672,6 +701,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmPair g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PrefetchRegs pfr = prefetch_next(g.p[0], blockIdx.x, gridDim.x, 256);       // the pair's prefetch request rides on product 0
     const int which = (int)blockIdx.x >= g.tiles0 ? 1 : 0;
     const GemmParams& p = g.p[which];
     const int t = blockIdx.x - (which ? g.tiles0 : 0);
@@ -679,6 +709,7 @@ __global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmPair g) {
     xcd_tile(t, g.ntx[which], (p.M + TBM - 1) / TBM, p.M, p.N, tr, tc);
     const int m0 = tr * TBM, n0 = tc * TBN;
     gemm_tile_dma<A_KC, B_KC, TBM, TBN, NSTAGE>(p, m0, n0, 0, (p.K + BK - 1) / BK, smem, false, true);
+    prefetch_sink(g.p[0], pfr);
 }
 
 // grouped weight gradients: blockIdx.x enumerates the tiles of all groups (RC x RC, fp32 result)

@@ -43,6 +43,12 @@ struct GemmParams {
     float* opt_p = nullptr; float* opt_m = nullptr; float* opt_v = nullptr; void* opt_lp = nullptr;   // [M,ldc] like C
     AdamWHyper opt = {0, 0, 0, 0, 0, 1, 1, 1};
     const GemmScratch* scratch = nullptr;   // host side only: where the tuner / split-K may put their scratch (null: heuristic, no split-K)
+    // Weight prefetch: while this product runs, its workgroups touch one dword of every 128-byte line of [pf, pf + pf_bytes) —
+    // the bf16 weights the NEXT product of the dependency chain will read — so that they sit in the Infinity Cache instead of
+    // HBM when that launch starts (every weight is cold when its GEMM starts: 676 MB of weights cycle through 256 MB).
+    const void* pf = nullptr;
+    unsigned pf_bytes = 0;
+    unsigned* pf_sink = nullptr;            // always null at run time: keeps the prefetch loads alive for the compiler
 };
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 // two independent products with the same operand layouts in ONE launch (query- and key-side projections of a

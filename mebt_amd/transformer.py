@@ -706,27 +706,15 @@ def sample_from_logits(logits, temperature=1.0, top_k=None, top_p=None, return_p
     return (ids, probs) if return_probs else ids
 
 
-def gumbel_sort(prob):
-    """reference :826-841 — kept for API completeness (full descending order of p_norm / Exp(1))"""
-    prob = prob / prob.sum(-1, keepdim=True)
-    key = prob / torch.empty_like(prob).exponential_() * (prob > 0).float()
-    return key.sort(dim=-1, descending=True)[1]
-
-
 def top_k_logits(logits, k):
-    """reference :891-895"""
-    v, _ = torch.topk(logits, k)
-    out = logits.clone()
-    out[out < v[..., [-1]]] = -float('Inf')
-    return out
-
-
-def top_p_probs(probs, p):
-    """reference :898-910"""
-    sp, si = torch.sort(probs, dim=-1, descending=True)
-    rem = torch.cumsum(sp, dim=-1) >= p
-    rem[..., 1:] = rem[..., :-1].clone()
-    rem[..., 0] = 0
-    rem = rem.scatter(-1, si, rem)
-    probs = probs.masked_fill(rem, 0.0)
-    return probs / torch.sum(probs, dim=-1, keepdim=True)
+    """reference :891-895 (also the `Net2NetTransformer.top_k_logits` method): everything below the k-th largest logit of a
+    row becomes -inf, ties with the k-th value are kept.  The selection runs in the sampler kernel (radix select of the k-th
+    value, csrc/sampler.hip): its filtered distribution is zero exactly on the dropped entries."""
+    V = logits.shape[-1]
+    lg = logits.to(torch.float32).contiguous().view(-1, V)
+    R = lg.shape[0]
+    ids = torch.empty(R, dtype=torch.long, device=lg.device)
+    probs = torch.empty(R, V, dtype=torch.float32, device=lg.device)
+    _lib.check(_lib.load().mebt_op_sample_seeded(_lib.ptr(lg), 0, 1.0, int(k), 0.0, _lib.ptr(ids), None, _lib.ptr(probs), R, V,
+                                                 _lib.cur_stream()))
+    return logits.masked_fill(probs.view(logits.shape) == 0, -float("Inf"))       # p = 0 exactly on the entries the filter dropped

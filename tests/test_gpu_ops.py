@@ -378,3 +378,16 @@ def test_sampler_seeded_noise_matches_cpu_twin(top_k, top_p):
     assert (ids2 != ids).float().mean().item() > 0.5
     check(lib().mebt_op_sample_seeded(ptr(lgd), seed, 0.9, top_k, top_p, ptr(ids2), None, None, R, V, cur_stream()))
     assert torch.equal(ids2, ids)
+
+
+def test_top_k_logits_helper_matches_reference_semantics():
+    """`top_k_logits` (transformer.py:891-895): values below the k-th largest become -inf, ties with it are kept"""
+    from mebt_amd.transformer import top_k_logits
+    g = torch.Generator().manual_seed(5)
+    lg = torch.randn(3, 7, 16384, generator=g)
+    lg[0, 0, 100] = lg[0, 0].topk(5).values[-1]                  # a tie with the 5-th value
+    out = top_k_logits(lg.to(DEV), 5).cpu()
+    v = lg.topk(5, dim=-1).values[..., -1:]
+    ref = lg.clone()
+    ref[ref < v] = -float("inf")
+    assert torch.equal(out, ref) and int((out[0, 0] > -float("inf")).sum()) == 6
