@@ -430,13 +430,27 @@ static int ln_fwd(const mebt_model* m, const void* x, void* y, int64_t gw, int64
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
 // Weight prefetch along the dependency chain (GemmParams::pf): product g asks its workgroups to pull the bf16 weights of
-// product g + 1 into the Infinity Cache.  MEBT_GEMM_PREFETCH=0 switches it off.
+// product g + 1 into the Infinity Cache.
+static int pf_level() {      // MEBT_GEMM_PREFETCH: 0 off; 1 (default) the next product's weights; 2 also the saved activations backward reads
+                             // next — measured SLOWER (11.27 vs 11.10 ms per step, level 0: 11.36; gpurun_out/r2m): kept as an experiment
+    static const int lv = [] { const char* e = getenv("MEBT_GEMM_PREFETCH"); return e ? atoi(e) : 1; }();
+    return lv;
+}
 static void set_pf(const mebt_model* m, GemmParams& p, int64_t w_off, int64_t n_elems) {
-    static const int on = [] { const char* e = getenv("MEBT_GEMM_PREFETCH"); return e ? atoi(e) : 1; }();
-    if (!on || m->d.dtype != MEBT_BF16 || w_off < 0 || n_elems <= 0) return;
+    if (pf_level() < 1 || m->d.dtype != MEBT_BF16 || w_off < 0 || n_elems <= 0) return;
     p.pf = m->Wop(w_off);
     p.pf_bytes = (unsigned)(n_elems * 2 > 0x7FFFFFFF ? 0x7FFFFFFF : n_elems * 2);
 }
+// second range: saved forward activations [lo, hi) of a block (contiguous in the training workspace, see carve())
+static void set_pf2(const mebt_model* m, GemmParams& p, const void* lo, const void* hi) {
+    if (pf_level() < 2 || m->d.dtype != MEBT_BF16 || !lo || !hi || hi <= lo) return;
+    const size_t n = (const char*)hi - (const char*)lo;
+    p.pf2 = lo;
+    p.pf2_bytes = (unsigned)(n > 0x7FFFFFFFull ? 0x7FFFFFFFull : n);
+}
+// the two halves of a block's saved activations in the order backward consumes them
+static void pf2_tail(const mebt_model* m, GemmParams& p, const LayerAct& a) { set_pf2(m, p, a.x, (const char*)a.out); }        // x, LN2 stats, hn, pre, u
+static void pf2_head(const mebt_model* m, GemmParams& p, const LayerAct& a) { set_pf2(m, p, a.qn, (const char*)a.x); }          // qn, kn, q, k, v, att, lse
 
 static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
                         const int64_t* x_ids, const int64_t* ci, const int64_t* ti, const float* const* embedded,
@@ -651,10 +665,11 @@ static int wgrad(const mebt_model* m, const void* dY, int ld_dy, const void* X, 
 }
 // dX[tokens,k_in] = dY W  (+aux)
 static int dgrad(const mebt_model* m, const void* dY, int ld_dy, int64_t w_off, void* dX, int tokens, int n_out, int k_in, int epilogue, const void* aux, int ld_aux, hipStream_t st,
-                 int64_t pf_off = -1, int64_t pf_elems = 0) {
+                 int64_t pf_off = -1, int64_t pf_elems = 0, const LayerAct* pf2_layer = nullptr, int pf2_part = 0) {
     GemmParams p = gp(dY, m->Wop(w_off), dX, tokens, k_in, n_out, ld_dy, k_in, k_in, 1, 0);
     p.epilogue = epilogue; p.aux = aux; p.ld_aux = ld_aux;
     set_pf(m, p, pf_off, pf_elems);
+    if (pf2_layer) { if (pf2_part) pf2_tail(m, p, *pf2_layer); else pf2_head(m, p, *pf2_layer); }
     return gemm(m, p, st);
 }
 
@@ -671,7 +686,8 @@ static int head_backward_common(mebt_model* m, hipStream_t st) {
         MEBT_HIP_CHECK(hipEventRecord(m->ev_layer[1], sd));
     }
     RC(wgrad(m, x.dlogits, V, x.hf, d, m->head_w, V, d, R, sd));
-    RC(dgrad(m, x.dlogits, V, m->head_w, x.dhf, R, V, d, EPI_NONE, nullptr, 0, st, m->lo[m->d.n_layer - 1].w2, (int64_t)4 * d * d));
+    RC(dgrad(m, x.dlogits, V, m->head_w, x.dhf, R, V, d, EPI_NONE, nullptr, 0, st, m->lo[m->d.n_layer - 1].w2, (int64_t)4 * d * d,
+             &x.L[m->d.n_layer - 1], 1));
     RC(ln_bwd(m, x.T_final, x.dhf, nullptr, m->lnf_w, m->lnf_b, x.meanf, x.rstdf, x.g_T, 0, 0, R, 0, 0, 0, st));
     x.gT_defined = true; x.gS_defined = false; x.gC_defined = false; x.doutm_ready = -1; x.last_bwd_lo = m->d.n_layer;
     return join_side(m, st);
@@ -856,7 +872,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     RC(dgrad(m, dmlp, d, o.w2, sc.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, st, o.w1, 4 * dd));   // d(pre) = (dmlp W2) * gelu'(pre)
     lv.colsum(sc.d4, Mq, 4 * d, 4 * d, m->gP + o.b1);
     lv.wgrad(sc.d4, 4 * d, a.hn, d, m->gW + o.w1, 4 * d, d, Mq);
-    RC(dgrad(m, sc.d4, 4 * d, o.w1, sc.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st, o.wp, dd));
+    RC(dgrad(m, sc.d4, 4 * d, o.w1, sc.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st, o.wp, dd, &a, 0));
     // dx = dout + LN2'(dh); the same kernel reduces dgamma/dbeta and writes the dropout-masked copy the
     // projection branch reads (x = qn + dropout(att Wp^T + bp))
     const void* dproj = sc.dx;
@@ -903,7 +919,8 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     if (mode == MEBT_MODE_LATENT_SELF || ismg) {
         lv.colsum(sc.dqkv_q, Mq, 3 * d, 3 * d, m->gP + o.bq);
         lv.wgrad(sc.dqkv_q, 3 * d, a.qn, d, m->gW + o.wq, 3 * d, d, Mq);
-        RC(dgrad(m, sc.dqkv_q, 3 * d, o.wq, sc.dqn, Mq, 3 * d, d, EPI_RESID, sc.dx, d, st, i > 0 ? m->lo[i - 1].w2 : -1, 4 * dd));   // + dx (residual on qn)
+        RC(dgrad(m, sc.dqkv_q, 3 * d, o.wq, sc.dqn, Mq, 3 * d, d, EPI_RESID, sc.dx, d, st, i > 0 ? m->lo[i - 1].w2 : -1, 4 * dd,
+                 i > 0 ? &x.L[i - 1] : nullptr, 1));   // + dx (residual on qn)
         if (side) RC(fork_side(m, st));
         RC(flush_leaves(m, lv, sd));
         if (ismg) {      // LN1 rows [0,NC) of each sample came from the contexts stream, the rest from the targets stream
@@ -923,7 +940,11 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
             GemmParams pq = gp(sc.dqkv_q, m->Wop(o.wq), sc.dqn, Mq, d, d, d, d, d, 1, 0);
             pq.epilogue = EPI_RESID; pq.aux = sc.dx; pq.ld_aux = d;
             GemmParams pk = gp(sc.dqkv_k, m->Wop(o.wk), sc.dkn, Mk, d, 2 * d, 2 * d, d, d, 1, 0);
-            if (i > 0) { set_pf(m, pk, m->lo[i - 1].w2, 4 * dd); if (Mk <= 0) set_pf(m, pq, m->lo[i - 1].w2, 4 * dd); }
+            if (i > 0) {
+                GemmParams& lead = Mk > 0 ? pk : pq;
+                set_pf(m, lead, m->lo[i - 1].w2, 4 * dd);
+                pf2_tail(m, lead, x.L[i - 1]);
+            }
             if (Mk > 0) RC(gemm_pair(m, pk, pq, st)); else RC(gemm(m, pq, st));
         }
         if (side) RC(fork_side(m, st));

@@ -273,22 +273,33 @@ __device__ __forceinline__ void xcd_tile(int t, int ntx, int nty, int M, int N, 
 // line (W * T + w * T + t) — one dword per 128-byte line, 2 VGPRs, issued before the workgroup's own loads so that the
 // counted waits of the main loop (which only assume "older operations finish first") are unaffected.  The values are only
 // consumed behind `pf_sink` (null at run time).
-struct PrefetchRegs { uint32_t v[2]; };
+struct PrefetchRegs { uint32_t v[6]; };
 __device__ __forceinline__ PrefetchRegs prefetch_next(const GemmParams& p, int wg, int nwg, int nthreads) {
     PrefetchRegs r;
-    r.v[0] = r.v[1] = 0;
-    if (!p.pf) return r;
-    const size_t nlines = p.pf_bytes >> 7;
-    const char* base = reinterpret_cast<const char*>(p.pf);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const size_t l = (size_t)i * nwg * nthreads + (size_t)wg * nthreads + threadIdx.x;
-        if (l < nlines) r.v[i] = *reinterpret_cast<const uint32_t*>(base + (l << 7));
+    for (int i = 0; i < 6; ++i) r.v[i] = 0;
+    if (p.pf) {
+        const size_t nlines = p.pf_bytes >> 7;
+        const char* base = reinterpret_cast<const char*>(p.pf);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t l = (size_t)i * nwg * nthreads + (size_t)wg * nthreads + threadIdx.x;
+            if (l < nlines) r.v[i] = *reinterpret_cast<const uint32_t*>(base + (l << 7));
+        }
+    }
+    if (p.pf2) {
+        const size_t nlines = p.pf2_bytes >> 7;
+        const char* base = reinterpret_cast<const char*>(p.pf2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t l = (size_t)i * nwg * nthreads + (size_t)wg * nthreads + threadIdx.x;
+            if (l < nlines) r.v[2 + i] = *reinterpret_cast<const uint32_t*>(base + (l << 7));
+        }
     }
     return r;
 }
 __device__ __forceinline__ void prefetch_sink(const GemmParams& p, const PrefetchRegs& r) {
-    if (p.pf_sink) *p.pf_sink = r.v[0] | r.v[1];
+    if (p.pf_sink) *p.pf_sink = r.v[0] | r.v[1] | r.v[2] | r.v[3] | r.v[4] | r.v[5];
 }
 
 template <bool KC, int ROWS>

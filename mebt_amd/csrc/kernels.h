@@ -48,6 +48,8 @@ struct GemmParams {
     // HBM when that launch starts (every weight is cold when its GEMM starts: 676 MB of weights cycle through 256 MB).
     const void* pf = nullptr;
     unsigned pf_bytes = 0;
+    const void* pf2 = nullptr;              // a second range, 4 lines per thread: saved forward activations the NEXT kernels of the
+    unsigned pf2_bytes = 0;                 // backward chain read (they were written a whole forward + half a backward ago)
     unsigned* pf_sink = nullptr;            // always null at run time: keeps the prefetch loads alive for the compiler
 };
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
