@@ -4,7 +4,7 @@ sample_vqgan_transformer_videos.py that every shipped pipeline uses to produce t
 continuation) and `extrapolate` (:96-157, continuation of given tokens with `edit=True`).
 
 They drive `Net2NetTransformer.sample` exactly like the reference (same argument order, same index
-sets); the pixel decode through the 3D-VQGAN is outside this hot path, so `log['samples']` is only
+sets); `log['samples']` (the pixel decode through the 3D-VQGAN first stage, mebt_amd/vqgan.py) is
 filled when the model carries a `first_stage_model`.
 """
 import numpy as np

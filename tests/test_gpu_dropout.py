@@ -60,7 +60,7 @@ def test_dropout_sites_forward_backward(name, dtype):
         assert abs(keep - (1 - pk[kind])) < 0.06, (kind, layer, keep)
 
     lg = nm.forward(x.reshape(B, -1).to(DEV), ci.to(DEV), ti.to(DEV), training=True, dropout_seed=seed)
-    tol = 1e-4 if dtype == "f32" else 8e-2
+    tol = 1e-4 if dtype == "f32" else 2e-2
     assert (lg.cpu() - logits.detach()).abs().max().item() < tol
     scale = 1.0 / (B * seq_len * (ntw / seq_len))
     nm.backward(lg, scale)
