@@ -201,7 +201,10 @@ extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) 
     const int hd = d.n_embd / d.n_head;
     if (hd != 32 && hd != 64 && hd != 128) { mebt_set_error("model_create: head size must be 32, 64 or 128"); return MEBT_ESHAPE; }
     if (d.vocab % 8 || d.vocab <= 0) { mebt_set_error("model_create: vocab must be a positive multiple of 8"); return MEBT_ESHAPE; }
-    if (d.n_latent <= 0) { mebt_set_error("model_create: sos_emb (latent tokens) must be > 0 for the latent routing modes"); return MEBT_ESHAPE; }
+    if (d.n_latent < 0) { mebt_set_error("model_create: sos_emb (latent tokens) must be >= 0"); return MEBT_ESHAPE; }
+    if (d.n_latent == 0)          // sos_emb = 0 (transformer.py:273-276): only meaningful when no block routes through the latents
+        for (int i = 0; i < d.n_layer; ++i)
+            if (d.modes[i] != MEBT_MODE_MASKGIT) { mebt_set_error("model_create: sos_emb = 0 needs every block in 'maskgit' mode (the latent routings read / write the latent tokens)"); return MEBT_ESHAPE; }
     if (d.dtype != MEBT_F32 && d.dtype != MEBT_BF16) { mebt_set_error("model_create: dtype must be f32 or bf16"); return MEBT_EDTYPE; }
     for (int i = 0; i < d.n_layer; ++i)
         if (d.modes[i] < 0 || d.modes[i] > MEBT_MODE_MASKGIT) {

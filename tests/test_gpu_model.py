@@ -191,3 +191,42 @@ def test_maskgit_blocks_rewrite_both_streams(dtype, drop):
         with torch.no_grad():
             ref_eval = orc.reconstruct_mask(P0, cfg, x.reshape(B, -1), ci, ti)
         assert (ev.cpu() - ref_eval).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_all_maskgit_without_latents(dtype):
+    """`sos_emb = 0` (transformer.py:273-276 gives a [B,0,d] latent tensor) with every block in the
+    'maskgit' full-attention mode — a plain MaskGIT transformer: forward, eval forward and gradients vs the oracle; a latent
+    routing mode together with sos_emb = 0 is refused."""
+    from mebt_amd.engine import NativeModel
+    from mebt_amd import _lib
+    modes = ["maskgit"] * 3
+    cfg = orc.OracleConfig(3, 2, 64, 32, 0, modes, shape=[2, 4, 4], budget=32, avg_loss=1.0)
+    nm = NativeModel(cfg.n_layer, cfg.n_head, cfg.n_embd, cfg.vocab_size, 0, cfg.block_size, cfg.mode, dtype=dtype)
+    nm.allocate(DEV)
+    P0 = orc.closed_form_params(cfg)
+    views = nm.views(orc.param_shapes(cfg))
+    with torch.no_grad():
+        for k, v in P0.items():
+            views[k].copy_(v)
+    nm.sync_lowp(force=True)
+    x, idx = mg.inputs("micro", 2, "nosos")
+    for t in (0.4, 0.0):
+        P = {k: v.clone().requires_grad_(True) for k, v in P0.items()}
+        logits, z_t, ntw, seq_len = orc.forward(P, cfg, x, idx, t, training=True)
+        _, _, loss = orc.loss_and_acc(logits, z_t, ntw, seq_len, cfg)
+        loss.backward()
+        ci, ti, _ = orc.divide_indices(idx, t, cfg, True)
+        lg = nm.forward(x.reshape(2, -1).to(DEV), ci.to(DEV), ti.to(DEV), training=True)
+        tol = FP32_TIGHT if dtype == "f32" else 2 * BF16_TOL
+        assert (lg.cpu() - logits.detach()).abs().max().item() < tol
+        nm.backward(lg, 1.0 / (2 * seq_len * (ntw / seq_len)))
+        torch.cuda.synchronize()
+        gv = nm.views(orc.param_shapes(cfg), grads=True)
+        lim = 2e-3 if dtype == "f32" else BF16_GRAD_TOL
+        for k, p in P.items():
+            ref = p.grad if p.grad is not None else torch.zeros_like(p)
+            scale = P[k.replace("attn.key.bias", "attn.query.bias")].grad.abs().max().item() + 1e-9
+            assert (gv[k].cpu() - ref).abs().max().item() / scale < lim, (t, k)
+    with pytest.raises(_lib.MebtError, match="maskgit"):
+        NativeModel(2, 2, 64, 16384, 0, 32, ["latent_enc", "maskgit"], dtype=dtype)
