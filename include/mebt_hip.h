@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MEBT_ABI_VERSION 1
+#define MEBT_ABI_VERSION 2
 #define MEBT_MAX_LAYERS 128
 
 typedef void* mebt_stream_t;            /* hipStream_t */

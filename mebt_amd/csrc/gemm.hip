@@ -194,8 +194,9 @@ static int time_cold(F&& launch, hipStream_t stream, const TuneRun& tr, float& b
     float tot = 0.f;
     hipEvent_t e0 = tr.e0, e1 = tr.e1;
     launch();                                                                    // code object, TLBs
+    static const int warm = [] { const char* e = getenv("MEBT_GEMM_TUNE_WARM"); return e ? atoi(e) : 0; }();   // experiment: time candidates on warm caches
     for (int r = 0; r < 2; ++r) {
-        MEBT_HIP_CHECK(hipMemsetAsync(tr.sc->flush, r, tr.sc->flush_bytes, stream));
+        if (!warm) MEBT_HIP_CHECK(hipMemsetAsync(tr.sc->flush, r, tr.sc->flush_bytes, stream));
         MEBT_HIP_CHECK(hipEventRecord(e0, stream));
         launch();
         MEBT_HIP_CHECK(hipEventRecord(e1, stream));
