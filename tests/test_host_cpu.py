@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert set(_lib.PROTOTYPES) == declared, set(_lib.PROTOTYPES) ^ declared      # the binding covers the whole header
     bound = _lib.load()
-    assert bound.mebt_abi_version() == 1
+    assert bound.mebt_abi_version() == 2
 
 
 def test_product_fails_loudly_without_gpu():
