@@ -1,7 +1,7 @@
 """Data parallelism with the REAL HIP engine on one MI355X: two ranks share GPU 0 and talk over gloo (a 1-GPU box cannot
 run RCCL between two ranks on the same device), each running `TrainLoop` with the bucketed reducer of mebt_amd/parallel.py:
 the real `NativeModel` bucket ranges, `mebt_op_cast_bf16` -> reduce-scatter -> `mebt_adamw_slice` on the optimizer stream
--> all-gather of the bf16 mirror / fp32 tail, `consolidate()`.  2 ranks x batch 2 must equal 1 process x batch 4 after two
+-> all-gather of the bf16 mirror / fp32 tail, `consolidate()`.  2 ranks x batch 2 must equal 1 process x batch 4 after three
 steps (the DDP contract, reference train_transformer.py:39-41).  GPU only."""
 import os
 
@@ -29,9 +29,9 @@ def _make(dtype):
 
 def _batches():
     g = torch.Generator().manual_seed(12)
-    xs = [torch.randint(0, 16384, (4, 2, 8, 8), generator=g) for _ in range(2)]
-    idxs = [torch.stack([torch.randperm(128, generator=g) for _ in range(4)]) for _ in range(2)]
-    return xs, idxs, (0.45, 0.3)
+    xs = [torch.randint(0, 16384, (4, 2, 8, 8), generator=g) for _ in range(3)]
+    idxs = [torch.stack([torch.randperm(128, generator=g) for _ in range(4)]) for _ in range(3)]
+    return xs, idxs, (0.45, 0.3, 0.0)            # t = 0: NC = 0 (empty key/value reductions: zero-filled gradient slices)
 
 
 def _worker(rank, world, port, dtype, mode, wire, ret):
@@ -92,7 +92,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank_double_batch(dtype, mode, wire):
     n_w, n_p = loop.native.n_w, loop.native.n_p
     if mode == "sharded":
         gsz = 2 if wire == "bf16" else 4
-        assert wire_bytes == 2 * ((n_w + n_p) * gsz + n_w * (2 if dtype == "bf16" else 4) + n_p * 4)     # two steps
+        assert wire_bytes == 3 * ((n_w + n_p) * gsz + n_w * (2 if dtype == "bf16" else 4) + n_p * 4)     # three steps
     worst = 0.0
     for k, v in model.state_dict().items():
         d = np.abs(v.cpu().numpy() - sd2[k]).max()
@@ -100,7 +100,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank_double_batch(dtype, mode, wire):
         if dtype == "f32" and not k.endswith("attn.key.bias"):      # key.bias: zero gradient, AdamW amplifies rounding noise
             assert d <= 2e-5 * (1 + np.abs(sd2[k]).max()), (k, d)
         else:
-            assert d <= 4.4 * lr, (k, d)                             # two +-lr steps of a ~0 gradient whose sign flipped
+            assert d <= 6.6 * lr, (k, d)                             # three +-lr steps of a ~0 gradient whose sign flipped
     for a, b in zip(loop.native.adam, adam2):
         ref = a.cpu().numpy()
         tol = (1e-4 if dtype == "f32" else 3e-2) * np.abs(ref).max()
