@@ -253,8 +253,8 @@ def _dp_sharded_worker(rank, world, port, ret, wire):
         cfg = mg.oracle_cfg("micro")
         P0 = orc.closed_form_params(cfg)
         shapes = orc.param_shapes(cfg)
-        x, idx = mg.inputs("micro", 4, "dp")
-        per = 4 // world
+        x, idx = mg.inputs("micro", 6, "dp6")
+        per = 6 // world
         xs, ids = x[rank * per:(rank + 1) * per], idx[rank * per:(rank + 1) * per]
         Wn, Pn = flat_layout(cfg.n_layer)
         lr, wd = 1e-3, 0.05
@@ -312,32 +312,34 @@ def _dp_sharded_worker(rank, world, port, ret, wire):
         assert (nat.Wlp.float() - nat.W).abs().max() <= 8e-3 * nat.W.abs().max()      # mirror == bf16(master) after the gather
         if rank == 1:
             ret.put((nat.W.numpy().copy(), nat.P.numpy().copy(), nat.adam[0].numpy().copy(), nat.adam[3].numpy().copy(), stale,
-                     changed, mirror_ok, red.bytes_on_wire))
+                     changed, mirror_ok, red.bytes_on_wire, len(red._sharded_ranges)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("wire", ["fp32", "bf16"])
-def test_data_parallel_sharded_optimizer_gloo_world2(wire):
+@pytest.mark.parametrize("wire,world", [("fp32", 2), ("bf16", 2), ("fp32", 3)])
+def test_data_parallel_sharded_optimizer_gloo(wire, world):
     """reduce-scatter -> AdamW on the owned shard -> all-gather (the default data-parallel path, parallel.py) on 2 ranks x
     half batch == 1 process x full batch with the replicated optimizer: parameters and moments after one step, read on the
     NON-zero rank after consolidate().  fp32 wire: to rounding; bf16 wire: every parameter within the +-lr step AdamW takes
-    at step 1, moments to bf16 resolution."""
+    at step 1, moments to bf16 resolution.  world = 3: the head (16384 x 64), the per-layer non-Linear slices and the
+    tail do not divide into aligned shards and take the replicated fallback (all-reduce + full-range update) next to the
+    sharded W buckets."""
     import torch.multiprocessing as mp
     from mebt_amd.engine import flat_layout
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000) + (7 if wire == "bf16" else 0)
-    procs = [ctx.Process(target=_dp_sharded_worker, args=(r, 2, port, ret, wire)) for r in range(2)]
+    port = 31500 + (os.getpid() % 2000) + (7 if wire == "bf16" else 0) + 11 * world
+    procs = [ctx.Process(target=_dp_sharded_worker, args=(r, world, port, ret, wire)) for r in range(world)]
     for p in procs:
         p.start()
-    W2, P2, mW2, vP2, stale, changed, mirror_ok, wire_bytes = ret.get(timeout=300)
+    W2, P2, mW2, vP2, stale, changed, mirror_ok, wire_bytes, n_sharded = ret.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     cfg = mg.oracle_cfg("micro")
-    x, idx = mg.inputs("micro", 4, "dp")
+    x, idx = mg.inputs("micro", 6, "dp6")
     st = orc.TrainState(orc.closed_form_params(cfg), lr=1e-3, weight_decay=0.05)
     r = orc.train_step(st, cfg, x, idx, 0.4)
     Wn, Pn = flat_layout(cfg.n_layer)
@@ -347,7 +349,11 @@ def test_data_parallel_sharded_optimizer_gloo_world2(wire):
     vPref = np.concatenate([st.v[n].numpy().reshape(-1) for n in Pn])
     assert stale and changed > 0 and mirror_ok            # rank 1 did NOT hold rank 0's shards of the fp32 master before consolidate
     n_all = W2.size + P2.size
-    assert wire_bytes == (2 if wire == "bf16" else 4) * n_all + 2 * W2.size + 4 * P2.size    # reduce-scatter + all-gather payloads
+    if world == 2:
+        assert wire_bytes == (2 if wire == "bf16" else 4) * n_all + 2 * W2.size + 4 * P2.size    # reduce-scatter + all-gather payloads
+        assert n_sharded == 8                 # head + 3 x (W, P) layer buckets + tail
+    else:
+        assert n_sharded == 3                 # only the three 2-layer W buckets divide by 4 x 3; head, the P slices and the tail went the replicated way
     if wire == "fp32":
         assert np.allclose(W2, Wref, rtol=2e-4, atol=2e-6) and np.allclose(P2, Pref, rtol=2e-4, atol=2e-6)
         assert np.allclose(mW2, mWref, rtol=1e-4, atol=1e-9) and np.allclose(vP2, vPref, rtol=1e-4, atol=1e-12)
