@@ -356,7 +356,7 @@ def test_data_parallel_sharded_optimizer_gloo(wire, world):
         assert n_sharded == 3                 # only the three 2-layer W buckets divide by 4 x 3; head, the P slices and the tail went the replicated way
     if wire == "fp32":
         assert np.allclose(W2, Wref, rtol=2e-4, atol=2e-6) and np.allclose(P2, Pref, rtol=2e-4, atol=2e-6)
-        assert np.allclose(mW2, mWref, rtol=1e-4, atol=1e-9) and np.allclose(vP2, vPref, rtol=1e-4, atol=1e-12)
+        assert np.allclose(mW2, mWref, rtol=1e-4, atol=1e-6 * np.abs(mWref).max()) and np.allclose(vP2, vPref, rtol=1e-4, atol=1e-6 * np.abs(vPref).max())
     else:
         assert np.abs(W2 - Wref).max() <= 2.2e-3 and np.abs(P2 - Pref).max() <= 2.2e-3
         assert (np.abs(W2 - Wref) > 2e-5).mean() < 0.02                     # sign flips of ~0 gradients only
