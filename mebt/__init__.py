@@ -4,6 +4,8 @@
 `mebt_amd`.  Nothing is implemented in this package."""
 from mebt_amd.transformer import Net2NetTransformer  # noqa: F401
 from mebt_amd.mask_sampler import MaskGen  # noqa: F401
+from mebt_amd.vqgan import VQGAN, load_vqgan  # noqa: F401
+from mebt_amd.data import TokenData as VideoData  # noqa: F401  (the `vtokens` token-grid contract of reference data.py:236-305)
 
 
 def load_transformer(ckpt_path, device=None):
