@@ -102,3 +102,27 @@ def extrapolate(model, vq_input, total_length, step_size, context_size, temperat
     if samples is not None:
         log["samples"] = samples
     return log
+
+
+@torch.no_grad()
+def draft_and_revise_sample(model, batch_size, total_length, step_size, context_size, n_draft, draft_t, draft_k, draft_p, n_revise,
+                            revise_t, revise_k, revise_p, M, draft=None):
+    """Counterpart of `sample` in reference draft_and_revise_videos.py:22-60: one draft-and-revise pass over a zero (or given
+    draft) code map of `step_size / 4` latent frames, then the first stage's decode.  `draft` (array-like of token ids,
+    e.g. the code map a `bidirect_sample` run saved) skips the draft phase, as the shipped scripts do (`--np_draft`)."""
+    assert total_length == step_size                           # reference :27
+    T, H, W = model.mask_sampler.shape[-3:]
+    step = int(step_size * 0.25)
+    shape = (batch_size, step, H, W)
+    dev = model.device
+    skip_draft = draft is not None
+    x = torch.as_tensor(draft, dtype=torch.long, device=dev) if skip_draft else torch.zeros(shape, dtype=torch.long, device=dev)
+    x = model.draft_and_revise(x, None, n_draft, draft_t, draft_k, draft_p, n_revise, revise_t, revise_k, revise_p, M, skip_draft)
+    code_map = x.reshape(shape)
+    if code_map.shape[1] == 1:
+        code_map = code_map.expand(-1, 4, H, W)
+    log = {"class_label": torch.zeros(batch_size, 1, dtype=torch.long, device=dev), "code_maps": code_map}
+    samples = _decode(model, code_map, total_length)
+    if samples is not None:
+        log["samples"] = samples
+    return log

@@ -190,3 +190,8 @@ def test_transformer_with_pixel_input_uses_the_first_stage():
     out = model.draft_and_revise(ids_ref.to(DEV), None, 2, 1.0, None, None, 2, 1.0, None, None, 1, False)
     rec = model.first_stage_model.decode(out.view(2, 2, 4, 4))
     assert tuple(rec.shape) == tuple(video.shape) and torch.isfinite(rec).all()
+    # the script-level driver (draft_and_revise_videos.py:22-60): code map + decoded frames in [0, 1]
+    from mebt_amd.sampling import draft_and_revise_sample
+    log = draft_and_revise_sample(model, 2, 8, 8, 8, 2, 1.0, None, None, 2, 0.3, None, None, 2, draft=ids_ref.numpy())
+    assert tuple(log["code_maps"].shape) == (2, 2, 4, 4) and tuple(log["samples"].shape) == (2, 3, 4, 16, 16)
+    assert float(log["samples"].min()) >= 0.0 and float(log["samples"].max()) <= 1.0
