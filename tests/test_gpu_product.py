@@ -266,6 +266,16 @@ def test_launcher_trains_from_token_file(tmp_path):
     from mebt.transformer import Net2NetTransformer
     m = Net2NetTransformer.load_from_checkpoint(str(tmp_path / "runs" / "step=6.ckpt"))
     assert torch.equal(m.state_dict()["transformer.head.weight"].cpu(), ck["state_dict"]["transformer.head.weight"])
+    # --ckpt_path resumes (optimizer moments, step counters, RNG): the run continues at step 7 and stops at max_steps
+    assert {"adam", "step_count", "rng"} <= set(ck["mebt_amd_loop"]) and ck["mebt_amd_loop"]["step_count"] == 6
+    out2 = subprocess.run([sys.executable, "-m", "mebt_amd.train", "--preset", "tiny", "--tokens", f, "--max_steps", "10", "--log_every", "2",
+                           "--ckpt_every", "10", "--default_root_dir", str(tmp_path / "runs"), "--ckpt_path", str(tmp_path / "runs" / "step=6.ckpt"),
+                           "--accumulate_grad_batches", "1"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    steps = [int(v) for v in re.findall(r"step (\d+):", out2.stdout)]
+    assert steps == [8, 10], out2.stdout
+    ck2 = torch.load(str(tmp_path / "runs" / "step=10.ckpt"), map_location="cpu", weights_only=False)
+    assert ck2["global_step"] == 10 and ck2["mebt_amd_loop"]["step_count"] == 10
 
 
 # ---- robustness of the host side -------------------------------------------------------------------------
