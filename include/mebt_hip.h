@@ -255,6 +255,9 @@ void mebt_debug_gemm_variant(int32_t dma);
 /* Benchmarking only: a caller-owned device buffer (>= 496 MiB) the operator-level mebt_op_gemm may use as tuner /
  * split-K scratch (model-level entry points use their workspace); NULL removes it. */
 void mebt_debug_gemm_scratch(void* buf, int64_t bytes);
+/* Diagnostics only: with a device buffer of 4 x 8 bytes per workgroup installed, wave 0 of every workgroup of the plain bf16
+ * GEMM kernels stamps s_memtime at entry / first k-tile landed / main loop done / epilogue stores retired (NULL: off). */
+void mebt_debug_gemm_stamps(unsigned long long* buf);
 /* Benchmarking only: LDS-DMA ring depth (2 or 3) of the grouped weight-gradient GEMM. */
 void mebt_debug_grouped_stages(int32_t n);
 

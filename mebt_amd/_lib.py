@@ -71,6 +71,7 @@ PROTOTYPES = {
     "mebt_debug_gemm_variant": (None, [c_i32]),
     "mebt_debug_grouped_stages": (None, [c_i32]),
     "mebt_debug_gemm_scratch": (None, [c_vp, c_i64]),
+    "mebt_debug_gemm_stamps": (None, [c_vp]),
     "mebt_gemm_autotune": (None, [c_i32]),
     "mebt_profile_enable": (c_i32, [c_i32]),
     "mebt_profile_read": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -49,6 +49,8 @@ static int g_gemm_dma = -1;           // -1 autotune / heuristic; forced (tests,
 static int g_gemm_nostore = 0;        // experiments only (variant >= 100): skip the C store of plain epilogues
 extern "C" void mebt_debug_gemm_variant(int dma) { g_gemm_nostore = dma >= 100; g_gemm_dma = dma >= 100 ? (dma == 199 ? -1 : dma - 100) : dma; }
 void mebt_gemm_force_split(int s) { g_gemm_force_split = s; }
+static unsigned long long* g_gemm_stamps = nullptr;
+extern "C" void mebt_debug_gemm_stamps(unsigned long long* buf) { g_gemm_stamps = buf; }
 extern "C" void mebt_debug_gemm_tile(int bm, int bn) { g_gemm_force_tile = (bm && bn) ? ((bm << 12) | bn) : 0; }
 
 // one bf16 launch with an explicit (block tile, staging) choice; staging 0 = register-staged 2 stages,
@@ -272,6 +274,7 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     if ((!p.a_kc && (p.M % 8)) || (!p.b_kc && (p.N % 8))) { mebt_set_error("gemm: row extent of an RC operand must be a multiple of 8"); return MEBT_ESHAPE; }
     if (dtype == MEBT_F32) p.c_f32 = 1;
     if (g_gemm_nostore && p.epilogue == EPI_NONE) p.C = nullptr;
+    p.stamps = g_gemm_stamps;
     if (p.K <= 0) { mebt_set_error("gemm: K must be positive (empty reductions are handled by the caller)"); return MEBT_ESHAPE; }
     int split = 1;
     const bool can_split = p.c_f32 && p.epilogue == EPI_NONE && p.split_k > 1;   // atomics split-K only on request

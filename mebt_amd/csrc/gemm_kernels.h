@@ -511,6 +511,11 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
     char* ring = smem + grp * (NSTAGE * STAGE);
     const int ktb = kt0 + grp;                          // pipeline tile t is k-tile ktb + KS * t
 
+    unsigned long long* stamp = nullptr;                // diagnostics: wave 0, lane 0 of the workgroup
+    if (p.stamps && tid == 0) {
+        stamp = p.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
+        stamp[0] = __builtin_amdgcn_s_memtime();
+    }
     DmaLoader<A_KC, TBM> la;
     DmaLoader<B_KC, TBN> lb;
     la.init(p.A, p.M, p.K, p.lda, m0, wave, lane);
@@ -540,6 +545,7 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
         else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT) : "memory");
         __builtin_amdgcn_s_barrier();
+        if (stamp && t == 0) stamp[1] = __builtin_amdgcn_s_memtime();
         if (t + AHEAD < nk) {                            // slot of tile t-1: every wave is past its reads
             int s2 = st + AHEAD; if (s2 >= NSTAGE) s2 -= NSTAGE;
             la.issue(ring + s2 * STAGE, ktb + KS * (t + AHEAD), wave);
@@ -562,6 +568,7 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
         }
         if (++st == NSTAGE) st = 0;
     }
+    if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
     if (KS == 2) {
         // odd pipeline -> LDS -> even pipeline.  The exchange area starts above the epilogue's staging slabs
         // (4 waves x 16 rows x <= 132 floats = 33 KiB) and fits the two rings (checked by the launcher).
@@ -583,6 +590,10 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
         epilogue_via_lds<TM, TN, false>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
     } else {
         epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
+    }
+    if (stamp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's own stores have left
+        stamp[3] = __builtin_amdgcn_s_memtime();
     }
 }
 

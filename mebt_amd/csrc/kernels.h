@@ -51,6 +51,8 @@ struct GemmParams {
     const void* pf2 = nullptr;              // a second range, 4 lines per thread: saved forward activations the NEXT kernels of the
     unsigned pf2_bytes = 0;                 // backward chain read (they were written a whole forward + half a backward ago)
     unsigned* pf_sink = nullptr;            // always null at run time: keeps the prefetch loads alive for the compiler
+    unsigned long long* stamps = nullptr;   // diagnostics only (mebt_debug_gemm_stamps): [workgroup][4] s_memtime at entry / first tile landed /
+                                            // main loop done / epilogue done, written by wave 0 of each workgroup
 };
 int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 // two independent products with the same operand layouts in ONE launch (query- and key-side projections of a
