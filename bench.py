@@ -370,11 +370,18 @@ def main():
                                        ("sharded over ranks" if world > 1 and reducer.mode == "sharded" else "separate"),
                           "loss": round(float(stats[4]), 4)},
                "roofline": roof}
+        # the legs below run outside the timed region; a failure in one of them must not cost the headline line
         if world == 1 and args.secondary != "none" and args.preset == "sky_16f":
-            out["secondary"] = secondary_metrics(args, cfg, model, loop, x, idx, device, lib, args.secondary)
+            try:
+                out["secondary"] = secondary_metrics(args, cfg, model, loop, x, idx, device, lib, args.secondary)
+            except Exception as e:          # noqa: BLE001
+                out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
-            sd = {k: v.detach() for k, v in model.state_dict().items()}
-            out["cpu_baseline"] = cpu_baseline(sd, cfg, args.t)
+            try:
+                sd = {k: v.detach() for k, v in model.state_dict().items()}
+                out["cpu_baseline"] = cpu_baseline(sd, cfg, args.t)
+            except Exception as e:          # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
