@@ -41,10 +41,14 @@ class _Done:
 
 
 class GradReducer:
-    def __init__(self, world_size=None, group=None, layers_per_bucket=4, mode=None, wire=None):
+    def __init__(self, world_size=None, group=None, layers_per_bucket=4, mode=None, wire=None, force=None):
         self.group = group
         self.world_size = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.rank = dist.get_rank(group) if (self.world_size > 1 and dist.is_initialized()) else 0
+        # `force`: run the collective path even with one rank (an initialised process group of size 1): every RCCL call, dtype,
+        # buffer aliasing and stream hand-off of the N > 1 path executes on a single GPU (tests/test_gpu_dp.py)
+        force = (os.environ.get("MEBT_DP_FORCE", "0") == "1") if force is None else force
+        self.active = self.world_size > 1 or (bool(force) and dist.is_initialized())
         self.grad_scale = 1.0 / self.world_size
         self.layers_per_bucket = layers_per_bucket
         self.mode = mode or os.environ.get("MEBT_DP_MODE", "sharded")
@@ -56,7 +60,7 @@ class GradReducer:
         self._wire_buf = {}
         self._rs_out = {}
         self._sharded_ranges = set()     # (which, start, end) of every bucket range that was cut into shards: what consolidate() gathers
-        self._inplace = not (self.world_size > 1 and dist.is_initialized() and dist.get_backend(group) != "nccl")
+        self._inplace = not (self.active and dist.is_initialized() and dist.get_backend(group) != "nccl")
 
     # ---- collectives -------------------------------------------------------------------------------------------------------
     # RCCL: asynchronous, ordered after the current stream, in place where send and receive buffers alias.  A gloo group
@@ -99,7 +103,7 @@ class GradReducer:
     def bucket_ready(self, native, stage, hi, lo):
         """Launch the asynchronous all-reduce(s) of the gradient slices that `stage` finalised; returns the
         list of work handles (empty when world_size == 1)."""
-        if self.world_size == 1:
+        if not self.active:
             return []
         works = []
         for which, a, b in self.bucket_ranges(native, stage, hi, lo):
@@ -190,7 +194,7 @@ class GradReducer:
     # ---- parameters ----------------------------------------------------------------------------------------------------------
     def broadcast_parameters(self, native, src=0):
         """DDP's start-up broadcast rank0 -> all"""
-        if self.world_size == 1:
+        if not self.active:
             return
         dist.broadcast(native.W, src=src, group=self.group)
         dist.broadcast(native.P, src=src, group=self.group)
@@ -200,7 +204,7 @@ class GradReducer:
     def consolidate(self, native, optimizer_state=False):
         """Make the fp32 masters (and, on request, the AdamW moments) complete on every rank: after sharded steps each rank
         holds the current values of its own shards only.  A collective: call on ALL ranks (before state_dict / a checkpoint)."""
-        if self.world_size == 1 or self.mode != "sharded":
+        if not self.active or self.mode != "sharded":
             return
         world, rank = self.world_size, self.rank
         tensors = [(0, native.W)] if self.master_stale else []
@@ -217,7 +221,7 @@ class GradReducer:
 
     def mean_scalars(self, t):
         """one small all-reduce for the logged scalars (the reference issues four: loss, acc1, acc5, lr)"""
-        if self.world_size == 1:
+        if not self.active:
             return t
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t / self.world_size

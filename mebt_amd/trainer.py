@@ -15,8 +15,8 @@ class TrainLoop:
     def __init__(self, model, reducer=None, max_steps=0, overlap_optimizer=None, fused_optimizer=None,
                  accumulate_grad_batches=1):
         if overlap_optimizer is None:   # pays when there is an all-reduce to hide behind; on one GPU both contend for HBM
-            world = reducer.world_size if reducer is not None else 1
-            overlap_optimizer = os.environ.get("MEBT_OVERLAP_OPT", "1" if world > 1 else "0") != "0"
+            multi = reducer is not None and getattr(reducer, "active", reducer.world_size > 1)
+            overlap_optimizer = os.environ.get("MEBT_OVERLAP_OPT", "1" if multi else "0") != "0"
         """model: mebt_amd.transformer.Net2NetTransformer on its GPU, with learning_rate /
         warmup_steps / weight_decay / cosine_lr set (train_transformer.py:54-66)."""
         self.model = model
@@ -33,7 +33,7 @@ class TrainLoop:
         # (after its all-reduce when data-parallel): AdamW streams 30 B/parameter through HBM while the rest
         # of backward is latency/compute-bound, so the two overlap almost perfectly
         self.opt_stream = torch.cuda.Stream(device=self.native.device) if overlap_optimizer else None
-        if self.reducer.world_size > 1 and self.reducer.mode == "sharded":
+        if self.reducer.active and self.reducer.mode == "sharded":
             self.native._adam_state()           # allocated up front: the first sharded update runs on the optimizer stream
             if self.reducer.wire == "bf16" and self.accum == 1 and os.environ.get("MEBT_DP_WIRE_GRADS", "1") != "0":
                 self.native.enable_wire_grads()     # weight gradients leave the MFMA epilogue in the wire format
@@ -42,7 +42,7 @@ class TrainLoop:
         # data-parallel job needs the gradients first, so this is the single-GPU path only
         if fused_optimizer is None:   # the fp32 parity mode has no fused epilogue (the engine would fall back to one AdamW launch per weight)
             fused_optimizer = os.environ.get("MEBT_FUSED_ADAMW", "1") != "0" and model.compute_dtype == "bf16"
-        self.fused_optimizer = bool(fused_optimizer) and self.reducer.world_size == 1
+        self.fused_optimizer = bool(fused_optimizer) and not self.reducer.active
         # gradient accumulation (train_transformer.py:46-49 -> Lightning accumulate_grad_batches): `step` is called once per
         # micro-batch; gradients of k consecutive calls are averaged (loss / k, as Lightning scales it), the all-reduce, the
         # optimizer and the step counters run on the k-th.  The optimizer-in-backward needs the whole gradient in one
@@ -87,7 +87,7 @@ class TrainLoop:
             nm.backward(logits, bwd_scale, between=lambda s, hi, lo: red.bucket_ready(nm, s, hi, lo))
             red.wait()
             nm.adamw_step(lr, m.weight_decay, self.step_count, grad_scale=red.grad_scale)
-        elif red.world_size > 1 and red.mode == "sharded":
+        elif red.active and red.mode == "sharded":
             # reduce-scatter -> AdamW on this rank's shard -> all-gather, bucket by bucket behind the backward (parallel.py)
             opt = self.opt_stream
             nm.backward(logits, bwd_scale, bucket_layers=red.layers_per_bucket,

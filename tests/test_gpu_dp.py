@@ -106,3 +106,63 @@ def test_two_ranks_on_one_gpu_equal_one_rank_double_batch(dtype, mode, wire):
         tol = (1e-4 if dtype == "f32" else 3e-2) * np.abs(ref).max()
         assert np.abs(ref - b).max() <= tol
     print(f"[dp {dtype} {mode} wire {wire}] max |dp| vs single process {worst:.3e}; loss {loss2:.5f}")
+
+
+def _rccl_worker(port, dtype, mode, wire, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from mebt_amd.parallel import GradReducer
+        from mebt_amd.trainer import TrainLoop
+        model = _make(dtype).to(DEV).train()
+        red = GradReducer(world_size=1, mode=mode, wire=wire, force=True)
+        assert red.active and red._inplace
+        loop = TrainLoop(model, red)
+        assert not loop.fused_optimizer and loop.opt_stream is not None
+        xs, idxs, ts = _batches()
+        for x, idx, t in zip(xs, idxs, ts):
+            st = loop.step(x.to(DEV), idx.to(DEV), t=t)
+        loss = red.mean_scalars(st[4:5].clone()).cpu()
+        loop.consolidate()
+        torch.cuda.synchronize()
+        sd = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+        ret.put((sd, float(loss), red.bytes_on_wire, loop.native.gWb is not None))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,mode,wire", [("bf16", "sharded", "bf16"), ("f32", "sharded", "fp32"), ("f32", "allreduce", "fp32")])
+def test_rccl_executes_the_collective_path_with_one_rank(dtype, mode, wire):
+    """RCCL itself (torch.distributed backend "nccl") on the one GPU of this box: a process group of size 1 with the
+    reducer forced active, so that `reduce_scatter_tensor` (bf16 and fp32), the in-place `all_gather_into_tensor` into the
+    bf16 mirror / fp32 tail, `all_reduce`, `broadcast`, the asynchronous work handles and the hand-offs between the compute,
+    RCCL and optimizer streams all run exactly as in the N-GPU job (a shard is then the whole bucket).  Result == the plain
+    single-process step."""
+    import torch.multiprocessing as mp
+    from mebt_amd.trainer import TrainLoop
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 33400 + (os.getpid() % 1500) + {"fp32": 0, "bf16": 3}[wire] + (5 if mode == "allreduce" else 0)
+    p = ctx.Process(target=_rccl_worker, args=(port, dtype, mode, wire, ret))
+    p.start()
+    sd1, loss1, wire_bytes, wire_grads = ret.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    model = _make(dtype).to(DEV).train()
+    loop = TrainLoop(model, fused_optimizer=False)
+    xs, idxs, ts = _batches()
+    for x, idx, t in zip(xs, idxs, ts):
+        st = loop.step(x.to(DEV), idx.to(DEV), t=t)
+    torch.cuda.synchronize()
+    assert wire_bytes > 0 and wire_grads == (dtype == "bf16" and mode == "sharded")
+    assert abs(float(st[4]) - loss1) < (1e-6 if dtype == "f32" else 2e-3) * abs(float(st[4]))
+    lr = 1e-3
+    for k, v in model.state_dict().items():
+        d = np.abs(v.cpu().numpy() - sd1[k]).max()
+        if dtype == "f32" and not k.endswith("attn.key.bias"):
+            assert d <= 1e-6 * (1 + np.abs(sd1[k]).max()), (k, d)          # one rank: the "sum" is the gradient itself
+        else:
+            assert d <= 6.6 * lr, (k, d)                                      # bf16 wire: sign flips of ~0 gradients, three steps
