@@ -105,7 +105,8 @@ def test_ucf128f_geometry_revise_forward_properties():
     m16.load_state_dict(sd)
     m16 = m16.to(DEV).eval()
     l16, _ = m16.reconstruct_mask(x, ci, ti)
-    assert (l16 - l32).abs().max().item() < 0.15 and (l16.argmax(-1) == l32.argmax(-1)).float().mean() > 0.5
+    # bf16 vs fp32 on the same weights: <= 2x the 0.9 % of max |logits| measured against the oracle (test_gpu_benchsize.py)
+    assert (l16 - l32).abs().max().item() < 1.7e-2 * l32.abs().max().item() and (l16.argmax(-1) == l32.argmax(-1)).float().mean() > 0.95
 
 
 def test_sample_loop_full_size_invariants():
