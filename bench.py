@@ -281,8 +281,10 @@ def main():
         local_rank, backend = 0, "gloo"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    dp_force = world == 1 and os.environ.get("MEBT_DP_FORCE") == "1"    # one rank, but the whole N > 1 path: RCCL group of size 1, sharded reducer
+    if world > 1 or dp_force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend, rank=rank, world_size=world, device_id=device if backend == "nccl" else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -364,10 +366,10 @@ def main():
                "per_gpu": round(value / world, 1),
                "config": {"workload": "Sky-Timelapse 16f MeBT train step: 24L/1024d/16h, 1024 VQ tokens + 256 latents, "
                                       f"batch {args.batch}/GPU, t={args.t} (NC=NT={n_targets // args.batch}), "
-                                      "fwd + masked CE + bwd + AdamW" + (f" + reduce-scatter / sharded AdamW / all-gather ({reducer.mode}, {reducer.wire} wire)" if world > 1 else ""),
+                                      "fwd + masked CE + bwd + AdamW" + (f" + reduce-scatter / sharded AdamW / all-gather ({reducer.mode}, {reducer.wire} wire)" if reducer.active else ""),
                           "global_batch": args.batch * world, "parallelism": f"dp{world}", "dropout": args.dropout,
                           "optimizer": "in-backward (fused into the weight-gradient launches)" if loop.fused_optimizer else
-                                       ("sharded over ranks" if world > 1 and reducer.mode == "sharded" else "separate"),
+                                       ("sharded over ranks" if reducer.active and reducer.mode == "sharded" else "separate"),
                           "loss": round(float(stats[4]), 4)},
                "roofline": roof}
         # the legs below run outside the timed region; a failure in one of them must not cost the headline line
@@ -383,7 +385,7 @@ def main():
             except Exception as e:          # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or dp_force:
         dist.barrier()
         dist.destroy_process_group()
 

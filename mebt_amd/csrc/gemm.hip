@@ -426,6 +426,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
                 for (int st = 2; st <= 4; ++st) {
                     float ms = 0.f;
                     if (int rc = time_cold([&] { launch_grouped_config(tc, tiles[t][0], tiles[t][1], st, stream); }, stream, tr, ms)) return rc;
+                    if (g_tune_log >= 2) fprintf(stderr, "    cand grouped %dx%d ring %d%s%s: %.1f us\n", tiles[t][0], tiles[t][1], st, tc.fused ? " +adamw" : "", tc.Cb ? " bf16-out" : "", ms * 1e3f);
                     if (ms < best) { best = ms; tbm = tiles[t][0]; tbn = tiles[t][1]; stages = st; }
                 }
             if (g_tune_log) {

@@ -213,9 +213,11 @@ class NativeModel:
             self.backward_head(logits, loss_scale, upstream)
         if between:
             between("head", None, None)
-        step = max(1, int(bucket_layers))
-        hi = self.n_layer - 1
+        sizes = list(bucket_layers) if isinstance(bucket_layers, (list, tuple)) else None     # per-bucket layer counts, top down
+        hi, nb = self.n_layer - 1, 0
         while hi >= 0:
+            step = max(1, int(sizes[min(nb, len(sizes) - 1)] if sizes else bucket_layers))
+            nb += 1
             lo = max(0, hi - step + 1)
             self.backward_layers(hi, lo)
             if between:

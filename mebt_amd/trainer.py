@@ -90,7 +90,7 @@ class TrainLoop:
         elif red.active and red.mode == "sharded":
             # reduce-scatter -> AdamW on this rank's shard -> all-gather, bucket by bucket behind the backward (parallel.py)
             opt = self.opt_stream
-            nm.backward(logits, bwd_scale, bucket_layers=red.layers_per_bucket,
+            nm.backward(logits, bwd_scale, bucket_layers=red.bucket_plan(nm.n_layer),
                         between=lambda s, hi, lo: red.reduce_update(nm, s, hi, lo, lr, m.weight_decay, self.step_count, opt_stream=opt))
             red.finish(opt)                                         # the next forward reads the gathered weights
         else:

@@ -296,13 +296,19 @@ def _dp_sharded_worker(rank, world, port, ret, wire):
         nat.gW = torch.cat([Pg[n].grad.reshape(-1) for n in Wn])
         nat.gP = torch.cat([Pg[n].grad.reshape(-1) for n in Pn])
         red.reduce_update(nat, "head", None, None, lr, wd, 1)
+        plan = red.bucket_plan(cfg.n_layer)
+        assert plan == [2, 2, 1, 1] and sum(plan) == cfg.n_layer       # tapered: the exposed last bucket is the smallest
         hi = cfg.n_layer - 1
-        while hi >= 0:
-            lo = max(0, hi - 1)
+        for size in plan:
+            lo = hi - size + 1
             red.reduce_update(nat, "layers", hi, lo, lr, wd, 1)
             hi = lo - 1
         red.reduce_update(nat, "embed", None, None, lr, wd, 1)
         red.finish()
+        stages = [("head", None, None)] + [("layers", h, h - s + 1) for h, s in zip(np.cumsum([cfg.n_layer - 1] + [-s for s in plan[:-1]]).tolist(), plan)] + [("embed", None, None)]
+        all_ranges = [r for st in stages for r in red.sharded_ranges(nat, *st)]
+        assert sum(b - a for w, a, b in all_ranges) == nat.W.numel() + nat.P.numel()              # the buckets tile both buffers exactly
+        divisible = sum(1 for w, a, b in all_ranges if (b - a) % (4 * world) == 0)
         # between steps: the bf16 mirror and P are complete everywhere, the fp32 master of W only on its owners
         mirror_ok = bool(torch.isfinite(nat.Wlp.float()).all())
         stale = red.master_stale
@@ -312,7 +318,7 @@ def _dp_sharded_worker(rank, world, port, ret, wire):
         assert (nat.Wlp.float() - nat.W).abs().max() <= 8e-3 * nat.W.abs().max()      # mirror == bf16(master) after the gather
         if rank == 1:
             ret.put((nat.W.numpy().copy(), nat.P.numpy().copy(), nat.adam[0].numpy().copy(), nat.adam[3].numpy().copy(), stale,
-                     changed, mirror_ok, red.bytes_on_wire, len(red._sharded_ranges)))
+                     changed, mirror_ok, red.bytes_on_wire, len(red._sharded_ranges), divisible, len(all_ranges)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -334,7 +340,7 @@ def test_data_parallel_sharded_optimizer_gloo(wire, world):
     procs = [ctx.Process(target=_dp_sharded_worker, args=(r, world, port, ret, wire)) for r in range(world)]
     for p in procs:
         p.start()
-    W2, P2, mW2, vP2, stale, changed, mirror_ok, wire_bytes, n_sharded = ret.get(timeout=300)
+    W2, P2, mW2, vP2, stale, changed, mirror_ok, wire_bytes, n_sharded, divisible, n_ranges = ret.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -351,9 +357,9 @@ def test_data_parallel_sharded_optimizer_gloo(wire, world):
     n_all = W2.size + P2.size
     if world == 2:
         assert wire_bytes == (2 if wire == "bf16" else 4) * n_all + 2 * W2.size + 4 * P2.size    # reduce-scatter + all-gather payloads
-        assert n_sharded == 8                 # head + 3 x (W, P) layer buckets + tail
+        assert n_sharded == n_ranges == 6     # head + 4 W layer buckets (2, 2, 1, 1 layers) + one bucket of all non-Linear parameters
     else:
-        assert n_sharded == 3                 # only the three 2-layer W buckets divide by 4 x 3; head, the P slices and the tail went the replicated way
+        assert n_sharded == divisible == 4 and n_ranges == 6      # only the four W layer buckets divide by 4 x 3; the head and the non-Linear bucket went the replicated way
     if wire == "fp32":
         assert np.allclose(W2, Wref, rtol=2e-4, atol=2e-6) and np.allclose(P2, Pref, rtol=2e-4, atol=2e-6)
         assert np.allclose(mW2, mWref, rtol=1e-4, atol=1e-6 * np.abs(mWref).max()) and np.allclose(vP2, vPref, rtol=1e-4, atol=1e-6 * np.abs(vPref).max())
