@@ -144,6 +144,15 @@ int mebt_model_set_fused_adamw(mebt_model* m, float* mW, float* vW, float lr, fl
  * gradient accumulation, fused optimizer disarmed) mebt_backward_* store the Linear weight gradients THERE, rounded once from
  * the fp32 MFMA accumulators, and leave gW untouched: the reduce-scatter of SURVEY.md §5.8 sends the buffer as is. */
 int mebt_model_bind_wire_grads(mebt_model* m, void* gWb);
+
+/* Sharded data parallelism (mebt_amd/parallel.py; the reference's counterpart is DDP's all-reduce, train_transformer.py:39-41):
+ * the all-gathers that bring the other ranks' updated parameters may still be running when the next forward is enqueued.
+ * `events[i]` (a hipEvent_t the caller recorded after the gather) must have completed before the forward touches the
+ * parameters first read by block `layer[i]`; layer -1 = everything outside the Linear weights (embeddings, biases,
+ * LayerNorms: read from the first kernel on), layer n_layer = the head weight.  One-shot: the next forward on this
+ * model (training or inference) waits for them on its stream (hipStreamWaitEvent, no host synchronisation) and forgets
+ * them.  The events stay owned by the caller and must outlive that forward's enqueue. */
+int mebt_model_set_forward_waits(mebt_model* m, int32_t n, const int32_t* layer, void* const* events);
 /* Gradient accumulation over micro-batches (reference train_transformer.py:46-49, Lightning's accumulate_grad_batches):
  * on = 1: the following mebt_backward_* calls ADD to gW / gP; on = 0 (default): they overwrite.  Not together with
  * mebt_model_set_fused_adamw. */

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "mebt_model_set_fused_adamw": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32]),
     "mebt_model_set_grad_accumulate": (c_i32, [c_vp, c_i32]),
     "mebt_model_bind_wire_grads": (c_i32, [c_vp, c_vp]),
+    "mebt_model_set_forward_waits": (c_i32, [c_vp, c_i32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
     "mebt_op_gemm": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 13 + [c_vp]),
     "mebt_op_layernorm_fwd": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "mebt_op_layernorm_bwd": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),

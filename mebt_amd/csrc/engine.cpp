@@ -98,6 +98,8 @@ struct mebt_model {
     float *fused_mW = nullptr, *fused_vW = nullptr;
     AdamWHyper fused_h = {0, 0, 0, 0, 0, 1, 1, 1};
     bool wire() const { return gWb && d.dtype == MEBT_BF16 && !grad_acc && !fused_on; }
+    // mebt_model_set_forward_waits: one-shot (first layer that reads the parameters, event) pairs the next forward honours
+    std::vector<std::pair<int, hipEvent_t>> fw_waits;
     int esz() const { return d.dtype == MEBT_BF16 ? 2 : 4; }
     // weight operand for GEMMs (bf16 mirror in bf16 mode)
     const void* Wop(int64_t off) const {
@@ -455,6 +457,28 @@ static void set_pf2(const mebt_model* m, GemmParams& p, const void* lo, const vo
 static void pf2_tail(const mebt_model* m, GemmParams& p, const LayerAct& a) { set_pf2(m, p, a.x, (const char*)a.out); }        // x, LN2 stats, hn, pre, u
 static void pf2_head(const mebt_model* m, GemmParams& p, const LayerAct& a) { set_pf2(m, p, a.qn, (const char*)a.x); }          // qn, kn, q, k, v, att, lse
 
+// Parameter dependencies of the next forward (sharded data parallelism: the all-gather of a bucket's updated weights may
+// still be in flight when the forward starts; it only has to be complete when the first block of that bucket runs).
+static int fw_wait(const mebt_model* m, int layer, hipStream_t st) {
+    for (const auto& w : m->fw_waits)
+        if (w.first == layer) MEBT_HIP_CHECK(hipStreamWaitEvent(st, w.second, 0));
+    return MEBT_OK;
+}
+static bool fw_pending(const mebt_model* m, int layer) {
+    for (const auto& w : m->fw_waits)
+        if (w.first == layer) return true;
+    return false;
+}
+extern "C" int mebt_model_set_forward_waits(mebt_model* m, int32_t n, const int32_t* layer, void* const* events) {
+    if (!m || n < 0 || (n > 0 && (!layer || !events))) { mebt_set_error("set_forward_waits: bad arguments"); return MEBT_EINVAL; }
+    m->fw_waits.clear();
+    for (int i = 0; i < n; ++i) {
+        if (layer[i] < -1 || layer[i] > m->d.n_layer || !events[i]) { mebt_set_error("set_forward_waits: layer outside [-1, n_layer] or null event"); m->fw_waits.clear(); return MEBT_EINVAL; }
+        m->fw_waits.emplace_back(layer[i], reinterpret_cast<hipEvent_t>(events[i]));
+    }
+    return MEBT_OK;
+}
+
 static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
                         const int64_t* x_ids, const int64_t* ci, const int64_t* ti, const float* const* embedded,
                         float* logits, int32_t training, uint64_t dropout_seed, mebt_stream_t stream) {
@@ -472,6 +496,7 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
     if (c.off + 256 > ws_bytes) { mebt_set_error("forward: workspace too small (see mebt_workspace_bytes)"); return MEBT_EWORKSPACE; }
     hipStream_t st = S(stream);
     const int d = m->d.n_embd, NS = m->d.n_latent, H = m->d.n_head, V = m->d.vocab, dt = m->d.dtype;
+    RC(fw_wait(m, -1, st));                                // the non-Linear parameters (embeddings, every bias / LayerNorm)
     x.ws = ws; x.B = B; x.N = N; x.NC = NC; x.NT = NT; x.x_ids = x_ids; x.ci = ci; x.ti = ti;
     x.drop_on = drop_on; x.drop_seed = dropout_seed;
     const float p_emb = drop_on ? m->d.embd_pdrop : 0.f, p_res = drop_on ? m->d.resid_pdrop : 0.f, p_att = drop_on ? m->d.attn_pdrop : 0.f;
@@ -513,6 +538,7 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         const LayerOffsets& o = m->lo[i];
         const int mode = m->d.modes[i];
         const int Mq = B * a.NQ, Mk = B * a.NK;
+        RC(fw_wait(m, i, st));                             // a bucket of Linear weights that starts at this block
         a.q_in = (mode == MEBT_MODE_LATENT_DEC) ? Tv : (mode == MEBT_MODE_MASKGIT) ? Cv : Sv;
         // LN1 on query and key with the SAME parameters (gpt.py:180-181), then the projections
         // (gpt.py:126-128); the three [d,d] weights are adjacent in W so QKV / KV fuse.  The key side
@@ -589,7 +615,8 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
             GemmParams p = gp(a.u, m->Wop(o.w2), a.out, Mq, d, 4 * d, 4 * d, 4 * d, d, 1, 1);
             p.bias = m->P + o.b2; p.epilogue = EPI_RESID; p.aux = a.x; p.ld_aux = d;
             p.drop = make_drop(dropout_seed, 16 * i + SITE_MLP, p_res);     // gpt.py:154
-            if (i + 1 < m->d.n_layer) set_pf(m, p, m->lo[i + 1].wq, (int64_t)3 * d * d);
+            if (fw_pending(m, i + 1)) {}                   // those weights may still be arriving: no touch before the wait
+            else if (i + 1 < m->d.n_layer) set_pf(m, p, m->lo[i + 1].wq, (int64_t)3 * d * d);
             else set_pf(m, p, m->head_w, (int64_t)V * d);
             RC(gemm(m, p, st));
         }
@@ -604,11 +631,13 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
     x.S_final = Sv; x.T_final = Tv;
     // logits = head(ln_f(targets))  (gpt.py:247-248; head has no bias)
     RC(ln_fwd(m, Tv, x.hf, m->lnf_w, m->lnf_b, x.meanf, x.rstdf, B * NT, 0, 0, 0, st));
+    RC(fw_wait(m, m->d.n_layer, st));                      // the head weight
     {
         GemmParams p = gp(x.hf, m->Wop(m->head_w), logits, B * NT, V, d, d, d, V, 1, 1);
         p.c_f32 = 1;
         RC(gemm(m, p, st));
     }
+    m->fw_waits.clear();                                   // one-shot
     x.valid = training != 0;
     x.loss_done = false;
     return MEBT_OK;

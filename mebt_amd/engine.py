@@ -269,6 +269,18 @@ class NativeModel:
             self.gWb = None
             check(self.lib.mebt_model_bind_wire_grads(self.h, None))
 
+    def set_forward_waits(self, waits):
+        """[(layer, torch.cuda.Event)]: the next forward (training or inference) waits, on its stream, for each event before
+        it reads the parameters first used by block `layer` (-1: everything outside the Linear weights; n_layer: the head).
+        One-shot.  The events are kept alive here until the next call."""
+        import ctypes as C
+        waits = list(waits)
+        n = len(waits)
+        layers = (C.c_int32 * max(1, n))(*[int(l) for l, _ in waits])
+        evs = (C.c_void_p * max(1, n))(*[int(e.cuda_event) for _, e in waits])
+        check(self.lib.mebt_model_set_forward_waits(self.h, n, layers, evs))
+        self._fw_events = [e for _, e in waits]
+
     def set_grad_accumulate(self, on):
         """on: the next backward adds to the gradient buffers (a further micro-batch); off: it overwrites them"""
         check(self.lib.mebt_model_set_grad_accumulate(self.h, 1 if on else 0))

@@ -52,6 +52,15 @@ class GradReducer:
         self.grad_scale = 1.0 / self.world_size
         self.layers_per_bucket = layers_per_bucket
         self.taper = os.environ.get("MEBT_DP_TAPER", "1") != "0"
+        # deferred gathers: the all-gathers of the updated shards are issued after the whole backward, in the order the NEXT
+        # forward reads the parameters, and that forward waits bucket by bucket (mebt_model_set_forward_waits) instead of
+        # waiting for all of them up front: the reduce-scatters get the backward window to themselves and the gathers
+        # overlap the forward
+        self.defer = os.environ.get("MEBT_DP_DEFER_GATHER", "1") != "0"
+        self._deferred = []          # (first layer that reads it, full, mine) per sharded bucket
+        self._repl_keys = []         # first-reading layers of buckets updated the replicated way (no gather, but the forward still waits for their AdamW)
+        self._last_opt = self._native = None
+        self._test_delay = int(os.environ.get("MEBT_DP_TEST_DELAY_CYCLES", "0"))
         self.mode = mode or os.environ.get("MEBT_DP_MODE", "sharded")
         self.wire = wire or os.environ.get("MEBT_DP_WIRE", "bf16")
         assert self.mode in ("sharded", "allreduce") and self.wire in ("bf16", "fp32")
@@ -151,6 +160,10 @@ class GradReducer:
         world, rank = self.world_size, self.rank
         gpu = native.gW.is_cuda
         main = torch.cuda.current_stream() if gpu else None
+        self._last_opt, self._native = opt_stream, native
+        # the first thing the next forward does with this bucket: -1 = its first kernel (embeddings, biases, LayerNorms),
+        # a block index, or n_layer = the head
+        key = native.n_layer if stage == "head" else (lo if stage == "layers" else -1)
         for which, a, b in self.sharded_ranges(native, stage, hi, lo):
             n = b - a
             if n == 0:
@@ -162,6 +175,7 @@ class GradReducer:
                 self._on_opt(opt_stream, main, lambda: (w.wait(), native.adamw_slice(which, a, n, g, lr, weight_decay, step, betas=betas,
                                                                                       eps=eps, grad_scale=self.grad_scale,
                                                                                       stream=self._sid(opt_stream))))
+                self._repl_keys.append(key)
                 continue
             shard = n // world
             sa = a + rank * shard
@@ -179,14 +193,17 @@ class GradReducer:
             self.bytes_on_wire += n * wire.element_size()
             lowp = native.Wlp if which == 0 else None
 
-            def tail(w=w, which=which, a=a, b=b, sa=sa, shard=shard, out=out, lowp=lowp):
+            def tail(w=w, which=which, a=a, b=b, sa=sa, shard=shard, out=out, lowp=lowp, key=key):
                 w.wait()                                                       # the optimizer stream waits for the reduce-scatter
                 native.adamw_slice(which, sa, shard, out, lr, weight_decay, step, betas=betas, eps=eps, grad_scale=self.grad_scale,
                                    stream=self._sid(opt_stream))
                 full_t = lowp if lowp is not None else (native.W if which == 0 else native.P)
                 full, mine = full_t[a:b], full_t[sa:sa + shard]
-                self.pending.append(self._all_gather(full, mine))
-                self.bytes_on_wire += full.numel() * full.element_size()
+                if self.defer:
+                    self._deferred.append((key, full, mine))                   # gather_deferred()
+                else:
+                    self.pending.append(self._all_gather(full, mine))
+                    self.bytes_on_wire += full.numel() * full.element_size()
                 if lowp is not None:
                     self.master_stale = True
 
@@ -196,17 +213,54 @@ class GradReducer:
     def _sid(stream):
         return stream.cuda_stream if stream is not None else None
 
-    @staticmethod
-    def _on_opt(opt_stream, main, fn):
+    def _on_opt(self, opt_stream, main, fn):
         if opt_stream is None:
             fn()
             return
         opt_stream.wait_stream(main)            # the bucket's gradients (and the cast) are enqueued on the compute stream
         with torch.cuda.stream(opt_stream):
+            if self._test_delay:                # tests: make the optimizer / gather side late, so a missing wait shows up as stale weights
+                torch.cuda._sleep(self._test_delay)
             fn()
+
+    def gather_deferred(self, native, opt_stream=None):
+        """After the last bucket of a step: issue the deferred all-gathers in the order the next forward needs them (non-Linear
+        parameters, blocks bottom-up, head) and hand the engine one event per bucket.  The compute stream is NOT made to wait
+        here: the next forward — training or inference — waits for each event right before the first block that reads the
+        bucket.  Anything else that reads parameters on the compute stream must call finish() first (consolidate() does)."""
+        if not self._deferred and not self._repl_keys:
+            return
+        order, self._deferred = sorted(self._deferred, key=lambda r: r[0]), []
+        repl, self._repl_keys = self._repl_keys, []
+        gpu = native.gW.is_cuda and hasattr(native, "set_forward_waits")
+        main = torch.cuda.current_stream() if native.gW.is_cuda else None
+        waits = []
+
+        def run():
+            if gpu and repl:                     # their AdamW ran on this stream: one event after all of it
+                ev = torch.cuda.Event()
+                ev.record()
+                waits.extend((k, ev) for k in sorted(set(repl)))
+            for key, full, mine in order:
+                w = self._all_gather(full, mine)
+                self.bytes_on_wire += full.numel() * full.element_size()
+                if gpu:
+                    w.wait()                     # this (optimizer) stream waits for the gather; RCCL runs them in order anyway
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    waits.append((key, ev))
+                else:
+                    self.pending.append(w)
+
+        self._on_opt(opt_stream, main, run)
+        if gpu:
+            native.set_forward_waits(waits)
 
     def finish(self, opt_stream=None):
         """the compute stream waits for every outstanding collective and for the optimizer stream (no host sync on GPU)"""
+        opt_stream = opt_stream if opt_stream is not None else self._last_opt
+        if self._deferred or self._repl_keys:    # a step whose gathers were never issued (gather_deferred not called): do it now
+            self.gather_deferred(self._native, opt_stream)
         for w in self.pending:
             w.wait()
         self.pending = []
@@ -231,6 +285,7 @@ class GradReducer:
         holds the current values of its own shards only.  A collective: call on ALL ranks (before state_dict / a checkpoint)."""
         if not self.active or self.mode != "sharded":
             return
+        self.finish()                            # deferred gathers of the last step, the optimizer stream
         world, rank = self.world_size, self.rank
         tensors = [(0, native.W)] if self.master_stale else []
         if optimizer_state and native.adam is not None:

@@ -92,7 +92,10 @@ class TrainLoop:
             opt = self.opt_stream
             nm.backward(logits, bwd_scale, bucket_layers=red.bucket_plan(nm.n_layer),
                         between=lambda s, hi, lo: red.reduce_update(nm, s, hi, lo, lr, m.weight_decay, self.step_count, opt_stream=opt))
-            red.finish(opt)                                         # the next forward reads the gathered weights
+            if red.defer:
+                red.gather_deferred(nm, opt)                        # the next forward waits for the gathers bucket by bucket
+            else:
+                red.finish(opt)                                     # the next forward reads the gathered weights
         else:
             main, opt = torch.cuda.current_stream(), self.opt_stream
 

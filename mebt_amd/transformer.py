@@ -384,6 +384,8 @@ class Net2NetTransformer(LightningModuleShim):
         if red is not None and getattr(red, "master_stale", False):
             raise RuntimeError("data-parallel sharded optimizer: the fp32 master weights are complete only on their owning "
                                "ranks; call TrainLoop.consolidate() on ALL ranks before state_dict() / saving a checkpoint")
+        if red is not None and getattr(red, "active", False):
+            red.finish()                        # gathers / optimizer work of the last step still in flight on other streams
         return super().state_dict(*args, **kwargs)
 
     # ---- forward ----------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 """Data parallelism with the REAL HIP engine on one MI355X: two ranks share GPU 0 and talk over gloo (a 1-GPU box cannot
 run RCCL between two ranks on the same device), each running `TrainLoop` with the bucketed reducer of mebt_amd/parallel.py:
 the real `NativeModel` bucket ranges, `mebt_op_cast_bf16` -> reduce-scatter -> `mebt_adamw_slice` on the optimizer stream
--> all-gather of the bf16 mirror / fp32 tail, `consolidate()`.  2 ranks x batch 2 must equal 1 process x batch 4 after three
+-> all-gather of the bf16 mirror / fp32 tail (deferred: issued after backward, the next forward waits bucket by bucket), `consolidate()`.  2 ranks x batch 2 must equal 1 process x batch 4 after three
 steps (the DDP contract, reference train_transformer.py:39-41).  GPU only."""
 import os
 
@@ -34,9 +34,10 @@ def _batches():
     return xs, idxs, (0.45, 0.3, 0.0)            # t = 0: NC = 0 (empty key/value reductions: zero-filled gradient slices)
 
 
-def _worker(rank, world, port, dtype, mode, wire, ret):
+def _worker(rank, world, port, dtype, mode, wire, defer, ret):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["MEBT_DP_DEFER_GATHER"] = "1" if defer else "0"
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -48,8 +49,14 @@ def _worker(rank, world, port, dtype, mode, wire, ret):
         assert not loop.fused_optimizer
         xs, idxs, ts = _batches()
         per = 4 // world
+        # batches resident before the loop: a pageable host-to-device copy inside it waits for the whole device and would
+        # serialise every step behind the optimizer stream's work
+        xs = [x[rank * per:(rank + 1) * per].to(DEV) for x in xs]
+        idxs = [i[rank * per:(rank + 1) * per].to(DEV) for i in idxs]
         for x, idx, t in zip(xs, idxs, ts):
-            st = loop.step(x[rank * per:(rank + 1) * per].to(DEV), idx[rank * per:(rank + 1) * per].to(DEV), t=t)
+            st = loop.step(x, idx, t=t)
+            if mode == "sharded":      # deferred: one event per bucket handed to the engine (head, blocks [3,2], [1], [0], non-Linear), none otherwise
+                assert red.defer == defer and len(getattr(loop.native, "_fw_events", [])) == (5 if defer else 0)
         loss = red.mean_scalars(st[4:5].clone()).cpu()
         stale = red.master_stale
         if stale:
@@ -65,14 +72,15 @@ def _worker(rank, world, port, dtype, mode, wire, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype,mode,wire", [("f32", "sharded", "fp32"), ("bf16", "sharded", "bf16"), ("f32", "allreduce", "fp32")])
-def test_two_ranks_on_one_gpu_equal_one_rank_double_batch(dtype, mode, wire):
+@pytest.mark.parametrize("dtype,mode,wire,defer", [("f32", "sharded", "fp32", True), ("bf16", "sharded", "bf16", True),
+                                                    ("bf16", "sharded", "bf16", False), ("f32", "allreduce", "fp32", True)])
+def test_two_ranks_on_one_gpu_equal_one_rank_double_batch(dtype, mode, wire, defer):
     import torch.multiprocessing as mp
     from mebt_amd.trainer import TrainLoop
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    port = 32100 + (os.getpid() % 1500) + {"fp32": 0, "bf16": 3}[wire] + (5 if mode == "allreduce" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, dtype, mode, wire, ret)) for r in range(2)]
+    port = 32100 + (os.getpid() % 1500) + {"fp32": 0, "bf16": 3}[wire] + (5 if mode == "allreduce" else 0) + (7 if not defer else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dtype, mode, wire, defer, ret)) for r in range(2)]
     for p in procs:
         p.start()
     sd2, loss2, stale, adam2, wire_bytes = ret.get(timeout=900)
@@ -105,12 +113,14 @@ def test_two_ranks_on_one_gpu_equal_one_rank_double_batch(dtype, mode, wire):
         ref = a.cpu().numpy()
         tol = (1e-4 if dtype == "f32" else 3e-2) * np.abs(ref).max()
         assert np.abs(ref - b).max() <= tol
-    print(f"[dp {dtype} {mode} wire {wire}] max |dp| vs single process {worst:.3e}; loss {loss2:.5f}")
+    print(f"[dp {dtype} {mode} wire {wire} defer {defer}] max |dp| vs single process {worst:.3e}; loss {loss2:.5f}")
 
 
-def _rccl_worker(port, dtype, mode, wire, ret):
+def _rccl_worker(port, dtype, mode, wire, delay, ret):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if delay:      # ~2 ms (at 2.4 GHz) in front of every bucket's optimizer / gather work on the optimizer stream
+        os.environ["MEBT_DP_TEST_DELAY_CYCLES"] = str(delay)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -122,8 +132,9 @@ def _rccl_worker(port, dtype, mode, wire, ret):
         loop = TrainLoop(model, red)
         assert not loop.fused_optimizer and loop.opt_stream is not None
         xs, idxs, ts = _batches()
+        xs, idxs = [x.to(DEV) for x in xs], [i.to(DEV) for i in idxs]      # resident: no device-wide wait between steps
         for x, idx, t in zip(xs, idxs, ts):
-            st = loop.step(x.to(DEV), idx.to(DEV), t=t)
+            st = loop.step(x, idx, t=t)
         loss = red.mean_scalars(st[4:5].clone()).cpu()
         loop.consolidate()
         torch.cuda.synchronize()
@@ -134,19 +145,24 @@ def _rccl_worker(port, dtype, mode, wire, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype,mode,wire", [("bf16", "sharded", "bf16"), ("f32", "sharded", "fp32"), ("f32", "allreduce", "fp32")])
-def test_rccl_executes_the_collective_path_with_one_rank(dtype, mode, wire):
+@pytest.mark.parametrize("dtype,mode,wire,delay", [("bf16", "sharded", "bf16", 0), ("f32", "sharded", "fp32", 0), ("f32", "allreduce", "fp32", 0),
+                                                    ("bf16", "sharded", "bf16", 5_000_000), ("f32", "sharded", "fp32", 5_000_000)])
+def test_rccl_executes_the_collective_path_with_one_rank(dtype, mode, wire, delay):
     """RCCL itself (torch.distributed backend "nccl") on the one GPU of this box: a process group of size 1 with the
     reducer forced active, so that `reduce_scatter_tensor` (bf16 and fp32), the in-place `all_gather_into_tensor` into the
     bf16 mirror / fp32 tail, `all_reduce`, `broadcast`, the asynchronous work handles and the hand-offs between the compute,
     RCCL and optimizer streams all run exactly as in the N-GPU job (a shard is then the whole bucket).  Result == the plain
-    single-process step."""
+    single-process step.  `delay`: every piece of optimizer-stream work (shard AdamW, the deferred gathers) is held back by
+    ~2 ms, so the host enqueues the next forward long before the parameters are final and the per-bucket waits
+    (mebt_model_set_forward_waits) are what orders it.  (Not a proof on this box: with all waits removed the run still
+    matched, because the compute and optimizer streams shared a hardware queue and the delay kernel held both back; what
+    this case does pin is the event plumbing — recorded, handed to the engine, waited for — under a fully asynchronous host.)"""
     import torch.multiprocessing as mp
     from mebt_amd.trainer import TrainLoop
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    port = 33400 + (os.getpid() % 1500) + {"fp32": 0, "bf16": 3}[wire] + (5 if mode == "allreduce" else 0)
-    p = ctx.Process(target=_rccl_worker, args=(port, dtype, mode, wire, ret))
+    port = 33400 + (os.getpid() % 1500) + {"fp32": 0, "bf16": 3}[wire] + (5 if mode == "allreduce" else 0) + (9 if delay else 0)
+    p = ctx.Process(target=_rccl_worker, args=(port, dtype, mode, wire, delay, ret))
     p.start()
     sd1, loss1, wire_bytes, wire_grads = ret.get(timeout=900)
     p.join(timeout=120)
