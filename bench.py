@@ -285,7 +285,11 @@ def main():
     if world > 1 or dp_force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group(backend, rank=rank, world_size=world, device_id=device if backend == "nccl" else None)
+        if backend == "nccl":
+            from mebt_amd.parallel import init_rccl
+            init_rccl(rank, world, device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     # the Sky config trains with embd/resid/attn dropout 0.1 (configs/stl/mebt_16f.yaml:12-14): the measured

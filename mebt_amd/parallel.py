@@ -33,6 +33,47 @@ import torch
 import torch.distributed as dist
 
 
+def init_rccl(rank, world_size, device):
+    """torch.distributed over RCCL with RCCL's own stream taken from the HIGH-priority pool: on MI355X high- and low-priority
+    HIP streams never share a hardware queue (streams_serialised below), so the collectives can neither be stuck behind the
+    compute stream's kernels nor hold them back, whatever queue the low-priority streams of this process landed on."""
+    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device, pg_options=opts)
+
+
+def streams_serialised(a, b, cycles=4_000_000):
+    """Do kernels on stream `b` queue up behind kernels on stream `a`?  HIP maps streams onto a few hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default; measured on MI355X: stream k of torch's pool shares a queue with streams k +- 4, and the
+    default stream with every fourth pool stream; high- and low-priority streams never share one).  Two streams on one
+    queue run in submission order — including the event waits in it, so "overlap" between them is none at all.  Measured,
+    not assumed: a ~2 ms spin kernel on `a`, then a trivial kernel on `b`; if `a`'s spin is over when `b`'s kernel
+    completes, `b` waited."""
+    x = torch.zeros(64, device=torch.device("cuda", torch.cuda.current_device()))
+    torch.cuda.synchronize()
+    ea, eb = torch.cuda.Event(), torch.cuda.Event()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(cycles)
+        ea.record()
+    with torch.cuda.stream(b):
+        x.add_(1)
+        eb.record()
+    eb.synchronize()
+    waited = ea.query()
+    torch.cuda.synchronize()
+    return bool(waited)
+
+
+def pick_concurrent_stream(ref, device=None, tries=12, priority=0):
+    """a new stream whose kernels really run beside those of `ref` (see streams_serialised)"""
+    s = None
+    streams_serialised(ref, ref)                          # warm-up: first launches, lazy stream creation
+    for _ in range(tries):
+        s = torch.cuda.Stream(device=device, priority=priority)
+        if not streams_serialised(s, ref) and not streams_serialised(ref, s):
+            return s
+    return s
+
+
 class _Done:
     """work handle of a collective that already completed (host-staged functional path)"""
 

@@ -49,7 +49,8 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        from .parallel import init_rccl
+        init_rccl(rank, world, dev)
     random.seed(42); np.random.seed(42); torch.manual_seed(42)          # pl.seed_everything(42)
 
     cfg = getattr(presets, args.preset)() if args.preset else load_config(args.base, unknown)

@@ -8,7 +8,7 @@ import random
 import numpy as np
 import torch
 
-from .parallel import GradReducer
+from .parallel import GradReducer, pick_concurrent_stream
 
 
 class TrainLoop:
@@ -32,7 +32,8 @@ class TrainLoop:
         # the optimizer runs bucket by bucket on its own stream, as soon as a bucket's gradients are final
         # (after its all-reduce when data-parallel): AdamW streams 30 B/parameter through HBM while the rest
         # of backward is latency/compute-bound, so the two overlap almost perfectly
-        self.opt_stream = torch.cuda.Stream(device=self.native.device) if overlap_optimizer else None
+        # ... provided the two streams do not share a hardware queue: probed, not assumed (parallel.pick_concurrent_stream)
+        self.opt_stream = pick_concurrent_stream(torch.cuda.current_stream(), device=self.native.device) if overlap_optimizer else None
         if self.reducer.active and self.reducer.mode == "sharded":
             self.native._adam_state()           # allocated up front: the first sharded update runs on the optimizer stream
             if self.reducer.wire == "bf16" and self.accum == 1 and os.environ.get("MEBT_DP_WIRE_GRADS", "1") != "0":

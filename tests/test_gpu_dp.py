@@ -122,7 +122,8 @@ def _rccl_worker(port, dtype, mode, wire, delay, ret):
     if delay:      # ~2 ms (at 2.4 GHz) in front of every bucket's optimizer / gather work on the optimizer stream
         os.environ["MEBT_DP_TEST_DELAY_CYCLES"] = str(delay)
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from mebt_amd.parallel import init_rccl
+    init_rccl(0, 1, torch.device("cuda", 0))
     try:
         from mebt_amd.parallel import GradReducer
         from mebt_amd.trainer import TrainLoop
@@ -154,9 +155,11 @@ def test_rccl_executes_the_collective_path_with_one_rank(dtype, mode, wire, dela
     RCCL and optimizer streams all run exactly as in the N-GPU job (a shard is then the whole bucket).  Result == the plain
     single-process step.  `delay`: every piece of optimizer-stream work (shard AdamW, the deferred gathers) is held back by
     ~2 ms, so the host enqueues the next forward long before the parameters are final and the per-bucket waits
-    (mebt_model_set_forward_waits) are what orders it.  (Not a proof on this box: with all waits removed the run still
-    matched, because the compute and optimizer streams shared a hardware queue and the delay kernel held both back; what
-    this case does pin is the event plumbing — recorded, handed to the engine, waited for — under a fully asynchronous host.)"""
+    (mebt_model_set_forward_waits) are what orders it: with the waits dropped (`set_forward_waits([])` after each step) the
+    same run ends at loss 9.7744 instead of 9.7710 — stale weights — once the optimizer stream really runs beside the
+    compute stream (TrainLoop picks it by probing, parallel.pick_concurrent_stream: streams that share a hardware queue
+    execute in submission order and hide the race).  The batches are resident before the loop: a pageable host-to-device
+    copy waits for the whole device."""
     import torch.multiprocessing as mp
     from mebt_amd.trainer import TrainLoop
     ctx = mp.get_context("spawn")
