@@ -256,6 +256,8 @@ int mebt_profile_read(int32_t family, double* launches, double* total_ms, double
 int mebt_debug_dropout_mask(uint64_t seed, uint32_t site, float p, int64_t n, float* out, mebt_stream_t stream);
 /* Benchmarking / tests only: 0 = keep every launch on the caller's stream (no side stream for gradient leaves). */
 void mebt_debug_side_stream(mebt_model* m, int32_t on);
+/* experiment: run that second stream's work on a caller-owned stream instead (NULL: back to the internal one) */
+void mebt_debug_set_side_stream(mebt_model* m, mebt_stream_t stream);
 /* Benchmarking / tests only: force the bf16 GEMM block tile (bm, bn in {128, 64}); (0, 0) restores the heuristic. */
 void mebt_debug_gemm_tile(int32_t bm, int32_t bn);
 /* Benchmarking / tests only: force the bf16 GEMM staging: 0 register-staged, 2 LDS-DMA 2 stages, 1 LDS-DMA

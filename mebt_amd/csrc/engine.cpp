@@ -91,6 +91,7 @@ struct mebt_model {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_e1 = nullptr, ev_layer[2] = {nullptr, nullptr}, ev_join = nullptr;
     bool use_side = true;
+    hipStream_t side_own = nullptr;      // the stream this object created (destroyed with it); `side` may point at a caller's stream instead
     // optimizer-in-backward (mebt_model_set_fused_adamw): when armed, the weight gradients of the blocks are applied
     // to W (AdamW) inside the weight-gradient launch instead of being stored in gW
     bool fused_on = false;
@@ -256,6 +257,7 @@ extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) 
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, least) != hipSuccess) { m->side = nullptr; m->use_side = false; (void)hipGetLastError(); }
     }
+    m->side_own = m->side;
     if (m->side) {
         hipEvent_t* evs[] = {&m->ev_fork, &m->ev_e1, &m->ev_layer[0], &m->ev_layer[1], &m->ev_join};
         for (hipEvent_t* e : evs) MEBT_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -270,11 +272,17 @@ extern "C" void mebt_model_destroy(mebt_model* m) {
         (void)hipStreamSynchronize(m->side);
         hipEvent_t evs[] = {m->ev_fork, m->ev_e1, m->ev_layer[0], m->ev_layer[1], m->ev_join};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-        (void)hipStreamDestroy(m->side);
+        if (m->side_own) (void)hipStreamDestroy(m->side_own);
     }
     delete m;
 }
 extern "C" void mebt_debug_side_stream(mebt_model* m, int32_t on) { if (m) m->use_side = on != 0 && m->side != nullptr; }
+// use the caller's stream (e.g. one it probed to run beside its compute stream: streams that share a hardware queue do not overlap)
+extern "C" void mebt_debug_set_side_stream(mebt_model* m, mebt_stream_t s) {
+    if (!m || !m->side_own) return;
+    (void)hipStreamSynchronize(m->side);
+    m->side = s ? reinterpret_cast<hipStream_t>(s) : m->side_own;
+}
 
 extern "C" int mebt_model_param_counts(const mebt_model* m, int64_t* n_w, int64_t* n_p) {
     if (!m) { mebt_set_error("null model"); return MEBT_EINVAL; }

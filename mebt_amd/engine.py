@@ -70,6 +70,11 @@ class NativeModel:
         # the chip: 11.3 vs 11.6 ms per Sky-16f step), MEBT_SIDE_STREAM=1 turns it on
         self.side_stream = os.environ.get("MEBT_SIDE_STREAM", "0") == "1"
         self.lib.mebt_debug_side_stream(self.h, 1 if self.side_stream else 0)
+        self._side = None
+        if self.side_stream and os.environ.get("MEBT_SIDE_STREAM_PROBED", "1") == "1" and torch.cuda.is_available():
+            from .parallel import pick_concurrent_stream            # a stream that really runs beside the compute stream
+            self._side = pick_concurrent_stream(torch.cuda.current_stream())
+            self.lib.mebt_debug_set_side_stream(self.h, self._side.cuda_stream)
         self.n_layer, self.n_embd, self.vocab, self.n_latent = n_layer, n_embd, vocab, n_latent
         self.W = self.P = self.gW = self.gP = self.Wlp = None
         self.gWb = None             # bf16 wire-format weight gradients (data-parallel sharded path)
