@@ -267,6 +267,13 @@ def main():
     ap.add_argument("--preset", default="sky_16f", choices=["sky_16f", "tiny"])
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio (block-buffered on a pipe, so
+    # it would come out AFTER the result line at exit): keep the real stdout aside and point fd 1 at stderr for
+    # everything else in this process, native libraries included.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch.distributed as dist
     from mebt_amd import presets
     from mebt_amd.parallel import GradReducer
@@ -388,7 +395,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(sd, cfg, args.t)
             except Exception as e:          # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or dp_force:
         dist.barrier()
         dist.destroy_process_group()
