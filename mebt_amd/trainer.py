@@ -91,8 +91,17 @@ class TrainLoop:
         elif red.active and red.mode == "sharded":
             # reduce-scatter -> AdamW on this rank's shard -> all-gather, bucket by bucket behind the backward (parallel.py)
             opt = self.opt_stream
-            nm.backward(logits, bwd_scale, bucket_layers=red.bucket_plan(nm.n_layer),
-                        between=lambda s, hi, lo: red.reduce_update(nm, s, hi, lo, lr, m.weight_decay, self.step_count, opt_stream=opt))
+            update = lambda s, hi, lo: red.reduce_update(nm, s, hi, lo, lr, m.weight_decay, self.step_count, opt_stream=opt)
+            if self.step_count == 1:
+                # the first backward is where the GEMM tuner times its candidates (in situ, on this stream): keep RCCL's
+                # kernels and the shard updates out of the way until it is through, or a noisy pick on one rank makes that
+                # rank the straggler of every later step
+                done = []
+                nm.backward(logits, bwd_scale, bucket_layers=red.bucket_plan(nm.n_layer), between=lambda s, hi, lo: done.append((s, hi, lo)))
+                for stage in done:
+                    update(*stage)
+            else:
+                nm.backward(logits, bwd_scale, bucket_layers=red.bucket_plan(nm.n_layer), between=update)
             if red.defer:
                 red.gather_deferred(nm, opt)                        # the next forward waits for the gathers bucket by bucket
             else:
