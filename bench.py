@@ -167,7 +167,7 @@ def secondary_metrics(args, cfg, model, loop, x, idx, device, lib, level):
     # (5) t ~ U(0,1) as in real training (random.seed(42), E[NT] = 513): first pass pays the GEMM tuner
     # for the (bucketed) signatures it has not seen, the second pass is the steady state
     rng = random.Random(42)
-    ts = [rng.random() for _ in range(60)]
+    ts = [rng.random() for _ in range(100)]           # the 100-step run of SURVEY.md §8d
     passes = []
     for _ in range(2):
         sync()
