@@ -214,6 +214,15 @@ def secondary_metrics(args, cfg, model, loop, x, idx, device, lib, level):
     fl = 64 * 4 * forward_flops_per_sample(uo, 7936, 256)
     out["c4_revise_64_forwards"] = {"batch": 4, "s": round(dt, 3), "forwards_per_s": round(64 / dt, 1), "tflops": round(fl / dt / 1e12, 1),
                                     "note": "64 forwards at (NC, NT) = (7936, 256) + sampling + scatter, block 8192"}
+    # the 30-step MaskGIT-style sample at the same geometry (the other C4 inference schedule), cosine mask
+    # schedule as the sampling script sets it: NT shrinks from 8192 to 0 over the steps
+    um.mask_sampler.schedule = "cosine"
+    x0u = torch.zeros(4, 32, 16, 16, dtype=torch.long, device=device)
+    with torch.no_grad():
+        f = lambda: um.sample(x0u, None, 1.0, None, None, 30, None, None, context_temperature=4.5, skips=False)
+        f()
+        dt = timed(f, 1, sync)
+    out["c4_sample_30_steps"] = {"batch": 4, "s": round(dt, 3), "sampler_steps_per_s": round(30 / dt, 1), "tokens_per_s": round(4 * 8192 / dt, 1)}
     del um
 
     # (8) C5 (BASELINE.json configs[4]): Taichi 16f end to end — pixels -> 3D-VQGAN encode (fp16 MFMA, fp32 codebook search) ->
