@@ -80,6 +80,36 @@ def test_sky16f_bf16_close_to_fp32_and_training_reduces_loss():
     assert losses[-1] < losses[0] - 1.0, losses                                   # the optimiser step learns
 
 
+def test_sky16f_memorises_a_structured_batch_under_the_real_training_regime():
+    """End to end at the benchmarked size, the way training actually runs: bf16, dropout 0.1, a fresh permutation and
+    t ~ U(0,1) every step (so NC / NT and with them every GEMM / attention shape change from step to step), AdamW inside the
+    weight-gradient launches.  Six "videos" whose frames repeat one 16 x 16 palette pattern are memorised: masked-token
+    loss from ln(16384) = 9.7 to < 0.5 within 400 steps (measured: 3.9 / 1.9 / 0.67 / 0.08 after 50 / 200 / 300 / 400),
+    every parameter finite."""
+    import random
+    from mebt_amd.trainer import TrainLoop
+    cfg = presets.sky_16f(dropout=0.1)
+    cfg.exp.exact_lr = 1e-4
+    torch.manual_seed(3)
+    model = presets.build_model(cfg, compute_dtype="bf16").to(DEV).train()
+    loop = TrainLoop(model)
+    assert loop.fused_optimizer
+    g = torch.Generator().manual_seed(5)
+    base = torch.randint(0, 32, (6, 1, 16, 16), generator=g)
+    x = ((base + torch.arange(4).view(1, 4, 1, 1) * 7) % 16384).to(DEV)
+    rng = random.Random(1)
+    first = last = None
+    for step in range(400):
+        idx = torch.stack([torch.randperm(1024, generator=g) for _ in range(6)]).to(DEV)
+        st = loop.step(x, idx, t=rng.random() * 0.98)
+        if step == 0:
+            first = float(st[4].cpu())
+    last = float(st[4].cpu())
+    assert abs(first - np.log(16384)) < 0.6 and np.isfinite(last) and last < 0.5, (first, last)
+    assert all(bool(torch.isfinite(v).all()) for v in model.state_dict().values())
+    print(f"[soak] loss {first:.3f} -> {last:.4f} in 400 steps")
+
+
 def test_ucf128f_geometry_revise_forward_properties():
     """C4: block_size 8192, grid [32,16,16]; a revise forward has NC=7936, NT=256.
     Properties: finite logits; bf16 agrees with fp32 loosely; permuting the CONTEXT order leaves the
