@@ -210,10 +210,18 @@ class GradReducer:
             if n == 0:
                 continue
             g = (native.gW if which == 0 else native.gP)[a:b]
+            gWb = getattr(native, "gWb", None) if which == 0 else None      # bound: the Linear weight gradients exist ONLY there (bf16)
             if n % (4 * world):      # cannot be cut into aligned shards: replicate (all-reduce + full-range update)
-                w = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self.bytes_on_wire += 2 * n * 4
-                self._on_opt(opt_stream, main, lambda: (w.wait(), native.adamw_slice(which, a, n, g, lr, weight_decay, step, betas=betas,
+                gsrc = gWb[a:b] if gWb is not None else g
+                if self._staged(gsrc):
+                    h = gsrc.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                    gsrc.copy_(h)
+                    w = _Done()
+                else:
+                    w = dist.all_reduce(gsrc, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.bytes_on_wire += 2 * n * gsrc.element_size()
+                self._on_opt(opt_stream, main, lambda: (w.wait(), native.adamw_slice(which, a, n, gsrc, lr, weight_decay, step, betas=betas,
                                                                                       eps=eps, grad_scale=self.grad_scale,
                                                                                       stream=self._sid(opt_stream))))
                 self._repl_keys.append(key)
@@ -221,7 +229,6 @@ class GradReducer:
             shard = n // world
             sa = a + rank * shard
             self._sharded_ranges.add((which, a, b))
-            gWb = getattr(native, "gWb", None) if which == 0 else None
             if self.wire == "bf16" and gWb is not None:
                 wire = gWb[a:b]                                                 # the backward already stored bf16 (no fp32 copy, no cast)
             elif self.wire == "bf16":
