@@ -317,6 +317,17 @@ def main():
     loop = TrainLoop(model, reducer)
     shape = cfg.model.mask.params.shape
     x, idx = synthetic_batch(args.batch, shape, rank, device)
+    if reducer.active and reducer.mode == "sharded":
+        # The sharded path has only ever met RCCL with one rank on the build machines.  If its first step raises on a real
+        # multi-GPU node (every rank runs the same calls, so every rank raises), fall back to the plain bucketed fp32
+        # all-reduce with a replicated optimizer rather than produce no number; the JSON line says which path ran.
+        try:
+            loop.step(x, idx, t=args.t)
+            torch.cuda.synchronize()
+        except Exception as e:          # noqa: BLE001
+            print(f"[bench] sharded data-parallel step failed ({type(e).__name__}: {e}); falling back to MEBT_DP_MODE=allreduce", file=sys.stderr, flush=True)
+            reducer = GradReducer(world_size=world, mode="allreduce")
+            loop = TrainLoop(model, reducer)
 
     def sync():
         torch.cuda.synchronize()
@@ -386,10 +397,11 @@ def main():
                "per_gpu": round(value / world, 1),
                "config": {"workload": "Sky-Timelapse 16f MeBT train step: 24L/1024d/16h, 1024 VQ tokens + 256 latents, "
                                       f"batch {args.batch}/GPU, t={args.t} (NC=NT={n_targets // args.batch}), "
-                                      "fwd + masked CE + bwd + AdamW" + (f" + reduce-scatter / sharded AdamW / all-gather ({reducer.mode}, {reducer.wire} wire)" if reducer.active else ""),
+                                      "fwd + masked CE + bwd + AdamW" + ((f" + reduce-scatter / sharded AdamW / all-gather ({reducer.wire} wire)" if reducer.mode == "sharded" else " + bucketed fp32 all-reduce") if reducer.active else ""),
                           "global_batch": args.batch * world, "parallelism": f"dp{world}", "dropout": args.dropout,
                           "optimizer": "in-backward (fused into the weight-gradient launches)" if loop.fused_optimizer else
-                                       ("sharded over ranks" if reducer.active and reducer.mode == "sharded" else "separate"),
+                                       ("sharded over ranks" if reducer.active and reducer.mode == "sharded" else
+                                        "replicated, behind a bucketed fp32 all-reduce" if reducer.active else "separate"),
                           "loss": round(float(stats[4]), 4)},
                "roofline": roof}
         # the legs below run outside the timed region; a failure in one of them must not cost the headline line

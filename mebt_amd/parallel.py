@@ -37,8 +37,14 @@ def init_rccl(rank, world_size, device):
     """torch.distributed over RCCL with RCCL's own stream taken from the HIGH-priority pool: on MI355X high- and low-priority
     HIP streams never share a hardware queue (streams_serialised below), so the collectives can neither be stuck behind the
     compute stream's kernels nor hold them back, whatever queue the low-priority streams of this process landed on."""
-    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-    dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device, pg_options=opts)
+    try:
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    except Exception:                # a torch build without the option: default stream priority, everything else unchanged
+        opts = None
+    if opts is not None:
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device, pg_options=opts)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device)
 
 
 def streams_serialised(a, b, cycles=4_000_000):
