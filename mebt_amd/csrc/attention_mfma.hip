@@ -472,7 +472,9 @@ static int check_layout(const AttnParams& p) {
 // one stage is enough when the streamed side fits one chunk: two workgroups per CU
 static int lds_bytes(int streamed_rows) { return streamed_rows <= CHUNK ? STAGE_BYTES : ATTN_LDS; }
 
-int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
+int launch_attn_fwd_mfma(const AttnParams& p_in, hipStream_t stream) {
+    AttnParams p = p_in;
+    drop_mark_small(p.drop, (uint64_t)p.B * p.H * p.NQ * p.NK);
     if (int rc = check_layout(p)) return rc;
     const dim3 grid((p.NQ + BLOCK_ROWS - 1) / BLOCK_ROWS, p.H, p.B);
     hipLaunchKernelGGL(attn_fwd_mfma, grid, dim3(WAVES * 64), lds_bytes(p.NK), stream, p);
@@ -480,7 +482,9 @@ int launch_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
     return MEBT_OK;
 }
 
-int launch_attn_bwd_mfma(const AttnParams& p, hipStream_t stream) {
+int launch_attn_bwd_mfma(const AttnParams& p_in, hipStream_t stream) {
+    AttnParams p = p_in;
+    drop_mark_small(p.drop, (uint64_t)p.B * p.H * p.NQ * p.NK);
     if (int rc = check_layout(p)) return rc;
     if ((p.lddo | p.lddq | p.lddk | p.lddv) % 8) { mebt_set_error("mfma attention: row strides must be multiples of 8 elements"); return MEBT_ESHAPE; }
     const dim3 gq((p.NQ + BLOCK_ROWS - 1) / BLOCK_ROWS, p.H, p.B);

@@ -169,16 +169,30 @@ struct DropCfg {
     uint32_t site;
     uint32_t thresh;
     float inv_keep;
+    uint32_t small;     // set by the launcher when the site has fewer than 2^33 elements: every pair index fits 32 bits
+    uint32_t base32;    // site * 0x632BE5AB + (seed >> 32): the wave-uniform part of pair_hash when the pair's high word is 0
 };
+// pair_hash(d.seed, d.site, pair) with one multiply less when the launcher vouches for pair < 2^32 (identical value:
+// with a zero high word the first product is the uniform site * 0x632BE5AB, folded into base32 on the host)
+__device__ __forceinline__ uint32_t pair_hash_cfg(const DropCfg& d, uint64_t pair) {
+    if (!d.small) return pair_hash(d.seed, d.site, pair);
+    uint32_t h = ((uint32_t)pair ^ (uint32_t)d.seed) + d.base32;
+    h *= 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    return h;
+}
 __device__ __forceinline__ float drop_keep(const DropCfg& d, uint64_t idx) {
-    return mix_hash(d.seed, d.site, idx) >= d.thresh ? d.inv_keep : 0.0f;
+    const uint32_t h = pair_hash_cfg(d, idx >> 1);
+    return ((idx & 1) ? (h >> 16) : (h & 0xFFFFu)) >= d.thresh ? d.inv_keep : 0.0f;
 }
 // keep factors of 4 consecutive elements idx0 .. idx0+3: two hashes when idx0 is even (the usual case:
 // vectors start at multiples of 4), identical values to drop_keep element by element
 __device__ __forceinline__ f32x4 drop_keep4(const DropCfg& d, uint64_t idx0) {
     f32x4 k;
     if ((idx0 & 1) == 0) {
-        const uint32_t h0 = pair_hash(d.seed, d.site, idx0 >> 1), h1 = pair_hash(d.seed, d.site, (idx0 >> 1) + 1);
+        const uint32_t h0 = pair_hash_cfg(d, idx0 >> 1), h1 = pair_hash_cfg(d, (idx0 >> 1) + 1);
         k[0] = (h0 & 0xFFFFu) >= d.thresh ? d.inv_keep : 0.0f;
         k[1] = (h0 >> 16) >= d.thresh ? d.inv_keep : 0.0f;
         k[2] = (h1 & 0xFFFFu) >= d.thresh ? d.inv_keep : 0.0f;

@@ -265,6 +265,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
 int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     GemmParams p = p_in;
     if (p.M <= 0 || p.N <= 0) return MEBT_OK;
+    drop_mark_small(p.drop, (uint64_t)p.M * p.ldc);        // the residual epilogue's dropout indexes row * ldc + column
     if (p.N % 4 != 0) { mebt_set_error("gemm: N must be a multiple of 4"); return MEBT_ESHAPE; }
     const int esz = dtype == MEBT_BF16 ? 2 : 4;
     const int kq = dtype == MEBT_BF16 ? BK : FBK;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include "common.h"
 
 enum { MEBT_F32 = 0, MEBT_BF16 = 1 };
@@ -12,7 +13,14 @@ static inline DropCfg make_drop(uint64_t seed, uint32_t site, float p) {
     d.seed = seed; d.site = site;
     d.thresh = p > 0.f ? (uint32_t)((double)p * 65536.0 + 0.5) : 0u;
     d.inv_keep = d.thresh ? (float)(65536.0 / (65536.0 - d.thresh)) : 1.0f;
+    d.small = 0;
+    d.base32 = site * 0x632BE5ABu + (uint32_t)(seed >> 32);
     return d;
+}
+// launcher side: this site indexes `n_elems` elements
+static inline void drop_mark_small(DropCfg& d, uint64_t n_elems) {
+    static const bool on = [] { const char* e = getenv("MEBT_DROP_SMALL"); return !(e && e[0] == '0'); }();
+    d.small = (on && n_elems < (1ull << 33)) ? 1u : 0u;
 }
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_GELU_BWD = 3, EPI_ADAMW = 4 /* internal: grouped weight gradients only */ };
 
