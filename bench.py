@@ -276,6 +276,13 @@ def main():
     ap.add_argument("--preset", default="sky_16f", choices=["sky_16f", "tiny"])
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a torch.distributed environment: start the N ranks as a child process (before anything
+    # here touches the GPU), relay rank 0's line, exit with the child's return code (mebt_amd/launch.py)
+    from mebt_amd.launch import spawn_ranks_if_needed
+    rc = spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
+
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio (block-buffered on a pipe, so
     # it would come out AFTER the result line at exit): keep the real stdout aside and point fd 1 at stderr for
     # everything else in this process, native libraries included.
@@ -317,15 +324,24 @@ def main():
     loop = TrainLoop(model, reducer)
     shape = cfg.model.mask.params.shape
     x, idx = synthetic_batch(args.batch, shape, rank, device)
+    dp_fallback = None
     if reducer.active and reducer.mode == "sharded":
         # The sharded path has only ever met RCCL with one rank on the build machines.  If its first step raises on a real
         # multi-GPU node (every rank runs the same calls, so every rank raises), fall back to the plain bucketed fp32
-        # all-reduce with a replicated optimizer rather than produce no number; the JSON line says which path ran.
+        # all-reduce with a replicated optimizer rather than produce no number; the JSON line carries `dp_fallback`.
         try:
             loop.step(x, idx, t=args.t)
             torch.cuda.synchronize()
         except Exception as e:          # noqa: BLE001
-            print(f"[bench] sharded data-parallel step failed ({type(e).__name__}: {e}); falling back to MEBT_DP_MODE=allreduce", file=sys.stderr, flush=True)
+            dp_fallback = f"{type(e).__name__}: {e}"
+            print(f"[bench] sharded data-parallel step failed ({dp_fallback}); falling back to MEBT_DP_MODE=allreduce", file=sys.stderr, flush=True)
+            try:
+                torch.cuda.synchronize()
+            except Exception:           # noqa: BLE001
+                pass
+            reducer.abandon(loop.native)                     # drop half-issued work, forward waits, the bf16 wire-gradient binding
+            torch.manual_seed(0)                             # the half-applied step touched some shards: start again from the
+            model = presets.build_model(cfg, compute_dtype=args.dtype).to(device).train()   # same initial weights on every rank
             reducer = GradReducer(world_size=world, mode="allreduce")
             loop = TrainLoop(model, reducer)
 
@@ -338,6 +354,7 @@ def main():
     for _ in range(args.warmup):
         stats = loop.step(x, idx, t=args.t)
     sync()
+    wire0 = reducer.bytes_on_wire
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats = loop.step(x, idx, t=args.t)
@@ -351,6 +368,65 @@ def main():
     n_targets = int(stats[3])                                  # masked tokens scored per rank per step
     ms = 1e3 * elapsed / args.steps
     value = world * n_targets * args.steps / elapsed
+    wire_bytes_per_step = (reducer.bytes_on_wire - wire0) / max(1, args.steps)
+
+    # data-parallel runs describe themselves: which path ran, how many ranks RCCL really spans, what went
+    # over the wire, how much of the communication was NOT hidden, and the efficiency against this same GPU's one-rank step
+    dp = None
+    if reducer.active:
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        K = max(4, min(10, args.steps))
+
+        def timed_steps(lp, n):
+            for _ in range(2):
+                lp.step(x, idx, t=args.t)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                lp.step(x, idx, t=args.t)
+            sync()
+            el = time.perf_counter() - t1
+            if world > 1:
+                tt = torch.tensor([el], device=device, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            return 1e3 * el / n
+
+        # (a) the same step with every collective elided (local copies / no-ops, same kernels and stream hand-offs)
+        reducer.elide = True
+        nocomm_ms = timed_steps(loop, K)
+        reducer.elide = False
+        reducer.finish()
+        # (b) this GPU alone: gradients stored + separate AdamW (what a rank computes, minus the sharding), and the fused
+        # single-GPU step the N = 1 headline runs — every rank measures its own, no collectives inside
+        torch.cuda.synchronize()
+        solo = {}
+        for name, fused in (("separate_optimizer", False), ("fused_optimizer", True)):
+            lp = TrainLoop(model, GradReducer(world_size=1, force=False), fused_optimizer=fused)
+            lp.step_count = loop.step_count
+            for _ in range(2):
+                lp.step(x, idx, t=args.t)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(K):
+                lp.step(x, idx, t=args.t)
+            torch.cuda.synchronize()
+            solo[name] = 1e3 * (time.perf_counter() - t1) / K
+        model._reducer = reducer
+        loop.native.enable_wire_grads(loop.wire_grads)       # the one-rank loops above unbound it
+        dp = {"dp_mode": reducer.mode, "wire": reducer.wire if reducer.mode == "sharded" else "fp32",
+              "rccl_ranks": int(ones.item()), "backend": backend, "dp_fallback": dp_fallback,
+              "deferred_gathers": bool(reducer.defer), "buckets": reducer.bucket_plan(loop.native.n_layer),
+              "bytes_on_wire_per_step": int(wire_bytes_per_step),
+              "step_ms_collectives_elided": round(nocomm_ms, 3),
+              "exposed_comm_ms": round(ms - nocomm_ms, 3),
+              "exposed_comm_method": "timed step minus the same step with every collective replaced by a local copy / no-op (max over ranks, same barrier-bracketed timer)",
+              "one_rank_ms": {k: round(v, 3) for k, v in solo.items()},
+              "scaling_efficiency": round(solo["separate_optimizer"] / ms, 4),
+              "scaling_efficiency_vs_fused": round(solo["fused_optimizer"] / ms, 4),
+              "scaling_efficiency_note": "per-GPU throughput of this run / per-GPU throughput of ONE rank of this job alone on its GPU (rank 0's figure), "
+                                         "separate_optimizer = gradients stored + streaming AdamW, fused = the N = 1 headline path"}
 
     # dominant kernel family: MFMA GEMMs — time every launch of 2 more steps with HIP events on the
     # launch stream (rank 0 records; every rank runs the steps because they contain collectives)
@@ -403,7 +479,7 @@ def main():
                                        ("sharded over ranks" if reducer.active and reducer.mode == "sharded" else
                                         "replicated, behind a bucketed fp32 all-reduce" if reducer.active else "separate"),
                           "loss": round(float(stats[4]), 4)},
-               "roofline": roof}
+               "roofline": roof, "data_parallel": dp}
         # the legs below run outside the timed region; a failure in one of them must not cost the headline line
         if world == 1 and args.secondary != "none" and args.preset == "sky_16f":
             try:

@@ -111,6 +111,10 @@ class GradReducer:
         self.mode = mode or os.environ.get("MEBT_DP_MODE", "sharded")
         self.wire = wire or os.environ.get("MEBT_DP_WIRE", "bf16")
         assert self.mode in ("sharded", "allreduce") and self.wire in ("bf16", "fp32")
+        # `elide` (bench.py, measurement only): every collective of the step becomes a local no-op / copy with the same
+        # buffers, kernels and stream hand-offs — the step time with it set is the compute side of the data-parallel step,
+        # the difference to the real step is communication that was not hidden (plus RCCL's kernels competing for CUs)
+        self.elide = False
         self.pending = []            # outstanding collectives the compute stream has to wait for
         self.bytes_on_wire = 0       # payload bytes handed to collectives (per rank, per direction)
         self.master_stale = False    # sharded + bf16 mirror: fp32 W is current only on the owner of each shard
@@ -127,6 +131,10 @@ class GradReducer:
         return (not self._inplace) and t.is_cuda
 
     def _reduce_scatter(self, out, inp):
+        if self.elide:               # measurement only: this rank's own contribution stands in for the sum
+            n = out.numel()
+            out.copy_(inp[self.rank * n:(self.rank + 1) * n])
+            return _Done()
         if self._staged(inp):
             ho = torch.empty(out.shape, dtype=out.dtype)
             dist.reduce_scatter_tensor(ho, inp.cpu(), op=dist.ReduceOp.SUM, group=self.group)
@@ -135,6 +143,8 @@ class GradReducer:
         return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _all_gather(self, full, mine):
+        if self.elide:
+            return _Done()
         if self._staged(full):
             hf = torch.empty(full.shape, dtype=full.dtype)
             dist.all_gather_into_tensor(hf, mine.cpu(), group=self.group)
@@ -189,6 +199,8 @@ class GradReducer:
         works = []
         for which, a, b in self.bucket_ranges(native, stage, hi, lo):
             v = (native.gW if which == 0 else native.gP)[a:b]
+            if self.elide:
+                continue
             works.append(dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.bytes_on_wire += v.numel() * v.element_size()
         self.pending += works
@@ -219,7 +231,9 @@ class GradReducer:
             gWb = getattr(native, "gWb", None) if which == 0 else None      # bound: the Linear weight gradients exist ONLY there (bf16)
             if n % (4 * world):      # cannot be cut into aligned shards: replicate (all-reduce + full-range update)
                 gsrc = gWb[a:b] if gWb is not None else g
-                if self._staged(gsrc):
+                if self.elide:
+                    w = _Done()
+                elif self._staged(gsrc):
                     h = gsrc.cpu()
                     dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
                     gsrc.copy_(h)
@@ -309,6 +323,17 @@ class GradReducer:
         self._on_opt(opt_stream, main, run)
         if gpu:
             native.set_forward_waits(waits)
+
+    def abandon(self, native=None):
+        """Give up on this reducer after a failed step: forget half-issued work and undo what it bound on the engine (the
+        forward waits and the bf16 wire-gradient binding), so that another reducer / TrainLoop can take the model over."""
+        self.pending, self._deferred, self._repl_keys = [], [], []
+        native = native if native is not None else self._native
+        if native is not None:
+            if hasattr(native, "set_forward_waits") and native.gW.is_cuda:
+                native.set_forward_waits([])
+            if hasattr(native, "enable_wire_grads"):
+                native.enable_wire_grads(False)
 
     def finish(self, opt_stream=None):
         """the compute stream waits for every outstanding collective and for the optimizer stream (no host sync on GPU)"""

@@ -2,6 +2,8 @@
 """Training launcher — counterpart of reference train_transformer.py for the token-grid path.
 
   python -m mebt_amd.train --base cfg.yaml [more.yaml] [key.sub=value ...] --max_steps 1000
+  python -m mebt_amd.train --base cfg.yaml --gpus 0,1,2,3,4,5,6,7      (the reference's flag, train_transformer.py:39,46: this
+                                                                        process starts one rank per listed device as a child job)
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m mebt_amd.train --base cfg.yaml
 
 Same config handling as the reference (YAML list + dot-list overrides, train_transformer.py:25-27;
@@ -34,7 +36,23 @@ def main():
     ap.add_argument("--ckpt_path", default=None)
     ap.add_argument("--accumulate_grad_batches", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--gpus", default=None, help="device list '0,1,2,3' or a count (reference train_transformer.py:39,46); more than "
+                                                 "one device and no torch.distributed environment: the ranks are started from here")
+    ap.add_argument("--check_val_every_n_epoch", type=int, default=1, help="Lightning's flag (scripts/train_config_log_gpus.sh:3)")
+    ap.add_argument("--limit_val_batches", type=int, default=0, help="0 = the whole validation set")
     args, unknown = ap.parse_known_args()
+
+    ngpu = 1
+    if args.gpus:
+        ids = [g for g in str(args.gpus).strip(",").split(",") if g != ""]
+        ngpu = int(ids[0]) if len(ids) == 1 and "," not in str(args.gpus) and int(ids[0]) > 1 else len(ids)
+        if len(ids) > 1:
+            os.environ.setdefault("HIP_VISIBLE_DEVICES", ",".join(ids))     # rank r -> r-th listed device
+    from .launch import spawn_ranks_if_needed
+    import sys
+    rc = spawn_ranks_if_needed(ngpu, "mebt_amd.train", sys.argv[1:], module=True)      # before anything touches the GPU
+    if rc is not None:
+        sys.exit(rc)
 
     import torch.distributed as dist
     from . import presets
@@ -83,37 +101,76 @@ def main():
     dargs["resolution"] = None
     dargs["spatial_length"] = shape[1]
     dargs.setdefault("batch_size", 6)
-    loader = TokenData(dargs, world_size=world, rank=rank).train_dataloader()
-    epoch = start_step // max(1, len(loader))
+    data = TokenData(dargs, world_size=world, rank=rank)
+    loader = data.train_dataloader()
+    # `opt_step` counts OPTIMIZER steps (Lightning's global_step: --max_steps, the checkpointed 'global_step' and the LR /
+    # beta(t) / t_prior schedules all count those); with accumulate_grad_batches = k a step is k micro-batches
+    per_epoch = max(1, len(loader))
+    micro = int(ckpt["mebt_amd_loop"].get("micro_batches", start_step * accum)) if (ckpt is not None and "mebt_amd_loop" in ckpt) else 0
+    epoch, skip = micro // per_epoch, micro % per_epoch
     if hasattr(loader.sampler, "set_epoch"):
         loader.sampler.set_epoch(epoch)
     it = iter(loader)
+    for _ in range(skip):                 # resume inside an epoch: the batches already consumed are not replayed
+        next(it)
+
+    def validate():
+        """Lightning's validation loop around validation_step (reference transformer.py:741-747): eval mode, no gradients,
+        one `t` per batch from the python RNG as in training; mean loss / top-1 / top-5 over the set, averaged over ranks."""
+        vl = data.val_dataloader()
+        model.eval()
+        tot = torch.zeros(4, dtype=torch.float64, device=dev)
+        for bi, vb in enumerate(vl):
+            if args.limit_val_batches and bi >= args.limit_val_batches:
+                break
+            vb = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in vb.items()}
+            with torch.no_grad():
+                acc1, acc5, loss, _ = model.shared_step(vb, bi)
+            tot += torch.stack([loss.double().reshape(()), torch.as_tensor(acc1, device=dev).double().reshape(()),
+                                torch.as_tensor(acc5, device=dev).double().reshape(()), torch.ones((), dtype=torch.float64, device=dev)])
+        model.train()
+        tot = loop.reducer.mean_scalars(tot).cpu()
+        n = max(1.0, float(tot[3]))
+        return float(tot[0]) / n, float(tot[1]) / n, float(tot[2]) / n, int(tot[3])
+
     t0 = time.perf_counter()
-    for step in range(start_step, args.max_steps):
+    opt_step = start_step
+    while opt_step < args.max_steps:
         try:
             batch = next(it)
         except StopIteration:
             epoch += 1
+            if args.check_val_every_n_epoch and epoch % args.check_val_every_n_epoch == 0:
+                vloss, v1, v5, nb = validate()
+                if rank == 0:
+                    print(f"epoch {epoch}: val/loss {vloss:.4f} acc1 {v1:.2f} acc5 {v5:.2f} ({nb} batches)", flush=True)
             if hasattr(loader.sampler, "set_epoch"):
                 loader.sampler.set_epoch(epoch)
             it = iter(loader)
             batch = next(it)
         x, idx = batch["video"], batch["indices"]
+        before = loop.step_count
         stats = loop.step(x.to(dev, non_blocking=True), idx.to(dev, non_blocking=True))
-        if (step + 1) % args.log_every == 0:
+        micro += 1
+        if loop.step_count == before:     # a non-final micro-batch of an accumulation group
+            continue
+        opt_step += 1
+        if opt_step % args.log_every == 0:
             s = loop.reducer.mean_scalars(torch.stack([stats[4], 100 * stats[1] / stats[3], 100 * stats[2] / stats[3]])).cpu()
             if rank == 0:
                 dt = time.perf_counter() - t0
-                print(f"step {step + 1}: train/loss {s[0]:.4f} acc1 {s[1]:.2f} acc5 {s[2]:.2f} "
-                      f"lr {model.learning_rate * model.lr_scale():.3e}  {dt / (step + 1 - start_step) * 1e3:.1f} ms/step", flush=True)
-        if args.ckpt_every and (step + 1) % args.ckpt_every == 0:
+                print(f"step {opt_step}: train/loss {s[0]:.4f} acc1 {s[1]:.2f} acc5 {s[2]:.2f} "
+                      f"lr {model.learning_rate * model.lr_scale():.3e}  {dt / (opt_step - start_step) * 1e3:.1f} ms/step", flush=True)
+        if args.ckpt_every and opt_step % args.ckpt_every == 0:
             loop.consolidate()           # sharded optimizer: a collective on all ranks, then rank 0 writes
-        if args.ckpt_every and rank == 0 and (step + 1) % args.ckpt_every == 0:
+        if args.ckpt_every and rank == 0 and opt_step % args.ckpt_every == 0:
             os.makedirs(args.default_root_dir, exist_ok=True)
+            lsd = loop.state_dict()
+            lsd["micro_batches"] = micro
             torch.save({"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-                        "hyper_parameters": model.hparams, "global_step": step + 1, "epoch": epoch,
-                        "mebt_amd_loop": loop.state_dict()},
-                       os.path.join(args.default_root_dir, f"step={step + 1}.ckpt"))
+                        "hyper_parameters": model.hparams, "global_step": opt_step, "epoch": epoch,
+                        "mebt_amd_loop": lsd},
+                       os.path.join(args.default_root_dir, f"step={opt_step}.ckpt"))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

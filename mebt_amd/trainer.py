@@ -34,10 +34,16 @@ class TrainLoop:
         # of backward is latency/compute-bound, so the two overlap almost perfectly
         # ... provided the two streams do not share a hardware queue: probed, not assumed (parallel.pick_concurrent_stream)
         self.opt_stream = pick_concurrent_stream(torch.cuda.current_stream(), device=self.native.device) if overlap_optimizer else None
-        if self.reducer.active and self.reducer.mode == "sharded":
+        # The engine's bf16 wire-gradient binding must match the step() branch that will run: with it bound the Linear weight
+        # gradients exist ONLY in gWb (bf16), which only reduce_update() reads.  Set it either way — a TrainLoop built on a
+        # model whose previous loop had bound it (bench.py's fallback) must not inherit the binding.
+        self.sharded = bool(self.reducer.active and self.reducer.mode == "sharded")
+        wire = (self.sharded and self.reducer.wire == "bf16" and self.accum == 1 and model.compute_dtype == "bf16"
+                and os.environ.get("MEBT_DP_WIRE_GRADS", "1") != "0")
+        if self.sharded:
             self.native._adam_state()           # allocated up front: the first sharded update runs on the optimizer stream
-            if self.reducer.wire == "bf16" and self.accum == 1 and os.environ.get("MEBT_DP_WIRE_GRADS", "1") != "0":
-                self.native.enable_wire_grads()     # weight gradients leave the MFMA epilogue in the wire format
+        self.wire_grads = bool(wire)
+        self.native.enable_wire_grads(wire)     # weight gradients leave the MFMA epilogue in the wire format (or not)
         # one process, bf16: AdamW of the blocks' Linear weights is applied inside the weight-gradient launches of
         # backward (the gradient never goes to HBM and the optimizer traffic hides behind MFMA work); the all-reduce of a
         # data-parallel job needs the gradients first, so this is the single-GPU path only
@@ -84,12 +90,13 @@ class TrainLoop:
             nm.backward(logits, scale)
             nm.set_fused_adamw(step=0)
             nm.adamw_range("rest", None, None, lr, m.weight_decay, self.step_count)
-        elif self.opt_stream is None:
+        elif self.opt_stream is None and not self.sharded:
             nm.backward(logits, bwd_scale, between=lambda s, hi, lo: red.bucket_ready(nm, s, hi, lo))
             red.wait()
             nm.adamw_step(lr, m.weight_decay, self.step_count, grad_scale=red.grad_scale)
-        elif red.active and red.mode == "sharded":
-            # reduce-scatter -> AdamW on this rank's shard -> all-gather, bucket by bucket behind the backward (parallel.py)
+        elif self.sharded:
+            # reduce-scatter -> AdamW on this rank's shard -> all-gather, bucket by bucket behind the backward (parallel.py);
+            # without an optimizer stream (MEBT_OVERLAP_OPT=0) the same calls run in line on the compute stream
             opt = self.opt_stream
             update = lambda s, hi, lo: red.reduce_update(nm, s, hi, lo, lr, m.weight_decay, self.step_count, opt_stream=opt)
             if self.step_count == 1:

@@ -367,6 +367,11 @@ class Net2NetTransformer(LightningModuleShim):
         return (self.global_step << 20) ^ self._seed_ctr
 
     def _bucket_hook(self, stage, hi, lo):
+        if getattr(self._native, "gWb", None) is not None:
+            # a sharded TrainLoop bound the bf16 wire-gradient buffer: the Linear weight gradients of this backward went to gWb
+            # only, which the autograd path (fp32 .grad views, bucket-wise all-reduce) never reads
+            raise RuntimeError("this model's weight gradients are bound to the bf16 wire buffer of a sharded data-parallel "
+                               "TrainLoop; drive it with TrainLoop.step(), or build the loop with wire='fp32' / MEBT_DP_WIRE_GRADS=0")
         if self._reducer is not None:
             self._reducer.bucket_ready(self._native, stage, hi, lo)
 

@@ -34,7 +34,7 @@ def _batches():
     return xs, idxs, (0.45, 0.3, 0.0)            # t = 0: NC = 0 (empty key/value reductions: zero-filled gradient slices)
 
 
-def _worker(rank, world, port, dtype, mode, wire, defer, ret):
+def _worker(rank, world, port, dtype, mode, wire, defer, ret, overlap=True):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["MEBT_DP_DEFER_GATHER"] = "1" if defer else "0"
@@ -45,8 +45,10 @@ def _worker(rank, world, port, dtype, mode, wire, defer, ret):
         from mebt_amd.trainer import TrainLoop
         model = _make(dtype).to(DEV).train()
         red = GradReducer(world_size=world, mode=mode, wire=wire, layers_per_bucket=2)
-        loop = TrainLoop(model, red)
-        assert not loop.fused_optimizer
+        loop = TrainLoop(model, red, overlap_optimizer=overlap)
+        assert not loop.fused_optimizer and (loop.opt_stream is not None) == overlap
+        # the engine's wire-gradient binding follows the path that will run: bound only for sharded bf16
+        assert (loop.native.gWb is not None) == (mode == "sharded" and wire == "bf16" and dtype == "bf16")
         xs, idxs, ts = _batches()
         per = 4 // world
         # batches resident before the loop: a pageable host-to-device copy inside it waits for the whole device and would
@@ -75,16 +77,21 @@ def _worker(rank, world, port, dtype, mode, wire, defer, ret):
 
 @pytest.mark.parametrize("dtype,mode,wire,defer,world", [("f32", "sharded", "fp32", True, 2), ("bf16", "sharded", "bf16", True, 2),
                                                           ("bf16", "sharded", "bf16", False, 2), ("f32", "allreduce", "fp32", True, 2),
-                                                          ("bf16", "sharded", "bf16", True, 3)])
+                                                          ("bf16", "sharded", "bf16", True, 3), ("bf16", "sharded", "bf16", True, -2)])
 def test_two_ranks_on_one_gpu_equal_one_rank_double_batch(dtype, mode, wire, defer, world):
+    # world = -2: two ranks WITHOUT an optimizer stream (MEBT_OVERLAP_OPT=0 / overlap_optimizer=False): the sharded calls run
+    # in line on the compute stream, with the bf16 wire gradients bound (that combination used to update the Linear
+    # weights from a never-written fp32 gradient buffer)
+    overlap = world > 0
+    world = abs(world)
     # world = 3: the head (16384 x 256) and the non-Linear bucket do not cut into 4 x 3 aligned shards and take the replicated
     # fallback — with the bf16 wire gradients bound, i.e. an all-reduce of the bf16 buffer the weight-gradient launches wrote
     import torch.multiprocessing as mp
     from mebt_amd.trainer import TrainLoop
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    port = 32100 + (os.getpid() % 1500) + {"fp32": 0, "bf16": 3}[wire] + (5 if mode == "allreduce" else 0) + (7 if not defer else 0) + 13 * (world - 2)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype, mode, wire, defer, ret)) for r in range(world)]
+    port = 32100 + (os.getpid() % 1500) + {"fp32": 0, "bf16": 3}[wire] + (5 if mode == "allreduce" else 0) + (7 if not defer else 0) + 13 * (world - 2) + (17 if not overlap else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype, mode, wire, defer, ret, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     sd2, loss2, stale, adam2, wire_bytes = ret.get(timeout=900)
@@ -249,3 +256,24 @@ def test_sharded_path_trains_the_full_size_network_like_the_fused_path():
     assert p.exitcode == 0
     assert abs(first - np.log(16384)) < 0.6 and np.isfinite(last) and last < 0.5 and acc > 0.9 and finite, (first, last, acc, finite)
     print(f"[dp soak] loss {first:.3f} -> {last:.4f} in 400 sharded steps; reconstruction {100 * acc:.1f} %")
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torch.distributed environment (the shape of the command the driver runs for N = 1):
+    the parent starts the two ranks as a child job, relays the one JSON line and exits with the child's code.
+    Both ranks share this box's GPU over gloo (MEBT_BENCH_SHARE_GPU=1): functional, not a performance number."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MEBT_BENCH_SHARE_GPU"] = "1"
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--secondary", "none", "--no-cpu-baseline"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["value"] > 0
+    dp = r["data_parallel"]
+    assert dp["dp_mode"] == "sharded" and dp["wire"] == "bf16" and dp["rccl_ranks"] == 2 and dp["dp_fallback"] is None
+    assert dp["bytes_on_wire_per_step"] > 1e9 and dp["scaling_efficiency"] > 0 and "exposed_comm_ms" in dp
+    assert "cuda_initialized=False" in out.stderr

@@ -405,3 +405,33 @@ def test_load_from_lightning_format_checkpoint(tmp_path):
     torch.save({"state_dict": m.state_dict(), "hyper_parameters": m.hparams, "global_step": 7}, path2)
     m2 = Net2NetTransformer.load_from_checkpoint(path2)
     assert m2.global_step == 7 and all(torch.equal(m2.state_dict()[k], v) for k, v in sd.items())
+
+
+def test_bench_parent_starts_ranks_as_a_child_and_never_touches_the_gpu(tmp_path):
+    """`bench.py --gpus N` / `python -m mebt_amd.train --gpus 0,1` without a torch.distributed environment re-launch themselves
+    through mebt_amd/launch.py: child process (never exec), stdout relayed, the child's return code, and the parent's
+    torch.cuda never initialised.  The child command is replaced by a stub here (no GPU in the build container)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from mebt_amd.launch import launch_command
+    cmd = launch_command(8, "bench.py", ["--gpus", "8"], port=1234)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd and cmd[-3:] == ["bench.py", "--gpus", "8"]
+    assert "127.0.0.1" in cmd
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    stub = tmp_path / "child.py"
+    stub.write_text("import sys\nprint('{\"value\": 1}')\nsys.exit(int(sys.argv[1]))\n")
+    for script in (["bench.py", "--gpus", "2", "--steps", "1"], ["-m", "mebt_amd.train", "--preset", "tiny", "--gpus", "0,1"]):
+        for code in (0, 3):
+            env["MEBT_LAUNCH_CHILD"] = f"{sys.executable} {stub} {code}"
+            out = subprocess.run([sys.executable] + script, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+            assert out.returncode == code, (script, out.stderr[-2000:])
+            assert out.stdout.strip() == '{"value": 1}', out.stdout
+            assert "cuda_initialized=False" in out.stderr and "starting 2 ranks" in out.stderr
+    # inside a distributed launch (WORLD_SIZE / RANK set) nothing is spawned
+    from mebt_amd import launch
+    os.environ["WORLD_SIZE"], os.environ["RANK"] = "2", "0"
+    try:
+        assert launch.spawn_ranks_if_needed(2, "bench.py", []) is None
+    finally:
+        del os.environ["WORLD_SIZE"], os.environ["RANK"]
+    assert launch.spawn_ranks_if_needed(1, "bench.py", []) is None
