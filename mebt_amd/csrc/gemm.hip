@@ -405,9 +405,10 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
     if (!n) return MEBT_OK;
     c.beta = w.beta; c.scratch = w.scratch; c.Cb = w.Cb; c.gW = w.gW;
     c.fused = w.fused; c.W = w.W; c.gW = w.gW; c.mW = w.mW; c.vW = w.vW; c.Wlp = w.Wlp; c.opt = w.opt;
-    for (int i = 1; i < n; ++i)              // insertion sort, K descending
+    for (int i = 1; i < n; ++i)              // insertion sort, K descending: the canonical order of the tuner key (the launchers order the items themselves)
         for (int j = i; j > 0 && c.g[j].K > c.g[j - 1].K; --j) { const GroupedWgrad::Item t = c.g[j]; c.g[j] = c.g[j - 1]; c.g[j - 1] = t; }
-    int tbm = 128, tbn = 128, stages = g_grouped_stages == 3 ? 3 : 2;
+    int tbm = 128, tbn = 128, stages = g_grouped_stages >= 32 ? g_grouped_stages : g_grouped_stages == 3 ? 3 : 2;
+    if (stages >= 32 && !grouped_split_ok(c)) stages = 2;
     {
         std::lock_guard<std::mutex> lk(g_tune_mutex);
         tune_init();
@@ -430,6 +431,13 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
                     if (g_tune_log >= 2) fprintf(stderr, "    cand grouped %dx%d ring %d%s%s: %.1f us\n", tiles[t][0], tiles[t][1], st, tc.fused ? " +adamw" : "", tc.Cb ? " bf16-out" : "", ms * 1e3f);
                     if (ms < best) { best = ms; tbm = tiles[t][0]; tbn = tiles[t][1]; stages = st; }
                 }
+            if (grouped_split_ok(tc))         // split roles: multiplier waves + AdamW streamer waves in one persistent workgroup per CU
+                for (int code : {34, 35, 50, 51}) {
+                    float ms = 0.f;
+                    if (int rc = time_cold([&] { launch_grouped_config(tc, 128, 128, code, stream); }, stream, tr, ms)) return rc;
+                    if (g_tune_log >= 2) fprintf(stderr, "    cand grouped split-role ring %d prefetch %d +adamw: %.1f us\n", code & 3, code < 48 ? 8 : 4, ms * 1e3f);
+                    if (ms < best) { best = ms; tbm = 128; tbn = 128; stages = code; }
+                }
             if (g_tune_log) {
                 fprintf(stderr, "[mebt gemm autotune] grouped wgrad");
                 for (int i = 0; i < n; ++i) fprintf(stderr, " %dx%dx%d", c.g[i].M, c.g[i].N, c.g[i].K);
@@ -439,6 +447,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
             tune_remember(key, it->second);
         }
         if (it != g_tuned.end()) { tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; stages = it->second & 255; }
+        if (stages >= 32 && !grouped_split_ok(c)) stages = 2;       // a cached choice of another mode's neighbour
     }
     launch_grouped_config(c, tbm, tbn, stages, stream);
     MEBT_HIP_CHECK(hipGetLastError());

@@ -762,6 +762,212 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w
 }
 
 // ------------------------------------------------------------------------------------------------
+// Grouped weight gradients + AdamW with SPLIT ROLES (optimizer-in-backward, one GPU).  wgrad_grouped_kernel above runs
+// the optimizer as the epilogue of each tile in the waves that just multiplied it: per workgroup the matrix pipes and the
+// HBM stream are used one after the other, and the launch took the SUM of the two (117 us for 39 GFLOP + 327 MB per block
+// at C2: 0.13 of the MFMA peak, 0.59 of the achievable HBM rate — bound by neither).  Here one persistent 8-wave workgroup
+// per CU walks a list of 128 x 128 tiles:
+//   waves 0-3 ("multipliers"): the LDS-DMA ring + MFMA k-loop of tile j; at its end they park the fp32 accumulators in a
+//                              64 KiB LDS stash and go on with tile j + 1;
+//   waves 4-7 ("streamers"):   AdamW on the stash of tile j - 1 (p, m, v read and written in place, bf16 mirror refreshed)
+//                              WHILE tile j multiplies — 16 chunks of 8 rows, p/m/v prefetched D chunks (and across the
+//                              tile boundary) ahead in registers, with a vmcnt queue of their own: the ring's counted
+//                              waits never see an HBM latency.
+// The optimizer moves 26 B per parameter (426 KB per tile, ~18 us of one CU's HBM share) against ~6-9 us of k-loop, so the
+// launch is an HBM stream with the multiplications hidden under it; only the first tile's k-loop (shortest reduction first)
+// and the last tile's update are exposed.  Both roles execute the same number of s_barriers: one per k-step (a streamer
+// processes its chunks between them, spread evenly over the k-steps), B1 "stash may be overwritten" and B2 "stash is full".
+// Stash image: row-major [128][128] fp32, 16-byte blocks XOR-swizzled by (row & 15): the multipliers' fragment-shaped
+// ds_write_b128 (16 rows x 16 B) and the streamers' row-contiguous ds_read_b128 are both conflict-free without padding.
+// ------------------------------------------------------------------------------------------------
+struct WgTile { int g, m0, n0, nk; };
+__device__ __forceinline__ WgTile wg_decode(const GroupedWgrad& w, int T) {
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < MEBT_MAX_GROUP; ++i)
+        if (i < w.n && T >= w.tile_start[i]) g = i;
+    const GroupedWgrad::Item& it = w.g[g];
+    int tr, tc;
+    xcd_tile(T - w.tile_start[g], it.ntx, (it.M + 127) / 128, it.M, it.N, tr, tc);
+    WgTile t;
+    t.g = g; t.m0 = tr * 128; t.n0 = tc * 128; t.nk = (it.K + BK - 1) / BK;
+    return t;
+}
+
+template <int NSTAGE, int D /* chunks of p/m/v in flight per streamer wave: divides 16 */>
+__global__ __launch_bounds__(512) void wgrad_adamw_kernel(const GroupedWgrad w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TBM = 128, TBN = 128, TM = 4, TN = 4;
+    constexpr int STAGE = (TBM + TBN) * BK * 2;             // 32 KiB per k-tile
+    constexpr int LPT = (TBM + TBN) / 32;                    // DMA instructions per multiplier wave per k-tile
+    constexpr int AHEAD = NSTAGE - 1;
+    constexpr int NCH = 16;                                  // chunks (8 rows) per tile
+    char* ring = smem;
+    char* stash = smem + NSTAGE * STAGE;                     // [128][128] fp32, swizzled
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x, T = w.tile_start[w.n];
+    const int ntiles = (T - (int)blockIdx.x + G - 1) / G;    // tiles blockIdx.x, blockIdx.x + G, ...
+
+    if (wave < 4) {
+        // ---------------------------------------------------------------- multipliers
+        const int wm = wave >> 1, wn = wave & 1;
+        DmaLoader<false, TBM> la;
+        DmaLoader<false, TBN> lb;
+        WgTile cur = wg_decode(w, blockIdx.x);
+        {
+            const GroupedWgrad::Item& it = w.g[cur.g];
+            la.init(it.A, it.M, it.K, it.lda, cur.m0, wave, lane);
+            lb.init(it.B, it.N, it.K, it.ldb, cur.n0, wave, lane);
+#pragma unroll
+            for (int a = 0; a < AHEAD; ++a)
+                if (a < cur.nk) { la.issue(ring + a * STAGE, a, wave); lb.issue(ring + a * STAGE + TBM * BK * 2, a, wave); }
+        }
+        for (int j = 0; j < ntiles; ++j) {
+            f32x4 acc[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int nk = cur.nk;
+            int st = 0;
+            for (int t = 0; t < nk; ++t) {
+                const int younger = min(AHEAD - 1, nk - 1 - t);
+                if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + AHEAD < nk) {
+                    int s2 = st + AHEAD; if (s2 >= NSTAGE) s2 -= NSTAGE;
+                    la.issue(ring + s2 * STAGE, t + AHEAD, wave);
+                    lb.issue(ring + s2 * STAGE + TBM * BK * 2, t + AHEAD, wave);
+                }
+                const char* sA = ring + st * STAGE;
+                const char* sB = sA + TBM * BK * 2;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 af[TM], bf[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i] = read_frag<false, TBM>(sA, wm * TM + i, ks, lane);
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) bf[jj] = read_frag<false, TBN>(sB, wn * TN + jj, ks, lane);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < TN; ++jj)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[jj], af[i], acc[i][jj], 0, 0, 0);
+                }
+                if (++st == NSTAGE) st = 0;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // B1: every multiplier is out of the ring, the streamers are done with the stash
+            asm volatile("" ::: "memory");
+            if (j + 1 < ntiles) {                            // the next tile's first k-tiles travel while the stash is written
+                cur = wg_decode(w, blockIdx.x + (j + 1) * G);
+                const GroupedWgrad::Item& it = w.g[cur.g];
+                la.init(it.A, it.M, it.K, it.lda, cur.m0, wave, lane);
+                lb.init(it.B, it.N, it.K, it.ldb, cur.n0, wave, lane);
+#pragma unroll
+                for (int a = 0; a < AHEAD; ++a)
+                    if (a < cur.nk) { la.issue(ring + a * STAGE, a, wave); lb.issue(ring + a * STAGE + TBM * BK * 2, a, wave); }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) {
+                    const int row = wm * 64 + i * 16 + (lane & 15);
+                    const int blk = (wn * 16 + jj * 4 + (lane >> 4)) ^ (row & 15);
+                    *reinterpret_cast<f32x4*>(stash + row * 512 + blk * 16) = acc[i][jj];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // B2: the stash holds tile j
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------- streamers
+    const int sw = wave - 4;                                 // rows 2 sw, 2 sw + 1 of every 8-row chunk
+    const int crow = 2 * sw + (lane >> 5), cblk = lane & 31;
+    const AdamWHyper opt = w.opt;
+    // Everything the streamers send to memory is UNCONDITIONAL and goes through buffer resources: a lane outside the tile, a
+    // missing bf16 mirror and "no next tile" are out-of-range offsets / zero-sized resources (loads return 0, stores are
+    // dropped, no traffic).  The instruction stream between a prefetch and its use is then the same on every path, so hipcc's
+    // counted vmcnt waits keep the full D chunks in flight — with conditional stores / fetches it drained the queue at every
+    // tile boundary (ISA: s_waitcnt vmcnt(0) at chunk 0).
+    struct Dst { __amdgpu_buffer_rsrc_t p, m, v, lp; int M, N, ldc, m0, n0; };
+    auto describe = [&](int T_, bool valid) {
+        Dst d;
+        const WgTile t = wg_decode(w, valid ? T_ : (int)blockIdx.x);
+        const GroupedWgrad::Item& it = w.g[t.g];
+        const ptrdiff_t off = it.C - w.gW;
+        const size_t bytes = valid ? (size_t)it.M * it.ldc * 4 : 0;
+        d.p = make_rsrc(w.W + off, bytes); d.m = make_rsrc(w.mW + off, bytes); d.v = make_rsrc(w.vW + off, bytes);
+        const bool has_lp = w.Wlp != nullptr;
+        d.lp = make_rsrc(has_lp ? (const void*)(reinterpret_cast<const bf16_t*>(w.Wlp) + off) : (const void*)w.W, has_lp ? bytes / 2 : 0);
+        d.M = it.M; d.N = it.N; d.ldc = it.ldc; d.m0 = t.m0; d.n0 = t.n0;
+        return d;
+    };
+    auto elem_off = [&](const Dst& d, int c) -> uint32_t {      // element offset of this lane's 4 columns in chunk c, or OOB
+        const int m = d.m0 + 8 * c + crow, n = d.n0 + 4 * cblk;
+        return (m < d.M && n < d.N) ? (uint32_t)m * (uint32_t)d.ldc + (uint32_t)n : 0x1FFFFFFFu;   // x 4 / x 2 stay >= any num_records
+    };
+    u32x4 rp[D], rm[D], rv[D];
+    auto fetch = [&](const Dst& d, int c, int slot) {
+        const uint32_t o = elem_off(d, c) * 4u;
+        rp[slot] = buf_load16(d.p, o); rm[slot] = buf_load16(d.m, o); rv[slot] = buf_load16(d.v, o);
+    };
+    Dst dcur = describe(blockIdx.x, true), dnext = dcur;
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    const u32x2 z2 = {0u, 0u};
+#pragma unroll
+    for (int c = 0; c < D; ++c) {                            // p/m/v of the first chunks travel during the first k-loop
+        fetch(dcur, c, c);
+        if (c + 1 < D) {                                     // four dropped stores: the same op count per chunk as the steady state (see above)
+            __builtin_amdgcn_raw_buffer_store_b128(z4, dcur.p, 0x7FFFFFF0u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(z4, dcur.m, 0x7FFFFFF0u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(z4, dcur.v, 0x7FFFFFF0u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(z2, dcur.lp, 0x7FFFFFF0u, 0, 0);
+        }
+    }
+
+    for (int j = 0; j <= ntiles; ++j) {                      // phase j: barriers of tile j's k-loop, chunks of tile j - 1
+        int nk = 0;
+        if (j < ntiles) nk = wg_decode(w, blockIdx.x + j * G).nk;
+        if (j >= 1) dnext = describe(blockIdx.x + j * G, j < ntiles);
+        int bar = 0;
+        if (j >= 1) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int step = c * nk / NCH;               // chunk c is processed before the barrier of k-step `step`
+                while (bar < step) { __builtin_amdgcn_s_barrier(); ++bar; }
+                const int slot = c % D;
+                const int row = 8 * c + crow;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(stash + row * 512 + ((cblk ^ (row & 15)) << 4));
+                f32x4 p = __builtin_bit_cast(f32x4, rp[slot]), mm = __builtin_bit_cast(f32x4, rm[slot]), vv = __builtin_bit_cast(f32x4, rv[slot]);
+                adamw_update4(p, g, mm, vv, opt);
+                const uint32_t eo = elem_off(dcur, c);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p), dcur.p, eo * 4u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mm), dcur.m, eo * 4u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), dcur.v, eo * 4u, 0, 0);
+                const bf16x4 lp = {(bf16_t)p[0], (bf16_t)p[1], (bf16_t)p[2], (bf16_t)p[3]};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lp), dcur.lp, eo * 2u, 0, 0);
+                // refill the slot: chunk c + D of this tile, or of the next one (a zero-sized resource after the last tile)
+                if (c + D < NCH) fetch(dcur, c + D, slot);
+                else fetch(dnext, c + D - NCH, slot);
+            }
+        }
+        while (bar < nk) { __builtin_amdgcn_s_barrier(); ++bar; }
+        if (j < ntiles) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's stash reads have returned
+            __builtin_amdgcn_s_barrier();                    // B1
+            __builtin_amdgcn_s_barrier();                    // B2
+            asm volatile("" ::: "memory");
+            dcur = dnext;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // f32 kernel (parity mode).  LDS image is always [k][row] (row fastest); KC operands are
 // transposed by the staging write, RC operands are copied.  BK = 16.
 // ------------------------------------------------------------------------------------------------
@@ -990,7 +1196,39 @@ static void layout_launch_pair(GemmPair& g, int tbm, int tbn, int staging, hipSt
 // grouped weight gradients of one block.  Items are ordered by reduction length, longest first (the key
 // projection reduces over twice as many tokens as the rest: started last, its tiles were the tail of the
 // launch), and the block tile / ring depth are autotuned per group signature like the single GEMMs.
+static int mebt_num_cus() {
+    static const int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+    return n;
+}
+// stages >= 32: the split-role kernel (wgrad_adamw_kernel, fused optimizer only): ring depth = stages & 3 (2 or 3), p/m/v prefetch
+// depth 8 chunks (32 + ring) or 4 (48 + ring); 128 x 128 tiles, one persistent workgroup per CU, shortest reduction first
+static inline bool grouped_split_ok(const GroupedWgrad& c) {
+    if (!c.fused || c.beta || c.Cb) return false;
+    for (int i = 0; i < c.n; ++i) if (c.g[i].N % 4 || c.g[i].M <= 0 || c.g[i].K <= 0) return false;
+    return true;
+}
+static void layout_launch_grouped_split(GroupedWgrad& c, int stages, hipStream_t stream) {
+    for (int i = 1; i < c.n; ++i)              // insertion sort, K ascending: the first tile's k-loop is the exposed one
+        for (int j = i; j > 0 && c.g[j].K < c.g[j - 1].K; --j) { const GroupedWgrad::Item t = c.g[j]; c.g[j] = c.g[j - 1]; c.g[j - 1] = t; }
+    int tiles = 0;
+    for (int i = 0; i < c.n; ++i) {
+        c.g[i].ntx = (c.g[i].N + 127) / 128;
+        c.tile_start[i] = tiles;
+        tiles += ((c.g[i].M + 127) / 128) * c.g[i].ntx;
+    }
+    for (int i = c.n; i <= MEBT_MAX_GROUP; ++i) c.tile_start[i] = tiles;
+    const int ring = (stages & 3) == 3 ? 3 : 2, deep = stages < 48;
+    const int grid = tiles < mebt_num_cus() ? tiles : mebt_num_cus();
+    const int lds = ring * 256 * BK * 2 + 128 * 128 * 4;
+    if (ring == 3 && deep) hipLaunchKernelGGL((wgrad_adamw_kernel<3, 8>), dim3(grid), dim3(512), lds, stream, c);
+    else if (ring == 3) hipLaunchKernelGGL((wgrad_adamw_kernel<3, 4>), dim3(grid), dim3(512), lds, stream, c);
+    else if (deep) hipLaunchKernelGGL((wgrad_adamw_kernel<2, 8>), dim3(grid), dim3(512), lds, stream, c);
+    else hipLaunchKernelGGL((wgrad_adamw_kernel<2, 4>), dim3(grid), dim3(512), lds, stream, c);
+}
 static void layout_launch_grouped(GroupedWgrad& c, int tbm, int tbn, int stages, hipStream_t stream) {
+    if (stages >= 32) { layout_launch_grouped_split(c, stages, stream); return; }
+    for (int i = 1; i < c.n; ++i)              // insertion sort, K descending (longest reduction first: its tiles are not the tail)
+        for (int j = i; j > 0 && c.g[j].K > c.g[j - 1].K; --j) { const GroupedWgrad::Item t = c.g[j]; c.g[j] = c.g[j - 1]; c.g[j - 1] = t; }
     int tiles = 0;
     for (int i = 0; i < c.n; ++i) {
         c.g[i].ntx = (c.g[i].N + tbn - 1) / tbn;
@@ -1069,5 +1307,9 @@ static int layout_set_grouped_attrs() {
     } while (0)
     SET_G(128, 128); SET_G(128, 64); SET_G(64, 128); SET_G(64, 64);
 #undef SET_G
+    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_adamw_kernel<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 256 * BK * 2 + 65536));
+    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_adamw_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 256 * BK * 2 + 65536));
+    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_adamw_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * BK * 2 + 65536));
+    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_adamw_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * BK * 2 + 65536));
     return MEBT_OK;
 }
