@@ -228,6 +228,13 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
             if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d: %.1f us\n", bm, bn, st, ms * 1e3f);
             if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = st; }
         }
+        for (int st = 2; st <= 4 && !few; ++st) {                                 // software-pipelined main loop (staging 8 + ring depth)
+            if (st * (bm + bn) * BK * 2 > 160 * 1024) continue;
+            float ms = 0.f;
+            if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, 8 + st, 1, stream); }, stream, tr, ms)) return rc;
+            if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d pipelined: %.1f us\n", bm, bn, st, ms * 1e3f);
+            if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = 8 + st; }
+        }
         if (!p.c_f32 && p.C && nt <= 256 && (long)bm * bn >= 128 * 128)          // split-K into fp32 slabs + reduce/epilogue kernel (staging 32 * log2(S) + ring)
             for (int S = 2; S <= 4; S *= 2) {
                 if (p.K % (S * BK) || p.K / S < 8 * BK || !splitk_fits(p, S)) continue;
@@ -258,7 +265,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
     }
     if (g_tune_log)
         fprintf(stderr, "[mebt gemm autotune] M=%d N=%d K=%d a_kc=%d b_kc=%d epi=%d c_f32=%d -> %dx%d ring %d%s (%.1f us cold)\n", p.M, p.N, p.K,
-                p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, staging & 15, staging >= 64 ? " split-K 4" : staging >= 32 ? " split-K 2" : staging >= 16 ? " x2 pipelines" : "", best * 1e3f);
+                p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, (staging >= 8 && staging < 16) ? staging - 8 : (staging & 15), staging >= 64 ? " split-K 4" : staging >= 32 ? " split-K 2" : staging >= 16 ? " x2 pipelines" : staging >= 8 ? " pipelined" : "", best * 1e3f);
     return MEBT_OK;
 }
 
@@ -407,8 +414,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
     c.fused = w.fused; c.W = w.W; c.gW = w.gW; c.mW = w.mW; c.vW = w.vW; c.Wlp = w.Wlp; c.opt = w.opt;
     for (int i = 1; i < n; ++i)              // insertion sort, K descending: the canonical order of the tuner key (the launchers order the items themselves)
         for (int j = i; j > 0 && c.g[j].K > c.g[j - 1].K; --j) { const GroupedWgrad::Item t = c.g[j]; c.g[j] = c.g[j - 1]; c.g[j - 1] = t; }
-    int tbm = 128, tbn = 128, stages = g_grouped_stages >= 32 ? g_grouped_stages : g_grouped_stages == 3 ? 3 : 2;
-    if (stages >= 32 && !grouped_split_ok(c)) stages = 2;
+    int tbm = 128, tbn = 128, stages = g_grouped_stages == 3 ? 3 : 2;
     {
         std::lock_guard<std::mutex> lk(g_tune_mutex);
         tune_init();
@@ -431,13 +437,6 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
                     if (g_tune_log >= 2) fprintf(stderr, "    cand grouped %dx%d ring %d%s%s: %.1f us\n", tiles[t][0], tiles[t][1], st, tc.fused ? " +adamw" : "", tc.Cb ? " bf16-out" : "", ms * 1e3f);
                     if (ms < best) { best = ms; tbm = tiles[t][0]; tbn = tiles[t][1]; stages = st; }
                 }
-            if (grouped_split_ok(tc))         // split roles: multiplier waves + AdamW streamer waves in one persistent workgroup per CU
-                for (int code : {34, 35, 50, 51}) {
-                    float ms = 0.f;
-                    if (int rc = time_cold([&] { launch_grouped_config(tc, 128, 128, code, stream); }, stream, tr, ms)) return rc;
-                    if (g_tune_log >= 2) fprintf(stderr, "    cand grouped split-role ring %d prefetch %d +adamw: %.1f us\n", code & 3, code < 48 ? 8 : 4, ms * 1e3f);
-                    if (ms < best) { best = ms; tbm = 128; tbn = 128; stages = code; }
-                }
             if (g_tune_log) {
                 fprintf(stderr, "[mebt gemm autotune] grouped wgrad");
                 for (int i = 0; i < n; ++i) fprintf(stderr, " %dx%dx%d", c.g[i].M, c.g[i].N, c.g[i].K);
@@ -447,7 +446,6 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
             tune_remember(key, it->second);
         }
         if (it != g_tuned.end()) { tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; stages = it->second & 255; }
-        if (stages >= 32 && !grouped_split_ok(c)) stages = 2;       // a cached choice of another mode's neighbour
     }
     launch_grouped_config(c, tbm, tbn, stages, stream);
     MEBT_HIP_CHECK(hipGetLastError());

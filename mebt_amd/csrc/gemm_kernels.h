@@ -597,6 +597,108 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
     }
 }
 
+// Software-pipelined variant of gemm_tile_dma (same ring, same images, same counted waits): the fragment reads of one
+// 32-deep k-step are issued BEFORE the MFMAs of the previous one, across the k-tile barrier as well, in two register sets:
+//     read F1(t) | MFMA F0(t) | lgkmcnt(0), vmcnt, barrier | read F0(t+1), DMA tile t+NSTAGE -> slot of tile t | MFMA F1(t)
+// In gemm_tile_dma every k-step starts with an exposed LDS round trip (the compiler waits for the reads right in front of
+// the MFMAs that consume them) and every k-tile with the DMA issue; tools/fill_bench.hip (the same loops without reads and
+// MFMAs) showed those loops running at 0.5-0.6 of the rate their own staging sustains (fc1 at 1536 rows: 11 us of fill,
+// 23 us with the multiplications), i.e. the launches were bound by the serial chain inside a k-step, not by the fill rate.
+// The slot of tile t is free for the next DMA at the barrier of tile t + 1 because every wave drains its LDS queue
+// (lgkmcnt(0): the F1(t) reads were issued a whole MFMA group earlier) before it arrives there.
+template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
+__device__ __forceinline__ void gemm_tile_pipe(const GemmParams& p, int m0, int n0, int kt0, int kt1, char* smem, bool atomic, bool add_bias) {
+    constexpr int STAGE = (TBM + TBN) * BK * 2;
+    constexpr int TM = TBM / 32, TN = TBN / 32;
+    constexpr int LPT = (TBM + TBN) / 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nk = kt1 - kt0;
+    DmaLoader<A_KC, TBM> la;
+    DmaLoader<B_KC, TBN> lb;
+    la.init(p.A, p.M, p.K, p.lda, m0, wave, lane);
+    lb.init(p.B, p.N, p.K, p.ldb, n0, wave, lane);
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int AHEAD = NSTAGE - 1;
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        if (a < nk) {
+            la.issue(smem + a * STAGE, kt0 + a, wave);
+            lb.issue(smem + a * STAGE + TBM * BK * 2, kt0 + a, wave);
+        }
+    auto wait_tile = [&](int t) {       // tile t has landed; the (up to AHEAD - 1) younger ones may stay in flight
+        const int younger = min(AHEAD - 1, nk - 1 - t);
+        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+    };
+    bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+    wait_tile(0);
+    __builtin_amdgcn_s_barrier();
+    if (AHEAD < nk) {
+        la.issue(smem + AHEAD * STAGE, kt0 + AHEAD, wave);
+        lb.issue(smem + AHEAD * STAGE + TBM * BK * 2, kt0 + AHEAD, wave);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a0[i] = read_frag<A_KC, TBM>(smem, wm * TM + i, 0, lane);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b0[j] = read_frag<B_KC, TBN>(smem + TBM * BK * 2, wn * TN + j, 0, lane);
+    int st = 0;
+    for (int t = 0; t < nk; ++t) {
+        const char* sA = smem + st * STAGE;
+        const char* sB = sA + TBM * BK * 2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a1[i] = read_frag<A_KC, TBM>(sA, wm * TM + i, 1, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b1[j] = read_frag<B_KC, TBN>(sB, wn * TN + j, 1, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
+        int sn = st + 1; if (sn == NSTAGE) sn = 0;
+        if (t + 1 < nk) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave is done with slot `st` (F1 is in registers)
+            wait_tile(t + 1);
+            __builtin_amdgcn_s_barrier();
+            const char* nA = smem + sn * STAGE;
+            const char* nB = nA + TBM * BK * 2;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a0[i] = read_frag<A_KC, TBM>(nA, wm * TM + i, 0, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b0[j] = read_frag<B_KC, TBN>(nB, wn * TN + j, 0, lane);
+            if (t + 1 + AHEAD < nk) {                                // into the slot of tile t: every wave is past its reads
+                la.issue(smem + st * STAGE, kt0 + t + 1 + AHEAD, wave);
+                lb.issue(smem + st * STAGE + TBM * BK * 2, kt0 + t + 1 + AHEAD, wave);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+        st = sn;
+    }
+    epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
+}
+
+template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
+__global__ __launch_bounds__(256) void gemm_bf16_pipe_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntx = gridDim.x, nty = gridDim.y;
+    const PrefetchRegs pfr = prefetch_next(p, blockIdx.y * ntx + blockIdx.x, ntx * nty, 256);
+    int tr, tc;
+    xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
+    gemm_tile_pipe<A_KC, B_KC, TBM, TBN, NSTAGE>(p, tr * TBM, tc * TBN, 0, (p.K + BK - 1) / BK, smem, false, true);
+    prefetch_sink(p, pfr);
+}
+
 // 8-wave workgroup on ONE 256 x 256 tile: waves 2 (M) x 4 (N), wave tile 128 x 64.  Per k-tile it moves 64 KiB for
 // 8.4 MFLOP (7.8 B per KFLOP, 40 % less than 192 x 128), which lifts the fill-rate cap of the large products
 // (outputs of >= 12 M elements: the MLP up-projection at 3072 rows, the vocabulary head).
@@ -762,212 +864,6 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w
 }
 
 // ------------------------------------------------------------------------------------------------
-// Grouped weight gradients + AdamW with SPLIT ROLES (optimizer-in-backward, one GPU).  wgrad_grouped_kernel above runs
-// the optimizer as the epilogue of each tile in the waves that just multiplied it: per workgroup the matrix pipes and the
-// HBM stream are used one after the other, and the launch took the SUM of the two (117 us for 39 GFLOP + 327 MB per block
-// at C2: 0.13 of the MFMA peak, 0.59 of the achievable HBM rate — bound by neither).  Here one persistent 8-wave workgroup
-// per CU walks a list of 128 x 128 tiles:
-//   waves 0-3 ("multipliers"): the LDS-DMA ring + MFMA k-loop of tile j; at its end they park the fp32 accumulators in a
-//                              64 KiB LDS stash and go on with tile j + 1;
-//   waves 4-7 ("streamers"):   AdamW on the stash of tile j - 1 (p, m, v read and written in place, bf16 mirror refreshed)
-//                              WHILE tile j multiplies — 16 chunks of 8 rows, p/m/v prefetched D chunks (and across the
-//                              tile boundary) ahead in registers, with a vmcnt queue of their own: the ring's counted
-//                              waits never see an HBM latency.
-// The optimizer moves 26 B per parameter (426 KB per tile, ~18 us of one CU's HBM share) against ~6-9 us of k-loop, so the
-// launch is an HBM stream with the multiplications hidden under it; only the first tile's k-loop (shortest reduction first)
-// and the last tile's update are exposed.  Both roles execute the same number of s_barriers: one per k-step (a streamer
-// processes its chunks between them, spread evenly over the k-steps), B1 "stash may be overwritten" and B2 "stash is full".
-// Stash image: row-major [128][128] fp32, 16-byte blocks XOR-swizzled by (row & 15): the multipliers' fragment-shaped
-// ds_write_b128 (16 rows x 16 B) and the streamers' row-contiguous ds_read_b128 are both conflict-free without padding.
-// ------------------------------------------------------------------------------------------------
-struct WgTile { int g, m0, n0, nk; };
-__device__ __forceinline__ WgTile wg_decode(const GroupedWgrad& w, int T) {
-    int g = 0;
-#pragma unroll
-    for (int i = 1; i < MEBT_MAX_GROUP; ++i)
-        if (i < w.n && T >= w.tile_start[i]) g = i;
-    const GroupedWgrad::Item& it = w.g[g];
-    int tr, tc;
-    xcd_tile(T - w.tile_start[g], it.ntx, (it.M + 127) / 128, it.M, it.N, tr, tc);
-    WgTile t;
-    t.g = g; t.m0 = tr * 128; t.n0 = tc * 128; t.nk = (it.K + BK - 1) / BK;
-    return t;
-}
-
-template <int NSTAGE, int D /* chunks of p/m/v in flight per streamer wave: divides 16 */>
-__global__ __launch_bounds__(512) void wgrad_adamw_kernel(const GroupedWgrad w) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TBM = 128, TBN = 128, TM = 4, TN = 4;
-    constexpr int STAGE = (TBM + TBN) * BK * 2;             // 32 KiB per k-tile
-    constexpr int LPT = (TBM + TBN) / 32;                    // DMA instructions per multiplier wave per k-tile
-    constexpr int AHEAD = NSTAGE - 1;
-    constexpr int NCH = 16;                                  // chunks (8 rows) per tile
-    char* ring = smem;
-    char* stash = smem + NSTAGE * STAGE;                     // [128][128] fp32, swizzled
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = gridDim.x, T = w.tile_start[w.n];
-    const int ntiles = (T - (int)blockIdx.x + G - 1) / G;    // tiles blockIdx.x, blockIdx.x + G, ...
-
-    if (wave < 4) {
-        // ---------------------------------------------------------------- multipliers
-        const int wm = wave >> 1, wn = wave & 1;
-        DmaLoader<false, TBM> la;
-        DmaLoader<false, TBN> lb;
-        WgTile cur = wg_decode(w, blockIdx.x);
-        {
-            const GroupedWgrad::Item& it = w.g[cur.g];
-            la.init(it.A, it.M, it.K, it.lda, cur.m0, wave, lane);
-            lb.init(it.B, it.N, it.K, it.ldb, cur.n0, wave, lane);
-#pragma unroll
-            for (int a = 0; a < AHEAD; ++a)
-                if (a < cur.nk) { la.issue(ring + a * STAGE, a, wave); lb.issue(ring + a * STAGE + TBM * BK * 2, a, wave); }
-        }
-        for (int j = 0; j < ntiles; ++j) {
-            f32x4 acc[TM][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jj = 0; jj < TN; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int nk = cur.nk;
-            int st = 0;
-            for (int t = 0; t < nk; ++t) {
-                const int younger = min(AHEAD - 1, nk - 1 - t);
-                if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-                __builtin_amdgcn_s_barrier();
-                if (t + AHEAD < nk) {
-                    int s2 = st + AHEAD; if (s2 >= NSTAGE) s2 -= NSTAGE;
-                    la.issue(ring + s2 * STAGE, t + AHEAD, wave);
-                    lb.issue(ring + s2 * STAGE + TBM * BK * 2, t + AHEAD, wave);
-                }
-                const char* sA = ring + st * STAGE;
-                const char* sB = sA + TBM * BK * 2;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 af[TM], bf[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) af[i] = read_frag<false, TBM>(sA, wm * TM + i, ks, lane);
-#pragma unroll
-                    for (int jj = 0; jj < TN; ++jj) bf[jj] = read_frag<false, TBN>(sB, wn * TN + jj, ks, lane);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int jj = 0; jj < TN; ++jj)
-                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[jj], af[i], acc[i][jj], 0, 0, 0);
-                }
-                if (++st == NSTAGE) st = 0;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                    // B1: every multiplier is out of the ring, the streamers are done with the stash
-            asm volatile("" ::: "memory");
-            if (j + 1 < ntiles) {                            // the next tile's first k-tiles travel while the stash is written
-                cur = wg_decode(w, blockIdx.x + (j + 1) * G);
-                const GroupedWgrad::Item& it = w.g[cur.g];
-                la.init(it.A, it.M, it.K, it.lda, cur.m0, wave, lane);
-                lb.init(it.B, it.N, it.K, it.ldb, cur.n0, wave, lane);
-#pragma unroll
-                for (int a = 0; a < AHEAD; ++a)
-                    if (a < cur.nk) { la.issue(ring + a * STAGE, a, wave); lb.issue(ring + a * STAGE + TBM * BK * 2, a, wave); }
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jj = 0; jj < TN; ++jj) {
-                    const int row = wm * 64 + i * 16 + (lane & 15);
-                    const int blk = (wn * 16 + jj * 4 + (lane >> 4)) ^ (row & 15);
-                    *reinterpret_cast<f32x4*>(stash + row * 512 + blk * 16) = acc[i][jj];
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                    // B2: the stash holds tile j
-        }
-        return;
-    }
-
-    // -------------------------------------------------------------------- streamers
-    const int sw = wave - 4;                                 // rows 2 sw, 2 sw + 1 of every 8-row chunk
-    const int crow = 2 * sw + (lane >> 5), cblk = lane & 31;
-    const AdamWHyper opt = w.opt;
-    // Everything the streamers send to memory is UNCONDITIONAL and goes through buffer resources: a lane outside the tile, a
-    // missing bf16 mirror and "no next tile" are out-of-range offsets / zero-sized resources (loads return 0, stores are
-    // dropped, no traffic).  The instruction stream between a prefetch and its use is then the same on every path, so hipcc's
-    // counted vmcnt waits keep the full D chunks in flight — with conditional stores / fetches it drained the queue at every
-    // tile boundary (ISA: s_waitcnt vmcnt(0) at chunk 0).
-    struct Dst { __amdgpu_buffer_rsrc_t p, m, v, lp; int M, N, ldc, m0, n0; };
-    auto describe = [&](int T_, bool valid) {
-        Dst d;
-        const WgTile t = wg_decode(w, valid ? T_ : (int)blockIdx.x);
-        const GroupedWgrad::Item& it = w.g[t.g];
-        const ptrdiff_t off = it.C - w.gW;
-        const size_t bytes = valid ? (size_t)it.M * it.ldc * 4 : 0;
-        d.p = make_rsrc(w.W + off, bytes); d.m = make_rsrc(w.mW + off, bytes); d.v = make_rsrc(w.vW + off, bytes);
-        const bool has_lp = w.Wlp != nullptr;
-        d.lp = make_rsrc(has_lp ? (const void*)(reinterpret_cast<const bf16_t*>(w.Wlp) + off) : (const void*)w.W, has_lp ? bytes / 2 : 0);
-        d.M = it.M; d.N = it.N; d.ldc = it.ldc; d.m0 = t.m0; d.n0 = t.n0;
-        return d;
-    };
-    auto elem_off = [&](const Dst& d, int c) -> uint32_t {      // element offset of this lane's 4 columns in chunk c, or OOB
-        const int m = d.m0 + 8 * c + crow, n = d.n0 + 4 * cblk;
-        return (m < d.M && n < d.N) ? (uint32_t)m * (uint32_t)d.ldc + (uint32_t)n : 0x1FFFFFFFu;   // x 4 / x 2 stay >= any num_records
-    };
-    u32x4 rp[D], rm[D], rv[D];
-    auto fetch = [&](const Dst& d, int c, int slot) {
-        const uint32_t o = elem_off(d, c) * 4u;
-        rp[slot] = buf_load16(d.p, o); rm[slot] = buf_load16(d.m, o); rv[slot] = buf_load16(d.v, o);
-    };
-    Dst dcur = describe(blockIdx.x, true), dnext = dcur;
-    const u32x4 z4 = {0u, 0u, 0u, 0u};
-    const u32x2 z2 = {0u, 0u};
-#pragma unroll
-    for (int c = 0; c < D; ++c) {                            // p/m/v of the first chunks travel during the first k-loop
-        fetch(dcur, c, c);
-        if (c + 1 < D) {                                     // four dropped stores: the same op count per chunk as the steady state (see above)
-            __builtin_amdgcn_raw_buffer_store_b128(z4, dcur.p, 0x7FFFFFF0u, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(z4, dcur.m, 0x7FFFFFF0u, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(z4, dcur.v, 0x7FFFFFF0u, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(z2, dcur.lp, 0x7FFFFFF0u, 0, 0);
-        }
-    }
-
-    for (int j = 0; j <= ntiles; ++j) {                      // phase j: barriers of tile j's k-loop, chunks of tile j - 1
-        int nk = 0;
-        if (j < ntiles) nk = wg_decode(w, blockIdx.x + j * G).nk;
-        if (j >= 1) dnext = describe(blockIdx.x + j * G, j < ntiles);
-        int bar = 0;
-        if (j >= 1) {
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int step = c * nk / NCH;               // chunk c is processed before the barrier of k-step `step`
-                while (bar < step) { __builtin_amdgcn_s_barrier(); ++bar; }
-                const int slot = c % D;
-                const int row = 8 * c + crow;
-                const f32x4 g = *reinterpret_cast<const f32x4*>(stash + row * 512 + ((cblk ^ (row & 15)) << 4));
-                f32x4 p = __builtin_bit_cast(f32x4, rp[slot]), mm = __builtin_bit_cast(f32x4, rm[slot]), vv = __builtin_bit_cast(f32x4, rv[slot]);
-                adamw_update4(p, g, mm, vv, opt);
-                const uint32_t eo = elem_off(dcur, c);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p), dcur.p, eo * 4u, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mm), dcur.m, eo * 4u, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), dcur.v, eo * 4u, 0, 0);
-                const bf16x4 lp = {(bf16_t)p[0], (bf16_t)p[1], (bf16_t)p[2], (bf16_t)p[3]};
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lp), dcur.lp, eo * 2u, 0, 0);
-                // refill the slot: chunk c + D of this tile, or of the next one (a zero-sized resource after the last tile)
-                if (c + D < NCH) fetch(dcur, c + D, slot);
-                else fetch(dnext, c + D - NCH, slot);
-            }
-        }
-        while (bar < nk) { __builtin_amdgcn_s_barrier(); ++bar; }
-        if (j < ntiles) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's stash reads have returned
-            __builtin_amdgcn_s_barrier();                    // B1
-            __builtin_amdgcn_s_barrier();                    // B2
-            asm volatile("" ::: "memory");
-            dcur = dnext;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // f32 kernel (parity mode).  LDS image is always [k][row] (row fastest); KC operands are
 // transposed by the staging write, RC operands are copied.  BK = 16.
 // ------------------------------------------------------------------------------------------------
@@ -1129,8 +1025,35 @@ static void layout_launch_ks2(const GemmParams& p, int tbm, int tbn, int ring, h
 #undef KS2_T
 }
 
+// staging 8 + ring (10 .. 12): the software-pipelined main loop (gemm_tile_pipe), whole reduction per workgroup
+template <bool AK, bool BKC>
+static bool layout_launch_pipe(const GemmParams& p, int tbm, int tbn, int ring, hipStream_t stream) {
+    const dim3 grid((p.N + tbn - 1) / tbn, (p.M + tbm - 1) / tbm, 1);
+#define PIPE_T(TM_, TN_)                                                                                                                      \
+    do {                                                                                                                                      \
+        if (ring * (TM_ + TN_) * BK * 2 > 160 * 1024) return false;                                                                           \
+        if (ring >= 4) hipLaunchKernelGGL((gemm_bf16_pipe_kernel<AK, BKC, TM_, TN_, (4 * (TM_ + TN_) * BK * 2 <= 160 * 1024 ? 4 : 2)>), grid, dim3(256), 4 * (TM_ + TN_) * BK * 2, stream, p); \
+        else if (ring == 3) hipLaunchKernelGGL((gemm_bf16_pipe_kernel<AK, BKC, TM_, TN_, 3>), grid, dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, p); \
+        else hipLaunchKernelGGL((gemm_bf16_pipe_kernel<AK, BKC, TM_, TN_, 2>), grid, dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, p);            \
+        return true;                                                                                                                          \
+    } while (0)
+    if (tbm == 128 && tbn == 128) PIPE_T(128, 128);
+    else if (tbm == 192 && tbn == 128) PIPE_T(192, 128);
+    else if (tbm == 96 && tbn == 128) PIPE_T(96, 128);
+    else if (tbm == 96 && tbn == 64) PIPE_T(96, 64);
+    else if (tbm == 128 && tbn == 64) PIPE_T(128, 64);
+    else if (tbm == 64 && tbn == 128) PIPE_T(64, 128);
+    else if (tbm == 64 && tbn == 64) PIPE_T(64, 64);
+#undef PIPE_T
+    return false;
+}
+
 template <bool AK, bool BKC>
 static void layout_launch_cfg(const GemmParams& p, int tbm, int tbn, int staging, int split, hipStream_t stream) {
+    if (staging >= 10 && staging <= 12 && split == 1 && !p.slab) {
+        if (layout_launch_pipe<AK, BKC>(p, tbm, tbn, staging - 8, stream)) return;
+        staging -= 8;
+    }
     const dim3 grid((p.N + tbn - 1) / tbn, (p.M + tbm - 1) / tbm, split);
 #define LAUNCH_T(TM_, TN_)                                                                                           \
         do {                                                                                                         \
@@ -1196,37 +1119,7 @@ static void layout_launch_pair(GemmPair& g, int tbm, int tbn, int staging, hipSt
 // grouped weight gradients of one block.  Items are ordered by reduction length, longest first (the key
 // projection reduces over twice as many tokens as the rest: started last, its tiles were the tail of the
 // launch), and the block tile / ring depth are autotuned per group signature like the single GEMMs.
-static int mebt_num_cus() {
-    static const int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
-    return n;
-}
-// stages >= 32: the split-role kernel (wgrad_adamw_kernel, fused optimizer only): ring depth = stages & 3 (2 or 3), p/m/v prefetch
-// depth 8 chunks (32 + ring) or 4 (48 + ring); 128 x 128 tiles, one persistent workgroup per CU, shortest reduction first
-static inline bool grouped_split_ok(const GroupedWgrad& c) {
-    if (!c.fused || c.beta || c.Cb) return false;
-    for (int i = 0; i < c.n; ++i) if (c.g[i].N % 4 || c.g[i].M <= 0 || c.g[i].K <= 0) return false;
-    return true;
-}
-static void layout_launch_grouped_split(GroupedWgrad& c, int stages, hipStream_t stream) {
-    for (int i = 1; i < c.n; ++i)              // insertion sort, K ascending: the first tile's k-loop is the exposed one
-        for (int j = i; j > 0 && c.g[j].K < c.g[j - 1].K; --j) { const GroupedWgrad::Item t = c.g[j]; c.g[j] = c.g[j - 1]; c.g[j - 1] = t; }
-    int tiles = 0;
-    for (int i = 0; i < c.n; ++i) {
-        c.g[i].ntx = (c.g[i].N + 127) / 128;
-        c.tile_start[i] = tiles;
-        tiles += ((c.g[i].M + 127) / 128) * c.g[i].ntx;
-    }
-    for (int i = c.n; i <= MEBT_MAX_GROUP; ++i) c.tile_start[i] = tiles;
-    const int ring = (stages & 3) == 3 ? 3 : 2, deep = stages < 48;
-    const int grid = tiles < mebt_num_cus() ? tiles : mebt_num_cus();
-    const int lds = ring * 256 * BK * 2 + 128 * 128 * 4;
-    if (ring == 3 && deep) hipLaunchKernelGGL((wgrad_adamw_kernel<3, 8>), dim3(grid), dim3(512), lds, stream, c);
-    else if (ring == 3) hipLaunchKernelGGL((wgrad_adamw_kernel<3, 4>), dim3(grid), dim3(512), lds, stream, c);
-    else if (deep) hipLaunchKernelGGL((wgrad_adamw_kernel<2, 8>), dim3(grid), dim3(512), lds, stream, c);
-    else hipLaunchKernelGGL((wgrad_adamw_kernel<2, 4>), dim3(grid), dim3(512), lds, stream, c);
-}
 static void layout_launch_grouped(GroupedWgrad& c, int tbm, int tbn, int stages, hipStream_t stream) {
-    if (stages >= 32) { layout_launch_grouped_split(c, stages, stream); return; }
     for (int i = 1; i < c.n; ++i)              // insertion sort, K descending (longest reduction first: its tiles are not the tail)
         for (int j = i; j > 0 && c.g[j].K > c.g[j - 1].K; --j) { const GroupedWgrad::Item t = c.g[j]; c.g[j] = c.g[j - 1]; c.g[j - 1] = t; }
     int tiles = 0;
@@ -1279,6 +1172,14 @@ static int layout_set_attrs() {
         if (ks2_lds(TM_, TN_, 3)) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_ks2_kernel<AK, BKC, TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ks2_lds(TM_, TN_, 3))); \
     } while (0)
     SET_T(128, 128); SET_T(128, 64); SET_T(64, 128); SET_T(64, 64); SET_D(192, 128); SET_D(96, 128); SET_D(96, 64);
+#define SET_PIPE(TM_, TN_)                                                                                                       \
+    do {                                                                                                                         \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pipe_kernel<AK, BKC, TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2)); \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pipe_kernel<AK, BKC, TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM_ + TN_) * BK * 2)); \
+        if (4 * (TM_ + TN_) * BK * 2 <= 160 * 1024) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pipe_kernel<AK, BKC, TM_, TN_, (4 * (TM_ + TN_) * BK * 2 <= 160 * 1024 ? 4 : 2)>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (TM_ + TN_) * BK * 2)); \
+    } while (0)
+    SET_PIPE(128, 128); SET_PIPE(192, 128); SET_PIPE(96, 128); SET_PIPE(96, 64); SET_PIPE(128, 64); SET_PIPE(64, 128); SET_PIPE(64, 64);
+#undef SET_PIPE
     MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w8_kernel<AK, BKC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * BK * 2));
     SET_K(96, 64); SET_K(64, 64); SET_K(96, 128); SET_K(64, 128); SET_K(128, 64);
 #undef SET_K
@@ -1307,9 +1208,5 @@ static int layout_set_grouped_attrs() {
     } while (0)
     SET_G(128, 128); SET_G(128, 64); SET_G(64, 128); SET_G(64, 64);
 #undef SET_G
-    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_adamw_kernel<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 256 * BK * 2 + 65536));
-    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_adamw_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 256 * BK * 2 + 65536));
-    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_adamw_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * BK * 2 + 65536));
-    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_adamw_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * BK * 2 + 65536));
     return MEBT_OK;
 }

@@ -245,43 +245,6 @@ def test_trainloop_fused_optimizer(name):
         assert d <= 1e-6 * max(1.0, a.abs().max().item()), (what, d)
 
 
-@pytest.mark.parametrize("code", [34, 35, 50, 51])
-@pytest.mark.parametrize("name", ["micro", "c1"])
-def test_split_role_wgrad_adamw_kernel(name, code):
-    """`wgrad_adamw_kernel` (multiplier waves + AdamW streamer waves in one persistent workgroup per CU), forced through
-    `mebt_debug_grouped_stages(32 + ring [+ 16])` with the tuner off: three fused bf16 steps give the same parameters, moments
-    and bf16 mirror as the separate optimizer — ragged tiles (micro: 64-wide weights under 128 x 128 tiles), NC = 0 steps and
-    all four (ring depth, prefetch depth) instantiations."""
-    from mebt_amd.trainer import TrainLoop
-    from mebt_amd import _lib
-    lib = _lib.load()
-    finals = []
-    try:
-        for fused in (False, True):
-            lib.mebt_gemm_autotune(0)
-            lib.mebt_debug_grouped_stages(code if fused else 2)
-            model = build_product(name, "bf16").train()
-            model.learning_rate, model.weight_decay, model.warmup_steps, model.cosine_lr = 1e-3, 0.01, 0, False
-            shape = tuple(model.mask_sampler.shape)
-            N = shape[0] * shape[1] * shape[2]
-            gen = torch.Generator().manual_seed(7)
-            loop = TrainLoop(model, fused_optimizer=fused)
-            assert loop.fused_optimizer == fused
-            for t in (0.4, 0.75, 0.0, 0.2):                        # t = 0: NC = 0 (empty key-side reductions)
-                x = torch.randint(0, 16384, (3, *shape), generator=gen).to(DEV)
-                idx = torch.stack([torch.randperm(N, generator=gen) for _ in range(3)]).to(DEV)
-                loop.step(x, idx, t=t)
-            nm = loop.native
-            torch.cuda.synchronize()
-            finals.append([nm.W.clone(), nm.P.clone(), nm.Wlp.clone().float(), nm.adam[0].clone(), nm.adam[1].clone()])
-    finally:
-        lib.mebt_debug_grouped_stages(2)
-        lib.mebt_gemm_autotune(1)
-    for a, b, what in zip(finals[0], finals[1], ("W", "P", "bf16 mirror", "exp_avg", "exp_avg_sq")):
-        d = (a - b).abs().max().item()
-        assert d <= 1e-6 * max(1.0, a.abs().max().item()), (what, d)
-
-
 def test_launcher_trains_from_token_file(tmp_path):
     """`python -m mebt_amd.train` (counterpart of train_transformer.py) on a token file in the reference's vtokens
     container layout: runs, logs finite losses, writes a Lightning-layout checkpoint that loads back."""
