@@ -8,7 +8,10 @@ from mebt_amd.vqgan import VQGAN, load_vqgan  # noqa: F401
 from mebt_amd.data import TokenData as VideoData  # noqa: F401  (the `vtokens` token-grid contract of reference data.py:236-305)
 
 
-def load_transformer(ckpt_path, device=None):
-    """counterpart of reference mebt/download.py:56-61: load a Lightning-format checkpoint, eval mode"""
-    model = Net2NetTransformer.load_from_checkpoint(ckpt_path).eval()
+def load_transformer(gpt_ckpt, vqgan_ckpt=None, device=None):
+    """reference mebt/download.py:56-61, same signature (`load_transformer(args.gpt_ckpt, vqgan_ckpt=None)` at
+    draft_and_revise_videos.py:138 / sample_vqgan_transformer_videos.py:218): load a Lightning-format checkpoint, eval mode.
+    The reference ignores `vqgan_ckpt` (the first stage comes from the checkpoint's own config) and leaves the model on the CPU;
+    `device`, when given, is honoured here."""
+    model = Net2NetTransformer.load_from_checkpoint(gpt_ckpt).eval()
     return model.to(device) if device is not None else model

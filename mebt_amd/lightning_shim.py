@@ -3,8 +3,109 @@ pl.LightningModule (mebt/transformer.py:60).  This base class provides the handf
 hot path touches (save_hyperparameters :146, log :679,736-745, global_step :231,244,
 current_epoch :334, device :341, trainer.global_step/max_steps :666-672) so that the launcher in
 mebt_amd/train.py — and a real Lightning Trainer, if one is installed — can drive the module."""
+import pickle
+import types
+
 import torch
 import torch.nn as nn
+
+
+# ---- reading the reference's real checkpoints -----------------------------------------------------------------------------
+# train_transformer.py:27-33 builds the model from OmegaConf nodes and `save_hyperparameters()` (transformer.py:146) pickles them
+# into the checkpoint: `hyper_parameters` = {'transformer_config': DictConfig, 'first_stage_config': DictConfig, 'mask_config':
+# DictConfig, ...}, possibly wrapped in pytorch_lightning's AttributeDict.  Neither package is installed on the target image, and
+# a checkpoint must not need them: the unpickler below stands in for every class of `omegaconf.*` / `pytorch_lightning.*` /
+# `lightning*` with an inert record of the pickled state, and `plain()` rebuilds ordinary containers from OmegaConf's layout
+# (a container keeps its children in `_content`: a dict / list of nodes; a value node keeps its value in `_val`).  Everything
+# else a checkpoint may name is allow-listed (torch, numpy array reconstruction, collections, typing, argparse.Namespace,
+# builtins); any other global is refused instead of imported.
+class _Record:
+    """inert stand-in for an instance of a class that is not installed: keeps the pickled state, runs no code of that class"""
+
+    def __new__(cls, *args, **kwargs):
+        o = object.__new__(cls)
+        o.__dict__["_args"] = args
+        return o
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple) and len(state) == 2 and isinstance(state[1], dict):    # (dict state, slots state)
+            state = {**(state[0] or {}), **state[1]}
+        self.__dict__["_state"] = state
+
+    def __call__(self, *args, **kwargs):           # enum-style `Class(value)` reconstruction
+        return self
+
+
+class _RecordDict(dict):
+    """the same for dict subclasses (pytorch_lightning.utilities.parsing.AttributeDict, omegaconf's OrderedDict-like helpers)"""
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.update(state)
+
+
+_STANDIN_PREFIXES = ("omegaconf", "pytorch_lightning", "lightning", "lightning_fabric")
+_DICT_LIKE = {"AttributeDict"}
+_ALLOWED_MODULES = ("torch", "numpy", "collections", "typing", "argparse", "builtins", "copyreg", "_codecs", "functools", "pathlib", "enum",
+                    "mebt_amd", "mebt", "__builtin__", "copy_reg")     # the last two: protocol-2 spellings (torch.save), mapped by pickle itself
+
+
+def _standin_class(module, name):
+    base = _RecordDict if name in _DICT_LIKE else _Record
+    return type(name, (base,), {"__module__": module, "_standin_for": f"{module}.{name}"})
+
+
+class TolerantUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        root = module.split(".", 1)[0]
+        if root in _STANDIN_PREFIXES:
+            return _standin_class(module, name)
+        if root in _ALLOWED_MODULES:
+            if root in ("builtins", "__builtin__") and name in ("eval", "exec", "compile", "open", "__import__", "getattr", "setattr", "delattr", "input"):
+                raise pickle.UnpicklingError(f"checkpoint names builtins.{name}: refused")
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"checkpoint names {module}.{name}, which is outside what a MeBT checkpoint may contain "
+                                     "(torch / numpy / stdlib containers; omegaconf and pytorch_lightning classes are read through stand-ins)")
+
+
+_tolerant_pickle = types.SimpleNamespace(__name__="pickle", Unpickler=TolerantUnpickler, load=lambda f, **kw: TolerantUnpickler(f, **kw).load(),
+                                         loads=pickle.loads, dump=pickle.dump, dumps=pickle.dumps, HIGHEST_PROTOCOL=pickle.HIGHEST_PROTOCOL,
+                                         UnpicklingError=pickle.UnpicklingError, PicklingError=pickle.PicklingError)
+
+
+def plain(v, _seen=None):
+    """OmegaConf / Lightning stand-ins (and anything dict- or list-like) -> plain dict / list / scalar, recursively"""
+    if isinstance(v, _Record):
+        st = v.__dict__.get("_state") or {}
+        if isinstance(st, dict) and "_content" in st:              # DictConfig / ListConfig
+            c = st["_content"]
+            if isinstance(c, dict):
+                return {plain(k): plain(x) for k, x in c.items()}
+            if isinstance(c, (list, tuple)):
+                return [plain(x) for x in c]
+            return plain(c)                                        # a None / missing / interpolation string container
+        if isinstance(st, dict) and "_val" in st:                  # AnyNode / StringNode / IntegerNode / FloatNode / BooleanNode / EnumNode
+            return plain(st["_val"])
+        a = v.__dict__.get("_args") or ()
+        return plain(a[0]) if len(a) == 1 else None                # an enum member or an opaque helper: its value, or nothing
+    if isinstance(v, dict):
+        return {plain(k): plain(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)) and not isinstance(v, str):
+        return [plain(x) for x in v]
+    if hasattr(v, "__dict__") and type(v).__name__ == "Namespace":      # argparse.Namespace hyper-parameters
+        return {k: plain(x) for k, x in vars(v).items()}
+    return v
+
+
+def load_checkpoint_file(path, map_location="cpu"):
+    """torch.load of a Lightning checkpoint that may pickle OmegaConf / Lightning objects, without those packages"""
+    ckpt = torch.load(path, map_location=map_location, weights_only=False, pickle_module=_tolerant_pickle)
+    if "hyper_parameters" in ckpt:
+        ckpt["hyper_parameters"] = plain(ckpt["hyper_parameters"])
+    return ckpt
 
 
 class _TrainerState:
@@ -38,15 +139,11 @@ class LightningModuleShim(nn.Module):
     def load_from_checkpoint(cls, path, map_location="cpu", strict=False, **overrides):
         """Lightning checkpoint format (download.py:56-61): {'state_dict', 'hyper_parameters', 'global_step', 'epoch',
         'pytorch-lightning_version', ...}.  `hyper_parameters` holds the constructor arguments `save_hyperparameters()`
-        recorded (transformer.py:146): config nodes arrive as plain nested dicts (or anything dict-like) and are wrapped
-        into attribute-access configs; Lightning's bookkeeping keys are ignored.  A checkpoint that pickles OmegaConf
-        objects needs `omegaconf` importable to be unpickled at all — that failure is reported as such."""
+        recorded (transformer.py:146): config nodes arrive as plain nested dicts OR as the OmegaConf DictConfig / ListConfig
+        objects the reference's launcher pickles (read without omegaconf / pytorch_lightning installed: load_checkpoint_file)
+        and are wrapped into attribute-access configs; Lightning's bookkeeping keys are ignored."""
         from .config import AttrDict
-        try:
-            ckpt = torch.load(path, map_location=map_location, weights_only=False)
-        except ModuleNotFoundError as e:
-            raise RuntimeError(f"{path} pickles objects of the module '{e.name}', which is not installed here: install it, or "
-                               "re-save the checkpoint with `hyper_parameters` as plain nested dicts") from e
+        ckpt = load_checkpoint_file(path, map_location=map_location)
 
         def wrap(v):
             if isinstance(v, AttrDict):

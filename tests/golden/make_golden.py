@@ -117,6 +117,15 @@ class ClosedFormRNG:
         return torch.from_numpy(cf.permutation("noise", n, stream=k))
 
 
+_REAL_RNG = (torch.Tensor.exponential_, torch.randn_like, torch.randperm)
+
+
+def unpatch_rng():
+    """torch's own generators again (the data-contract fixture draws from the seeded global torch RNG, as the reference's
+    dataset does: its values depend on torch.randperm being the real one)"""
+    torch.Tensor.exponential_, torch.randn_like, torch.randperm = _REAL_RNG
+
+
 def patch_rng(rng):
     torch.Tensor.exponential_ = lambda self, *a, **k: rng.exponential_(self)
     torch.randn_like = lambda t, *a, **k: rng.randn_like(t)
@@ -171,7 +180,8 @@ def oracle_cfg(name, schedule="linear"):
                             avg_loss=1.0, label_smoothing=c.get("label_smoothing", 0.0))
 
 
-def build_reference(name, schedule="linear"):
+def build_reference(name, schedule="linear", **overrides):
+    """`overrides`: extra / replaced keys of the transformer config node (beta_params, beta_iter, t_prior ...)"""
     from mebt.transformer import Net2NetTransformer
     c = CONFIGS[name]
     tcfg = Cfg(unconditional=True, vocab_size=16384, first_stage_vocab_size=16384,
@@ -182,6 +192,7 @@ def build_reference(name, schedule="linear"):
                mode=list(c["mode"]), class_cond_dim=None)
     if "label_smoothing" in c:
         tcfg["label_smoothing"] = c["label_smoothing"]
+    tcfg.update(overrides)
     mcfg = Cfg(target="mebt.mask_sampler.MaskGen",
                params=Cfg(iid=False, schedule=schedule, max_token=c["block_size"], method="mlm",
                           shape=c["shape"], t_range=[0.0, 1.0], budget=c["budget"]))
@@ -217,7 +228,7 @@ def save(name, **arrays):
     out = {}
     for k, v in arrays.items():
         out[k] = v.numpy() if torch.is_tensor(v) else np.asarray(v)
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(os.environ.get("MEBT_GOLDEN_OUT", HERE), name + ".npz")      # MEBT_GOLDEN_OUT: regenerate elsewhere (tests)
     np.savez_compressed(path, **out)
     print(f"wrote {path}  ({os.path.getsize(path)/1024:.1f} KiB)")
 
@@ -483,7 +494,8 @@ def gen_data_contract():
     """Items of the reference's HDF5Dataset_vtokens (mebt/data.py:330-414) on a small synthetic token file.  h5py is not
     installed here: `h5py.File` is stubbed by an npz reader (a container stub, the dataset logic is the reference's)."""
     import importlib
-    tmp = os.path.join(HERE, "_tokens_tmp.npz")
+    unpatch_rng()
+    tmp = os.path.join(os.environ.get("MEBT_GOLDEN_OUT", HERE), "_tokens_tmp.npz")
     rs = np.random.RandomState(7)
     lens = [9, 3, 12, 5, 20, 4, 7]                       # frames per video; sequence_length 4 -> videos 1 and 5 are too short
     idx = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
@@ -500,6 +512,8 @@ def gen_data_contract():
     sys.modules["torchvision.datasets.video_utils"].VideoClips = object
     if not hasattr(sys.modules["pytorch_lightning"], "LightningDataModule"):
         sys.modules["pytorch_lightning"].LightningDataModule = object
+    if not getattr(sys.modules.get("mebt.data"), "__file__", None):     # gen_script_drivers' import-time stub: drop it, import the real one
+        sys.modules.pop("mebt.data", None)
     try:
         data_mod = importlib.import_module("mebt.data")
     except Exception as e:                                 # heavy optional imports of the module: stub what is missing, once more
@@ -608,6 +622,131 @@ def gen_vqgan():
              dec_ids=dec_ids, rec_idx=vi, rec_vals=rec.reshape(-1)[vi], rec_mean=rec.mean(dim=(0, 1, 3, 4)), rec_sq=(rec ** 2).mean(dim=(0, 1, 3, 4)))
 
 
+def gen_edit_beta_window():
+    """Branches of the hot path the first fixtures did not reach: `edit=True` in sample / draft_and_revise
+    (transformer.py:373-376,399,658-660), the beta(t) schedule of the training `t` (:113-119,229-241), the video-length
+    priors (:24-49) and a WINDOWED train step — divide_indices slicing a temporal window (mask_sampler.py:83-99), so that
+    seq_len < N — on the C1 config.  Library RNG draws are forced AND recorded: the arguments the reference hands to
+    Beta(alpha, beta), np.random.choice(vid_t, p=prior) and np.random.randint are part of the fixture."""
+    out = {}
+    # ---- edit=True: sample() continuing from index sets, schedule counted on the edited tokens only
+    model, _ = build_reference("micro", schedule="cosine")
+    model.eval()
+    rng = ClosedFormRNG()
+    patch_rng(rng)
+    x0, idx = inputs("micro", 2, "edit")
+    with torch.no_grad():
+        xs, ci, ti = model.sample(x0, None, 1.0, None, None, 5, idx[:, :12], idx[:, 12:], context_temperature=3.0, skips=False, edit=True)
+    out["edit_x0"], out["edit_idx"], out["edit_x"], out["edit_ci"], out["edit_ti"] = x0, idx, xs, ci, ti
+    out["edit_ndraws"] = np.array(rng.k)
+    # ---- edit=True: draft_and_revise with caller-given index sets for the draft, full revise afterwards
+    model, _ = build_reference("micro")
+    model.eval()
+    rng = ClosedFormRNG()
+    patch_rng(rng)
+    x0, idx = inputs("micro", 2, "edit-dnr")
+    with torch.no_grad():
+        xs = model.draft_and_revise(x0, None, 4, 1.0, None, None, 4, 0.7, None, None, 2, False, False, idx[:, :16], idx[:, 16:], True)
+    out["edit_dnr_x0"], out["edit_dnr_idx"], out["edit_dnr_x"] = x0, idx, xs
+    out["edit_dnr_ndraws"] = np.array(rng.k)
+
+    # ---- video-length priors at a few global steps (pure numpy, transformer.py:24-49)
+    import mebt.transformer as rt
+    steps = np.array([0, 1, 15000, 30000, 45000, 90000, 250000])
+    lengths = np.arange(4) + 1
+    for name in ("uniform", "gaussian2", "gaussian100000_2", "longest"):
+        out["prior_" + name] = np.stack([getattr(rt, name)(lengths, int(s)) for s in steps])
+    out["prior_steps"], out["prior_lengths"] = steps, lengths
+
+    # ---- beta(t): what the reference hands to Beta() at given global steps, and a train-mode forward with the drawn t forced
+    import torch.distributions.beta as tdb
+    model, ocfg = build_reference("micro", beta_params=[3.0, 9.0], beta_iter=1000)
+    model.train()
+    calls = []
+    forced = [0.35, 0.62, 0.18, 0.5, 0.77]
+    real_beta = tdb.Beta
+
+    class FakeBeta:
+        def __init__(self, a, b):
+            calls.append((float(a), float(b)))
+
+        def sample(self):
+            return torch.tensor(forced[len(calls) - 1])
+    tdb.Beta = FakeBeta
+    torch.distributions.beta.Beta = FakeBeta
+    try:
+        gsteps = [0, 250, 500, 1000, 1001]
+        losses = []
+        for s, gs in enumerate(gsteps):
+            model.global_step = gs
+            x, idx = inputs("micro", 2, f"beta{s}")
+            out[f"beta{s}_x"], out[f"beta{s}_indices"] = x, idx
+            with torch.no_grad():
+                acc1, acc5, loss, ratio = model.shared_step({"video": x, "label": x, "indices": idx}, 0)
+            losses.append([float(loss), float(acc1), float(acc5), float(ratio)])
+    finally:
+        tdb.Beta = real_beta
+        torch.distributions.beta.Beta = real_beta
+    out["beta_params"], out["beta_iter"] = np.array([3.0, 9.0]), np.array(1000.0)
+    out["beta_gsteps"], out["beta_calls"], out["beta_forced_t"], out["beta_meta"] = np.array(gsteps), np.array(calls), np.array(forced), np.array(losses)
+    save("edit_beta_priors", **out)
+
+    # ---- windowed train step on C1 (t_prior = gaussian2): one optimizer step with T = 1 of 2 latent frames, start frame 1
+    out = {}
+    model, ocfg = build_reference("c1", t_prior="gaussian2")
+    model.train()
+    model.learning_rate, model.weight_decay = 1e-3, 0.05
+    model.global_step = 12345
+    opt = model.configure_optimizers()
+    rec = {}
+    real_choice, real_randint = np.random.choice, np.random.randint
+
+    def fake_choice(a, p=None, **kw):
+        rec["choice_a"], rec["choice_p"] = np.asarray(a).copy(), np.asarray(p).copy()
+        return 1
+    def fake_randint(lo, hi=None, **kw):
+        rec["randint"] = (lo, hi)
+        return 1
+    np.random.choice, np.random.randint = fake_choice, fake_randint
+    try:
+        x, idx = inputs("c1", 3, "window")
+        opt.zero_grad()
+        acc1, acc5, loss, ratio = _shared_step_with_t(model, x, idx, 0.4)
+        loss.backward()
+    finally:
+        np.random.choice, np.random.randint = real_choice, real_randint
+    names = sorted(orc.param_shapes(ocfg).keys())
+    sd = dict(model.named_parameters())
+    probe = cf.permutation("train-probe", 4096)[:16]
+    out["x"], out["indices"], out["t"], out["global_step"] = x, idx, np.array(0.4), np.array(12345)
+    out["choice_a"], out["choice_p"], out["randint"] = rec["choice_a"], rec["choice_p"], np.array(rec["randint"])
+    out["meta"] = np.array([float(loss), float(acc1), float(acc5), float(ratio)])
+    out["gradnorm"] = np.array([float(sd[n].grad.double().norm()) if sd[n].grad is not None else 0.0 for n in names])
+    out["gprobe"] = np.stack([(sd[n].grad if sd[n].grad is not None else torch.zeros_like(sd[n])).reshape(-1)[probe % sd[n].numel()].numpy() for n in names])
+    opt.step()
+    out["pnorm"] = np.array([float(sd[n].detach().double().norm()) for n in names])
+    out["pprobe"] = np.stack([sd[n].detach().reshape(-1)[probe % sd[n].numel()].numpy() for n in names])
+    out["names"], out["probe"] = np.array(names), probe
+    save("train_window_c1", **out)
+
+
+def gen_utils():
+    """mebt/utils.py helpers on the path: shift_dim (:30-53; used by the VQGAN and the sampling scripts) and accuracy (:80-94)."""
+    import mebt.utils as mu
+    out = {}
+    x = torch.from_numpy(cf.pseudo_normal("utils/x", (2, 3, 4, 5, 6), std=1.0))
+    cases = [(1, -1), (-1, 1), (0, 2), (3, 1), (2, 2)]
+    out["x"], out["shift_cases"] = x, np.array(cases)
+    for i, (a, b) in enumerate(cases):
+        out[f"shift{i}"] = mu.shift_dim(x, a, b).contiguous()
+    logits = torch.from_numpy(cf.pseudo_normal("utils/logits", (64, 50), std=2.0))
+    target = torch.from_numpy(cf.randint("utils/target", (64,), 50))
+    out["acc_logits"], out["acc_target"] = logits, target
+    a1, a5 = mu.accuracy(logits, target, topk=(1, 5))
+    out["acc"] = np.array([float(a1), float(a5)])
+    save("utils", **out)
+
+
 def _shared_step_with_t(model, x, idx, t):
     """shared_step (:717-732) with the python RNG draw `t` (:228) forced."""
     orig = random.random
@@ -618,19 +757,20 @@ def _shared_step_with_t(model, x, idx, t):
         random.random = orig
 
 
-def main():
+GENERATORS = ["gen_forward", "gen_hidden", "gen_divide", "gen_sampler_ops", "gen_sample_loops", "gen_train", "gen_edit_beta_window", "gen_utils",
+              "gen_script_drivers", "gen_data_contract", "gen_vqgan"]
+
+
+def main(only=None):
+    """python tests/golden/make_golden.py [gen_name ...]  — all generators run in ONE process, in this order (the later ones
+    register import-time stand-ins for optional third-party modules that the earlier ones must not see)."""
     install_stubs()
     torch.manual_seed(0)
-    gen_forward()
-    gen_hidden()
-    gen_divide()
-    gen_sampler_ops()
-    gen_sample_loops()
-    gen_train()
-    gen_script_drivers()
-    gen_data_contract()
-    gen_vqgan()
+    for g in GENERATORS:
+        if only and g not in only:
+            continue
+        globals()[g]()
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:] or None)

@@ -36,8 +36,9 @@ def build_native(cfg, dtype, P=None, device="cuda"):
     return nm
 
 
-def product_config(name, schedule="linear", vtokens=True):
-    """Config objects for the shipped Net2NetTransformer equal to make_golden.build_reference's."""
+def product_config(name, schedule="linear", vtokens=True, **overrides):
+    """Config objects for the shipped Net2NetTransformer equal to make_golden.build_reference's (`overrides`: extra keys of
+    the transformer node, as there)."""
     from mebt_amd.config import AttrDict
     from tests.golden import make_golden as mg
     c = mg.CONFIGS[name]
@@ -48,18 +49,19 @@ def product_config(name, schedule="linear", vtokens=True):
                     avg_loss=True, mode=list(c["mode"]), class_cond_dim=None)
     if "label_smoothing" in c:
         tcfg["label_smoothing"] = c["label_smoothing"]
+    tcfg.update(overrides)
     mcfg = AttrDict(target="mebt.mask_sampler.MaskGen",
                     params=AttrDict(iid=False, schedule=schedule, max_token=c["block_size"], method="mlm",
                                     shape=c["shape"], t_range=[0.0, 1.0], budget=c["budget"]))
     return tcfg, AttrDict(params=AttrDict(ckpt_path=None)), mcfg
 
 
-def build_product(name, dtype, schedule="linear", device="cuda"):
+def build_product(name, dtype, schedule="linear", device="cuda", **overrides):
     """The shipped module (mebt.transformer.Net2NetTransformer) with the closed-form weights."""
     from mebt.transformer import Net2NetTransformer
     from oracle import closed_form as cf
     from tests.golden import make_golden as mg
-    tcfg, vcfg, mcfg = product_config(name, schedule)
+    tcfg, vcfg, mcfg = product_config(name, schedule, **overrides)
     model = Net2NetTransformer(tcfg, vcfg, mcfg, cond_stage_key="label")
     model.compute_dtype = dtype
     sd = {k: torch.from_numpy(v) for k, v in cf.state_dict_numpy(orc.param_shapes(mg.oracle_cfg(name, schedule))).items()}

@@ -13,6 +13,8 @@ from oracle import mebt_oracle as orc
 from tests.golden import make_golden as mg
 from tests.helpers import load_golden, product_config
 
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -407,6 +409,57 @@ def test_load_from_lightning_format_checkpoint(tmp_path):
     assert m2.global_step == 7 and all(torch.equal(m2.state_dict()[k], v) for k, v in sd.items())
 
 
+@pytest.mark.parametrize("flavour", ["plain", "attributedict"])
+def test_load_reference_checkpoint_with_omegaconf_hparams(tmp_path, flavour):
+    """a checkpoint as the REFERENCE's run writes it — `hyper_parameters` pickles OmegaConf DictConfig / ListConfig
+    nodes (train_transformer.py:27-33, transformer.py:146), here produced by tests/golden/make_lightning_ckpt.py with stand-in
+    classes under the real module / class names and OmegaConf's pickle layout.  It loads with NEITHER omegaconf NOR
+    pytorch_lightning importable, through `mebt.load_transformer(gpt_ckpt, vqgan_ckpt=None)` exactly as
+    draft_and_revise_videos.py:138 calls it, and a file naming any other foreign class is refused."""
+    import pickle
+    import torch
+    from oracle import closed_form as cf
+    from tests.golden import make_lightning_ckpt as mk
+    cfg = mg.oracle_cfg("micro")
+    sd = {k: torch.from_numpy(v) for k, v in cf.state_dict_numpy(orc.param_shapes(cfg)).items()}
+    c = mg.CONFIGS["micro"]
+    hp = {"transformer_config": {"unconditional": True, "vocab_size": 16384, "first_stage_vocab_size": 16384, "block_size": c["block_size"],
+                                 "n_layer": c["n_layer"], "n_head": c["n_head"], "n_embd": c["n_embd"], "n_unmasked": 0, "embd_pdrop": 0.0,
+                                 "resid_pdrop": 0.1, "attn_pdrop": 0.0, "sample_every_n_latent_frames": 0, "first_stage_key": "video",
+                                 "cond_stage_key": "label", "vtokens": True, "vtokens_pos": False, "vis_epoch": 100, "sos_emb": c["sos_emb"],
+                                 "avg_loss": True, "mode": list(c["mode"]), "class_cond_dim": None, "t_prior": "gaussian2"},
+          "first_stage_config": {"params": {"ckpt_path": None, "ignore_keys": ["loss"]}},
+          "mask_config": {"target": "mebt.mask_sampler.MaskGen",
+                          "params": {"iid": False, "schedule": "linear", "max_token": c["block_size"], "method": "mlm", "shape": list(c["shape"]),
+                                     "t_range": [0.0, 1.0], "budget": c["budget"]}},
+          "ckpt_path": None, "ignore_keys": [], "first_stage_key": "video", "cond_stage_key": "label", "pkeep": 1.0, "sos_token": 0}
+    path = mk.write(str(tmp_path / "epoch=11-step=50000.ckpt"), sd, hp, flavour)
+    assert "omegaconf" not in sys.modules and "pytorch_lightning" not in sys.modules
+    with pytest.raises(ModuleNotFoundError):                     # the file really does name those classes
+        torch.load(path, map_location="cpu", weights_only=False)
+    import mebt
+    from mebt.download import load_transformer
+    assert load_transformer is mebt.load_transformer
+    m = load_transformer(path, vqgan_ckpt=None)
+    assert not m.training and m.global_step == 50000 and m.current_epoch == 11
+    assert [b.mode for b in m.transformer.blocks] == list(c["mode"]) and m.config.resid_pdrop == 0.1 and m.config.t_prior == "gaussian2"
+    assert list(m.mask_sampler.shape) == list(c["shape"]) and m.mask_sampler.budget == c["budget"] and m.hparams["pkeep"] == 1.0
+    assert type(m.config.mode) is list and type(m.config.n_layer) is int and m.config.class_cond_dim is None
+    got = m.state_dict()
+    assert set(got) == set(sd) and all(torch.equal(got[k], v) for k, v in sd.items())
+    # what our launcher re-saves is plain containers: loads back the ordinary way too
+    torch.save({"state_dict": m.state_dict(), "hyper_parameters": m.hparams, "global_step": 3}, str(tmp_path / "resaved.ckpt"))
+    assert mebt.load_transformer(str(tmp_path / "resaved.ckpt"), None, torch.device("cpu")).global_step == 3
+
+    class Evil:                                                   # any other foreign global is refused, not imported
+        def __reduce__(self):
+            return (os.system, ("true",))
+    bad = str(tmp_path / "bad.ckpt")
+    torch.save({"state_dict": {}, "hyper_parameters": {"x": Evil()}}, bad)
+    with pytest.raises(pickle.UnpicklingError):
+        mebt.load_transformer(bad)
+
+
 def test_bench_parent_starts_ranks_as_a_child_and_never_touches_the_gpu(tmp_path):
     """`bench.py --gpus N` / `python -m mebt_amd.train --gpus 0,1` without a torch.distributed environment re-launch themselves
     through mebt_amd/launch.py: child process (never exec), stdout relayed, the child's return code, and the parent's
@@ -435,3 +488,76 @@ def test_bench_parent_starts_ranks_as_a_child_and_never_touches_the_gpu(tmp_path
     finally:
         del os.environ["WORLD_SIZE"], os.environ["RANK"]
     assert launch.spawn_ranks_if_needed(1, "bench.py", []) is None
+
+
+def test_t_priors_and_beta_schedule_match_reference_golden():
+    """Host logic of the training-time draws: the video-length priors (reference transformer.py:24-49) at several global
+    steps, and the (alpha, beta) the beta(t) schedule hands to torch's Beta at given global steps (:229-241) — values
+    recorded from the imported reference (tests/golden/edit_beta_priors.npz)."""
+    import torch.distributions.beta as tdb
+    from mebt_amd import transformer as T
+    from tests.helpers import product_config
+    from mebt.transformer import Net2NetTransformer
+    g = np.load(os.path.join(G, "edit_beta_priors.npz"))
+    for name in ("uniform", "gaussian2", "gaussian100000_2", "longest"):
+        got = np.stack([T.T_PRIORS[name](g["prior_lengths"], int(s)) for s in g["prior_steps"]])
+        np.testing.assert_allclose(got, g["prior_" + name], rtol=1e-12, atol=0)
+    tcfg, vcfg, mcfg = product_config("micro", beta_params=[3.0, 9.0], beta_iter=1000)
+    model = Net2NetTransformer(tcfg, vcfg, mcfg, cond_stage_key="label").train()
+    assert model.beta and model.beta_iter == 1000.0
+    calls, forced = [], list(g["beta_forced_t"])
+
+    class FakeBeta:
+        def __init__(self, a, b):
+            calls.append((float(a), float(b)))
+
+        def sample(self):
+            return torch.tensor(forced[len(calls) - 1])
+    real = tdb.Beta
+    tdb.Beta = torch.distributions.beta.Beta = FakeBeta
+    try:
+        ts = []
+        for gs in g["beta_gsteps"]:
+            model.global_step = int(gs)
+            ts.append(model._draw_t(False))
+    finally:
+        tdb.Beta = torch.distributions.beta.Beta = real
+    np.testing.assert_allclose(np.array(calls), g["beta_calls"], rtol=0, atol=0)
+    np.testing.assert_allclose(np.array(ts), g["beta_forced_t"], rtol=1e-7)
+    # eval mode never uses the schedule (:240-241): a python-RNG draw
+    model.eval()
+    assert 0.0 <= model._draw_t(False) < 1.0 and len(calls) == len(g["beta_gsteps"])
+
+
+def test_mebt_utils_alias_matches_reference_golden():
+    """`mebt.utils.shift_dim` / `accuracy` (reference mebt/utils.py:30-53,80-94) under the reference's import
+    path, against values from the imported reference."""
+    import mebt.utils as mu
+    g = np.load(os.path.join(G, "utils.npz"))
+    x = torch.from_numpy(g["x"])
+    for i, (a, b) in enumerate(g["shift_cases"]):
+        y = mu.shift_dim(x, int(a), int(b))
+        assert tuple(y.shape) == tuple(g[f"shift{i}"].shape) and torch.equal(y.contiguous(), torch.from_numpy(g[f"shift{i}"]))
+    a1, a5 = mu.accuracy(torch.from_numpy(g["acc_logits"]), torch.from_numpy(g["acc_target"]), topk=(1, 5))
+    np.testing.assert_allclose([float(a1), float(a5)], g["acc"], rtol=1e-6)
+    import utils as top                                     # the top-level `utils.instantiate_from_config` of the YAML `target:` strings
+    assert callable(top.instantiate_from_config)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/mebt"), reason="needs the reference checkout (build container only)")
+def test_golden_fixtures_regenerate_bit_identically(tmp_path):
+    """`python tests/golden/make_golden.py` as committed — ONE process, every generator — reproduces every
+    committed fixture array for array (the recipe used to crash between two generators)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MEBT_GOLDEN_OUT=str(tmp_path))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_golden.py")], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    made = sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz"))
+    assert made == sorted(f for f in os.listdir(G) if f.endswith('.npz')), made
+    for f in made:
+        a, b = np.load(os.path.join(tmp_path, f)), np.load(os.path.join(G, f))
+        assert sorted(a.files) == sorted(b.files), f
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), (f, k)

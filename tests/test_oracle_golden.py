@@ -182,6 +182,27 @@ def test_train_steps(name):
         np.testing.assert_allclose(pp, g[f"s{s}_pprobe"], atol=3e-5, rtol=1e-3)
 
 
+def test_windowed_train_step_c1():
+    """A train step whose mask sampler sliced a temporal window (seq_len = 64 of N = 128: mask_sampler.py:83-99) on the C1
+    config, against the reference (tests/golden/train_window_c1.npz; the reference's two numpy draws forced to T = 1, start 1)."""
+    g = load("train_window_c1")
+    cfg, P = mg.oracle_cfg("c1"), params("c1")
+    names = [str(n) for n in g["names"]]
+    st = orc.TrainState(P, lr=1e-3, weight_decay=0.05)
+    assert list(g["choice_a"]) == [1, 2] and list(g["randint"]) == [0, 2]
+    r = orc.train_step(st, cfg, torch.from_numpy(g["x"]), torch.from_numpy(g["indices"]), float(g["t"]), window=(1, 1))
+    meta = g["meta"]
+    assert abs(r["loss"] - meta[0]) < 2e-5 * abs(meta[0]) and r["n_targets"] == 3 * 39      # ceil(0.6 * 64) targets per sample
+    assert abs(r["acc1"] - meta[1]) < 1e-4 and abs(r["acc5"] - meta[2]) < 1e-4
+    gn = np.array([float(r["grads"][n].double().norm()) for n in names])
+    np.testing.assert_allclose(gn, g["gradnorm"], rtol=2e-4, atol=1e-7)
+    probe = g["probe"]
+    gp = np.stack([r["grads"][n].reshape(-1)[probe % r["grads"][n].numel()].numpy() for n in names])
+    np.testing.assert_allclose(gp, g["gprobe"], atol=2e-6, rtol=2e-3)
+    pn = np.array([float(st.P[n].detach().double().norm()) for n in names])
+    np.testing.assert_allclose(pn, g["pnorm"], rtol=1e-5)
+
+
 def test_flop_model_matches_survey():
     cfg = orc.OracleConfig(24, 16, 1024, 1024, 256,
                            ["latent_enc", "latent_self"] * 6 + ["latent_enc"] + ["latent_dec", "lt2l"] * 5 + ["latent_dec"])
