@@ -194,6 +194,10 @@ int mebt_op_sample(const float* logits, const float* noise, float temperature, i
  * interface for golden tests. */
 int mebt_op_sample_seeded(const float* logits, uint64_t seed, float temperature, int32_t top_k, float top_p, int64_t* ids,
                           float* score, float* probs, int32_t rows, int32_t V, mebt_stream_t stream);
+/* kth[r] = the top_k-th largest value of row r of logits [rows, V] (1 <= top_k < V): the threshold of the reference's module-level
+ * `top_k_logits` (transformer.py:891-895: everything below it becomes -inf, ties are kept).  ids_scratch: [rows] int64. */
+int mebt_op_topk_threshold(const float* logits, int32_t top_k, float* kth, int64_t* ids_scratch, int32_t rows, int32_t V,
+                           mebt_stream_t stream);
 /* x[b, ti[b,j]] = ids[b,j]  (the sparse_coo/to_dense/where scatter of transformer.py:413-439). */
 int mebt_op_scatter_ids(int64_t* x, const int64_t* ti, const int64_t* ids, int32_t B, int32_t N, int32_t NT,
                         mebt_stream_t stream);

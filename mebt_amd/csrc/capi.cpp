@@ -119,6 +119,16 @@ extern "C" int mebt_op_sample_seeded(const float* logits, uint64_t seed, float t
     return launch_sample(p, S(stream));
 }
 
+// the k-th largest logit of every row (exact: temperature 1 leaves the values untouched): the threshold of `top_k_logits`
+extern "C" int mebt_op_topk_threshold(const float* logits, int32_t top_k, float* kth, int64_t* ids_scratch, int32_t rows, int32_t V, mebt_stream_t stream) {
+    if (!logits || !kth || !ids_scratch) { mebt_set_error("topk_threshold: null pointer"); return MEBT_EINVAL; }
+    if (top_k <= 0 || top_k >= V) { mebt_set_error("topk_threshold: k must be in [1, V)"); return MEBT_ESHAPE; }
+    SampleParams p;
+    p.logits = logits; p.noise = nullptr; p.noise_seed = 0; p.temperature = 1.0f; p.top_k = top_k; p.top_p = 0.f; p.ids = ids_scratch;
+    p.score = nullptr; p.probs = nullptr; p.rows = rows; p.V = V; p.kth = kth;
+    return launch_sample(p, S(stream));
+}
+
 extern "C" int mebt_op_scatter_ids(int64_t* x, const int64_t* ti, const int64_t* ids, int32_t B, int32_t N, int32_t NT, mebt_stream_t stream) {
     if (!x || !ti || !ids) { mebt_set_error("scatter_ids: null pointer"); return MEBT_EINVAL; }
     return launch_scatter_ids(x, ti, ids, B, N, NT, S(stream));

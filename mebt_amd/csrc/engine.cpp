@@ -77,6 +77,7 @@ struct mebt_model {
     int64_t head_w = 0, lnf_w = 0, lnf_b = 0, mask_emb = 0, sos_emb = 0, pos_emb = 0, tok_emb = 0;
     float *W = nullptr, *gW = nullptr, *P = nullptr, *gP = nullptr;
     void* Wlp = nullptr;
+    bool tune_flush = true;    // fixed at creation (the workspace layout depends on it): was in-situ GEMM tuning on?
     void* gWb = nullptr;       // mebt_model_bind_wire_grads: bf16 gradient buffer laid out like gW; when set, the Linear weight
                                // gradients are stored there (and ONLY there) straight from the MFMA accumulators
 
@@ -219,6 +220,7 @@ extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) 
         return MEBT_EINVAL;
     }
     mebt_model* m = new mebt_model();
+    m->tune_flush = mebt_gemm_autotune_enabled() != 0;
     m->d = d;
     const int64_t dd = (int64_t)d.n_embd * d.n_embd, e = d.n_embd;
     int64_t w = 0, p = 0;
@@ -323,7 +325,10 @@ static void mode_shape(const mebt_model* m, int mode, int NC, int NT, int& NQ, i
 static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int NT, int training) {
     const int64_t d = m->d.n_embd, e = m->esz(), NS = m->d.n_latent, H = m->d.n_head, V = m->d.vocab;
     if (m->d.dtype == MEBT_BF16) {     // the library allocates nothing: the tuner's flush buffer and the split-K slabs come from here
-        x.tune.flush = c.take((int64_t)MEBT_TUNE_FLUSH_BYTES); x.tune.flush_bytes = MEBT_TUNE_FLUSH_BYTES;
+        // the 384 MB cache-flush buffer only while in-situ tuning is on (inference-only models and every extra model of a
+        // process paid for it); with tuning off a launch never times candidates.  16 bytes keep `flush` non-null = "scratch present".
+        const int64_t fb = m->tune_flush ? (int64_t)MEBT_TUNE_FLUSH_BYTES : 16;
+        x.tune.flush = c.take(fb); x.tune.flush_bytes = (size_t)fb;
         x.tune.splitk = (float*)c.take((int64_t)MEBT_TUNE_SPLITK_BYTES); x.tune.splitk_bytes = MEBT_TUNE_SPLITK_BYTES;
     } else {
         x.tune = {nullptr, 0, nullptr, 0};

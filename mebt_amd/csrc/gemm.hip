@@ -164,6 +164,7 @@ static void tune_remember(const TuneKey& k, int v) {
 }
 // 0: never tune (heuristic / cached choices only; every entry point is then free of host synchronisation and
 // capture-safe), 1: tune unseen signatures at their first launch.  Default: MEBT_GEMM_AUTOTUNE (1).
+int mebt_gemm_autotune_enabled() { std::lock_guard<std::mutex> lk(g_tune_mutex); tune_init(); return g_autotune; }
 extern "C" void mebt_gemm_autotune(int32_t mode) { std::lock_guard<std::mutex> lk(g_tune_mutex); tune_init(); g_autotune = mode ? 1 : 0; }
 
 static void heuristic_config(const GemmParams& p, int& tbm, int& tbn, int& staging) {

@@ -90,6 +90,7 @@ struct GroupedColsum {
 };
 int launch_colsum_grouped(GroupedColsum& c, int dtype, hipStream_t stream);
 int gemm_init_attributes();
+int mebt_gemm_autotune_enabled();      // is in-situ tuning on (MEBT_GEMM_AUTOTUNE / mebt_gemm_autotune)?
 void mebt_gemm_force_split(int s);
 
 // ---- embedding gather (reference transformer.py:255-277) and its scatter-add backward -----------
@@ -215,6 +216,8 @@ struct SampleParams {
     float* score;          // [rows] p[ids] after temperature/top-k/top-p
     float* probs;          // optional [rows,V]
     int rows, V;
+    float* kth = nullptr;  // optional [rows]: the k-th largest value of logits / (temperature + 1e-8) of each row (top_k > 0), i.e. the
+                           // threshold below which `top_k_logits` writes -inf (reference transformer.py:891-895)
 };
 int launch_sample(const SampleParams& p, hipStream_t stream);
 int launch_scatter_ids(int64_t* x, const int64_t* ti, const int64_t* ids, int B, int N, int NT, hipStream_t stream);

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
             __syncthreads();
         }
         const uint32_t kth = sel_prefix;
+        if (p.kth && tid == 0) p.kth[row] = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7FFFFFFFu) : ~kth);    // fkey^-1
         for (int e = tid; e < V; e += 256) if (fkey(sv[e]) < kth) sv[e] = -INFINITY;
         __syncthreads();
     }

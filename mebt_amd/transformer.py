@@ -715,13 +715,17 @@ def sample_from_logits(logits, temperature=1.0, top_k=None, top_p=None, return_p
 
 def top_k_logits(logits, k):
     """reference :891-895 (also the `Net2NetTransformer.top_k_logits` method): everything below the k-th largest logit of a
-    row becomes -inf, ties with the k-th value are kept.  The selection runs in the sampler kernel (radix select of the k-th
-    value, csrc/sampler.hip): its filtered distribution is zero exactly on the dropped entries."""
+    row becomes -inf, ties with the k-th value are kept.  The k-th value comes from the sampler kernel's radix select
+    (csrc/sampler.hip, `mebt_op_topk_threshold`); kept entries keep their value however small (a mask derived from
+    the filtered softmax also dropped kept entries whose probability underflows)."""
+    if not logits.is_cuda:
+        raise RuntimeError("mebt_amd has no CPU path: top_k_logits needs a tensor on the MI355X (cuda) device")
     V = logits.shape[-1]
+    if k >= V:
+        return logits.clone()
     lg = logits.to(torch.float32).contiguous().view(-1, V)
     R = lg.shape[0]
-    ids = torch.empty(R, dtype=torch.long, device=lg.device)
-    probs = torch.empty(R, V, dtype=torch.float32, device=lg.device)
-    _lib.check(_lib.load().mebt_op_sample_seeded(_lib.ptr(lg), 0, 1.0, int(k), 0.0, _lib.ptr(ids), None, _lib.ptr(probs), R, V,
-                                                 _lib.cur_stream()))
-    return logits.masked_fill(probs.view(logits.shape) == 0, -float("Inf"))       # p = 0 exactly on the entries the filter dropped
+    thr = torch.empty(R, dtype=torch.float32, device=lg.device)
+    scratch = torch.empty(R, dtype=torch.long, device=lg.device)
+    _lib.check(_lib.load().mebt_op_topk_threshold(_lib.ptr(lg), int(k), _lib.ptr(thr), _lib.ptr(scratch), R, V, _lib.cur_stream()))
+    return logits.masked_fill(logits.to(torch.float32) < thr.view(*logits.shape[:-1], 1), -float("Inf"))

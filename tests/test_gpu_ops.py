@@ -393,3 +393,10 @@ def test_top_k_logits_helper_matches_reference_semantics():
     ref = lg.clone()
     ref[ref < v] = -float("inf")
     assert torch.equal(out, ref) and int((out[0, 0] > -float("inf")).sum()) == 6
+    # kept entries stay kept however small their softmax weight: a spread of 400 underflows exp() in fp32
+    lg2 = torch.linspace(-400.0, 0.0, 16384).repeat(2, 1)
+    out2 = top_k_logits(lg2.to(DEV), 16000).cpu()
+    assert int((out2[0] > -float("inf")).sum()) == 16000 and torch.equal(out2[0, 384:], lg2[0, 384:])
+    assert torch.equal(top_k_logits(lg2.to(DEV), 16384).cpu(), lg2)        # k = V: nothing is dropped
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        top_k_logits(lg2, 5)

@@ -87,6 +87,111 @@ def test_draft_and_revise_bit_exact():
         assert (xs.cpu().numpy() == g[f"d{i}_x"]).all(), i
 
 
+def test_edit_mode_sample_and_draft_and_revise_bit_exact():
+    """`edit=True` (reference transformer.py:373-376,399: the mask schedule counts only the edited tokens; :658-660: the revise
+    passes of draft_and_revise drop the caller's index sets) against vectors from the imported reference."""
+    g = load_golden("edit_beta_priors")
+    model = build_product("micro", "f32", schedule="cosine").eval()
+    hook, state = closed_form_hook()
+    model.noise_hook = hook
+    idx = torch.from_numpy(g["edit_idx"]).to(DEV)
+    xs, ci, ti = model.sample(torch.from_numpy(g["edit_x0"]).to(DEV), None, 1.0, None, None, 5, idx[:, :12], idx[:, 12:],
+                              context_temperature=3.0, skips=False, edit=True)
+    assert state["k"] == int(g["edit_ndraws"])
+    assert (xs.cpu().numpy() == g["edit_x"]).all() and (ci.cpu().numpy() == g["edit_ci"]).all() and (ti.cpu().numpy() == g["edit_ti"]).all()
+    # the same call without edit=True takes different steps (the schedule then counts all N tokens): the flag is live
+    hook2, _ = closed_form_hook()
+    model.noise_hook = hook2
+    xs2, ci2, _ = model.sample(torch.from_numpy(g["edit_x0"]).to(DEV), None, 1.0, None, None, 5, idx[:, :12], idx[:, 12:],
+                               context_temperature=3.0, skips=False, edit=False)
+    assert ci2.shape != ci.shape or not (xs2.cpu().numpy() == g["edit_x"]).all()
+    model = build_product("micro", "f32").eval()
+    hook, state = closed_form_hook()
+    model.noise_hook = hook
+    idx = torch.from_numpy(g["edit_dnr_idx"]).to(DEV)
+    xs = model.draft_and_revise(torch.from_numpy(g["edit_dnr_x0"]).to(DEV), None, 4, 1.0, None, None, 4, 0.7, None, None, 2, False, False,
+                                idx[:, :16], idx[:, 16:], True)
+    assert state["k"] == int(g["edit_dnr_ndraws"])
+    assert (xs.cpu().numpy() == g["edit_dnr_x"]).all()
+
+
+def test_beta_schedule_training_forward():
+    """beta(t) schedule (reference transformer.py:113-119,229-241): at each global step the module hands the reference's (alpha,
+    beta) to torch's Beta, and the train-mode shared_step with the drawn t gives the reference's loss / accuracies."""
+    import torch.distributions.beta as tdb
+    g = load_golden("edit_beta_priors")
+    model = build_product("micro", "f32", beta_params=[3.0, 9.0], beta_iter=1000).train()
+    calls, forced = [], list(g["beta_forced_t"])
+
+    class FakeBeta:
+        def __init__(self, a, b):
+            calls.append((float(a), float(b)))
+
+        def sample(self):
+            return torch.tensor(forced[len(calls) - 1])
+    real = tdb.Beta
+    tdb.Beta = torch.distributions.beta.Beta = FakeBeta
+    try:
+        for s, gs in enumerate(g["beta_gsteps"]):
+            model.global_step = int(gs)
+            x, idx = torch.from_numpy(g[f"beta{s}_x"]).to(DEV), torch.from_numpy(g[f"beta{s}_indices"]).to(DEV)
+            with torch.no_grad():
+                acc1, acc5, loss, ratio = model.shared_step({"video": x, "label": x, "indices": idx}, 0)
+            meta = g["beta_meta"][s]
+            assert abs(float(loss) - meta[0]) < 2e-5 * abs(meta[0]) and abs(float(acc1) - meta[1]) < 1e-3 and abs(float(acc5) - meta[2]) < 1e-3
+            assert abs(float(ratio) - meta[3]) < 1e-7
+    finally:
+        tdb.Beta = torch.distributions.beta.Beta = real
+    np.testing.assert_allclose(np.array(calls), g["beta_calls"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_windowed_train_step_c1(dtype):
+    """The video-length curriculum on the GPU (every 128-frame config trains this way): t_prior = gaussian2, the mask sampler's
+    two numpy draws forced to a window of T = 1 of 2 latent frames starting at frame 1, so seq_len = 64 < N = 128
+    (reference transformer.py:243-245, mask_sampler.py:83-99) — one optimizer step of the HIP engine on C1 against the
+    imported reference: the prior handed to np.random.choice, loss, every gradient norm / probe, post-step parameter norms."""
+    from mebt_amd.trainer import TrainLoop
+    g = load_golden("train_window_c1")
+    names = [str(n) for n in g["names"]]
+    model = build_product("c1", dtype, t_prior="gaussian2").train()
+    model.learning_rate, model.weight_decay, model.warmup_steps, model.cosine_lr = 1e-3, 0.05, 0, False
+    model.global_step = int(g["global_step"])
+    loop = TrainLoop(model, fused_optimizer=False)
+    rec = {}
+    real_choice, real_randint = np.random.choice, np.random.randint
+
+    def fake_choice(a, p=None, **kw):
+        rec["a"], rec["p"] = np.asarray(a).copy(), np.asarray(p).copy()
+        return 1
+
+    def fake_randint(lo, hi=None, **kw):
+        rec["randint"] = (lo, hi)
+        return 1
+    np.random.choice, np.random.randint = fake_choice, fake_randint
+    try:
+        stats = loop.step(torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["indices"]).to(DEV), t=float(g["t"])).cpu().numpy()
+    finally:
+        np.random.choice, np.random.randint = real_choice, real_randint
+    assert list(rec["a"]) == list(g["choice_a"]) and tuple(rec["randint"]) == tuple(g["randint"])
+    np.testing.assert_allclose(rec["p"], g["choice_p"], rtol=1e-12)
+    tol = 1.0 if dtype == "f32" else 60.0
+    assert int(stats[3]) == 3 * 39
+    assert abs(stats[4] - g["meta"][0]) < tol * 5e-5 * abs(g["meta"][0]), (stats[4], g["meta"][0])
+    nm = loop.native
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    grads = nm.views(shapes, grads=True)
+    gn = np.array([float(grads[n].double().norm()) for n in names])
+    np.testing.assert_allclose(gn, g["gradnorm"], rtol=tol * 5e-4, atol=1e-7 * tol)
+    if dtype == "f32":
+        probe = g["probe"]
+        gp = np.stack([grads[n].reshape(-1)[torch.from_numpy(probe % grads[n].numel()).to(DEV)].cpu().numpy() for n in names])
+        np.testing.assert_allclose(gp, g["gprobe"], atol=3e-6, rtol=5e-3)
+        sd = model.state_dict()
+        pn = np.array([float(sd[n].double().norm()) for n in names])
+        np.testing.assert_allclose(pn, g["pnorm"], rtol=2e-5)
+
+
 def test_script_drivers_bit_exact():
     """bidirect_sample / extrapolate (sample_vqgan_transformer_videos.py:22-157) against vectors produced by
     the reference script's own functions (tests/golden/make_golden.py:gen_script_drivers)."""
