@@ -803,9 +803,13 @@ struct Leaves {
     GroupedWgrad w;
     GroupedColsum c;
     Leaves() { w.n = 0; c.n = 0; }
-    void wgrad(const void* dY, int ld_dy, const void* X, int ld_x, float* C, int n_out, int k_in, int tokens) {
+    // `bias`: the layer's bias gradient [n_out] (+= column sums of dY); bf16 mode adds it up inside the grouped launch, the
+    // fp32 parity mode keeps the separate column-sum pass
+    void wgrad(const void* dY, int ld_dy, const void* X, int ld_x, float* C, int n_out, int k_in, int tokens, float* bias = nullptr, bool in_gemm = false) {
         GroupedWgrad::Item& it = w.g[w.n++];
         it.A = dY; it.B = X; it.C = C; it.M = n_out; it.N = k_in; it.K = tokens; it.lda = ld_dy; it.ldb = ld_x; it.ldc = k_in; it.ntx = 0;
+        it.bias = in_gemm ? bias : nullptr;
+        if (bias && !in_gemm) colsum(dY, tokens, n_out, ld_dy, bias);
     }
     void colsum(const void* X, int M, int N, int ldx, float* out) {
         GroupedColsum::Item& it = c.g[c.n++];
@@ -911,12 +915,11 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     else if (p_res > 0.f) RC(launch_apply_dropout(dout, sc.dout_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_MLP, p_res), st));
     else MEBT_HIP_CHECK(hipMemcpyAsync(sc.dout_m, dout, (size_t)Mq * d * esz, hipMemcpyDeviceToDevice, st));
     const void* dmlp = sc.dout_m;
-    lv.colsum(dmlp, Mq, d, d, m->gP + o.b2);
-    lv.wgrad(dmlp, d, a.u, 4 * d, m->gW + o.w2, d, 4 * d, Mq);
+    const bool bg = dt == MEBT_BF16;           // bias gradients inside the grouped weight-gradient launch
+    lv.wgrad(dmlp, d, a.u, 4 * d, m->gW + o.w2, d, 4 * d, Mq, m->gP + o.b2, bg);
     const int64_t dd = (int64_t)d * d;
     RC(dgrad(m, dmlp, d, o.w2, sc.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, st, o.w1, 4 * dd));   // d(pre) = (dmlp W2) * gelu'(pre)
-    lv.colsum(sc.d4, Mq, 4 * d, 4 * d, m->gP + o.b1);
-    lv.wgrad(sc.d4, 4 * d, a.hn, d, m->gW + o.w1, 4 * d, d, Mq);
+    lv.wgrad(sc.d4, 4 * d, a.hn, d, m->gW + o.w1, 4 * d, d, Mq, m->gP + o.b1, bg);
     RC(dgrad(m, sc.d4, 4 * d, o.w1, sc.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st, o.wp, dd, &a, 0));
     // dx = dout + LN2'(dh); the same kernel reduces dgamma/dbeta and writes the dropout-masked copy the
     // projection branch reads (x = qn + dropout(att Wp^T + bp))
@@ -933,8 +936,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         if (side) RC(fork_side(m, st));
         RC(launch_ln_bwd(p, dt, st, sd));
     }
-    lv.colsum(dproj, Mq, d, d, m->gP + o.bp);
-    lv.wgrad(dproj, d, a.att, d, m->gW + o.wp, d, d, Mq);
+    lv.wgrad(dproj, d, a.att, d, m->gW + o.wp, d, d, Mq, m->gP + o.bp, bg);
     RC(dgrad(m, dproj, d, o.wp, x.datt, Mq, d, d, EPI_NONE, nullptr, 0, st, o.wq, 3 * dd));
     // attention backward
     AttnParams ap;
@@ -962,8 +964,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         p.rows = rows; p.d = d; p.seg = seg; p.seg_stride = seg_stride; p.seg_off = seg_off;
     };
     if (mode == MEBT_MODE_LATENT_SELF || ismg) {
-        lv.colsum(sc.dqkv_q, Mq, 3 * d, 3 * d, m->gP + o.bq);
-        lv.wgrad(sc.dqkv_q, 3 * d, a.qn, d, m->gW + o.wq, 3 * d, d, Mq);
+        lv.wgrad(sc.dqkv_q, 3 * d, a.qn, d, m->gW + o.wq, 3 * d, d, Mq, m->gP + o.bq, bg);
         RC(dgrad(m, sc.dqkv_q, 3 * d, o.wq, sc.dqn, Mq, 3 * d, d, EPI_RESID, sc.dx, d, st, i > 0 ? m->lo[i - 1].w2 : -1, 4 * dd,
                  i > 0 ? &x.L[i - 1] : nullptr, 1));   // + dx (residual on qn)
         if (side) RC(fork_side(m, st));
@@ -977,10 +978,8 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
             ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0);
         }
     } else {
-        lv.colsum(sc.dqkv_q, Mq, d, d, m->gP + o.bq);
-        lv.wgrad(sc.dqkv_q, d, a.qn, d, m->gW + o.wq, d, d, Mq);
-        lv.colsum(sc.dqkv_k, Mk, 2 * d, 2 * d, m->gP + o.bk);
-        lv.wgrad(sc.dqkv_k, 2 * d, a.kn, d, m->gW + o.wk, 2 * d, d, Mk);
+        lv.wgrad(sc.dqkv_q, d, a.qn, d, m->gW + o.wq, d, d, Mq, m->gP + o.bq, bg);
+        lv.wgrad(sc.dqkv_k, 2 * d, a.kn, d, m->gW + o.wk, 2 * d, d, Mk, m->gP + o.bk, bg);
         {
             GemmParams pq = gp(sc.dqkv_q, m->Wop(o.wq), sc.dqn, Mq, d, d, d, d, d, 1, 0);
             pq.epilogue = EPI_RESID; pq.aux = sc.dx; pq.ld_aux = d;

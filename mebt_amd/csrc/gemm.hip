@@ -430,6 +430,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
             // candidates are timed in the mode that will run; a fused launch is not idempotent, so its candidates
             // run with a zero learning rate, zero decay and beta1 = beta2 = 1 (p, m, v are rewritten unchanged)
             GroupedWgrad tc = c;
+            for (int i = 0; i < n; ++i) tc.g[i].bias = nullptr;      // the bias row sums are atomic adds: not in the repeated candidate runs
             if (tc.fused) { tc.opt.lr = 0.f; tc.opt.weight_decay = 0.f; tc.opt.beta1 = 1.f; tc.opt.beta2 = 1.f; }
             for (int t = 0; t < 4; ++t)
                 for (int st = 2; st <= 4; ++st) {

@@ -497,7 +497,7 @@ struct DmaLoader {
 // For outputs of a chip's worth of tiles or less and a deep reduction (the MLP down-projection and its dgrad:
 // 256 tiles x 64 k-tiles) a single 4-wave workgroup per CU is bound by the latency of one k-step (barrier, LDS
 // read, 12-24 dependent MFMAs); the second pipeline fills exactly those bubbles.
-template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE, int KS = 1>
+template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE, int KS = 1, bool ROWSUM = false>
 __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n0, int kt0, int kt1, char* smem, bool atomic, bool add_bias) {
     constexpr int STAGE = (TBM + TBN) * BK * 2;
     constexpr int TM = TBM / 32, TN = TBN / 32;
@@ -527,6 +527,16 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ROWSUM: row sums of A over k (bias gradients) ride on the fragments of tile column 0: rs[i] = ones . af[i]^T per k-step
+    const bool do_rs = ROWSUM && p.rowsum_a != nullptr && n0 == 0 && wn == 0;
+    f32x4 rs[ROWSUM ? TM : 1];
+    bf16x8 ones;
+    if (ROWSUM) {
+#pragma unroll
+        for (int i = 0; i < (ROWSUM ? TM : 1); ++i) rs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+    }
     constexpr int AHEAD = NSTAGE - 1;                   // tiles in flight behind the one being multiplied
 #pragma unroll
     for (int a = 0; a < AHEAD; ++a)
@@ -565,10 +575,21 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            if (ROWSUM && do_rs) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) rs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], rs[i], 0, 0, 0);
+            }
         }
         if (++st == NSTAGE) st = 0;
     }
     if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
+    if (ROWSUM && do_rs && (lane >> 4) == 0) {          // every column of rs[i] holds the sum of row (lane & 15) of fragment i
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (TBM / 2) + i * 16 + (lane & 15);
+            if (m < p.M) atomicAdd(p.rowsum_a + m, rs[i][0]);
+        }
+    }
     if (KS == 2) {
         // odd pipeline -> LDS -> even pipeline.  The exchange area starts above the epilogue's staging slabs
         // (4 waves x 16 rows x <= 132 floats = 33 KiB) and fits the two rings (checked by the launcher).
@@ -850,6 +871,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w
     p.A = it.A; p.B = it.B; p.C = it.C; p.C2 = nullptr; p.bias = nullptr; p.aux = nullptr;
     p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb; p.ldc = it.ldc; p.ld_aux = 0;
     p.a_kc = 0; p.b_kc = 0; p.epilogue = EPI_NONE; p.c_f32 = 1; p.beta = w.beta; p.split_k = 1; p.drop.thresh = 0;
+    p.rowsum_a = it.bias;
     if (w.Cb) { p.C = reinterpret_cast<bf16_t*>(w.Cb) + (it.C - w.gW); p.c_f32 = 0; }
     if (w.fused) {
         const ptrdiff_t off = it.C - w.gW;
@@ -860,7 +882,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w
     int tr, tc;
     xcd_tile(t, it.ntx, (it.M + TBM - 1) / TBM, it.M, it.N, tr, tc);
     const int m0 = tr * TBM, n0 = tc * TBN;
-    gemm_tile_dma<false, false, TBM, TBN, NSTAGE>(p, m0, n0, 0, (it.K + BK - 1) / BK, smem, false, false);
+    gemm_tile_dma<false, false, TBM, TBN, NSTAGE, 1, true>(p, m0, n0, 0, (it.K + BK - 1) / BK, smem, false, false);
 }
 
 // ------------------------------------------------------------------------------------------------

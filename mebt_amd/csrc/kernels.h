@@ -59,6 +59,7 @@ struct GemmParams {
     const void* pf2 = nullptr;              // a second range, 4 lines per thread: saved forward activations the NEXT kernels of the
     unsigned pf2_bytes = 0;                 // backward chain read (they were written a whole forward + half a backward ago)
     unsigned* pf_sink = nullptr;            // always null at run time: keeps the prefetch loads alive for the compiler
+    float* rowsum_a = nullptr;              // internal (grouped weight gradients): [M] fp32 += sum_k A(m, k), added by the tiles of column 0
     unsigned long long* stamps = nullptr;   // diagnostics only (mebt_debug_gemm_stamps): [workgroup][4] s_memtime at entry / first tile landed /
                                             // main loop done / epilogue done, written by wave 0 of each workgroup
 };
@@ -73,7 +74,10 @@ struct GemmPair { GemmParams p[2]; int tiles0; int ntx[2]; };     // kernel argu
 struct GroupedWgrad {
     int n;
     int tile_start[MEBT_MAX_GROUP + 1];
-    struct Item { const void* A; const void* B; float* C; int M, N, K, lda, ldb, ldc, ntx; } g[MEBT_MAX_GROUP];
+    // bias: optional [M] fp32, += sum over the K tokens of dY (the Linear layer's bias gradient, nn.Linear backward): dY is this
+    // product's A operand, so the workgroups of tile column 0 add it up from the fragments they multiply anyway (one extra MFMA
+    // against a ones fragment per A fragment) instead of a separate column-sum pass re-reading every dY of the block (28 MB at C2)
+    struct Item { const void* A; const void* B; float* C; int M, N, K, lda, ldb, ldc, ntx; float* bias = nullptr; } g[MEBT_MAX_GROUP];
     // optimizer-in-backward: when `fused`, item i's gradient is applied to W + (C - gW) etc. instead of stored
     int fused = 0;
     float* W = nullptr; float* gW = nullptr; float* mW = nullptr; float* vW = nullptr; void* Wlp = nullptr;
