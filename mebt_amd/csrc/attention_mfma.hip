@@ -118,8 +118,10 @@ constexpr int CHUNK_TILES = 4;                   // 64-row tiles per chunk
 constexpr int CHUNK = CHUNK_TILES * TILE;        // 256 streamed rows per chunk
 constexpr int CHUNK_BYTES = CHUNK_TILES * TILE_BYTES;          // one operand: 32 KiB
 constexpr int STAT_BYTES = CHUNK * 4;                          // one fp32 vector of a chunk (dK/dV kernel)
-constexpr int STAGE_BYTES = 2 * CHUNK_BYTES + 2 * STAT_BYTES;  // two operands (+ lse, delta)
-constexpr int ATTN_LDS = 2 * STAGE_BYTES;                      // 132 KiB
+constexpr int MASK_BYTES = 4096;                               // dropout keep bits of a chunk (backward kernels): 4 DMA pieces
+constexpr int MASK_OFF = 2 * CHUNK_BYTES + 2 * STAT_BYTES;
+constexpr int STAGE_BYTES = MASK_OFF + MASK_BYTES;             // two operands (+ lse, delta) + keep bits
+constexpr int ATTN_LDS = 2 * STAGE_BYTES;                      // 140 KiB
 constexpr int DMA_PER_WAVE = 2 * (CHUNK_BYTES / 1024) / WAVES; // 8 LDS-DMA instructions per wave per chunk
 
 // One operand of a chunk = 32 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces w, w+8, w+16, w+24.
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_mfma(const AttnParams p) 
         lv.issue(smem + STAGE_BYTES + CHUNK_BYTES, 1, wave);
     }
     const float c = 0.125f * LOG2E;     // 1/sqrt(64) folded with log2(e)
+    const int mtiles = mebt_attn_dmask_tiles(p.NK);
     FragOffsets fo;
     fo.init(lane);
 
@@ -221,8 +224,16 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_mfma(const AttnParams p) 
             m = mn;
             if (p.drop.thresh) {   // attn_drop on the probabilities (gpt.py:135); the row sum above stays undropped
                 const uint64_t dbase = (((uint64_t)b * p.H + h) * p.NQ + q) * p.NK + k0;
+                uint32_t bits = 0;
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) s[kb] *= drop_keep4(p.drop, dbase + 16 * kb + 4 * g);
+                for (int kb = 0; kb < 4; ++kb) {
+                    const f32x4 keep = drop_keep4(p.drop, dbase + 16 * kb + 4 * g);
+                    s[kb] *= keep;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bits |= (keep[r] != 0.f ? 1u : 0u) << (4 * kb + r);
+                }
+                if (p.dmask && q < p.NQ)      // the keep bits of this lane's 16 elements: read back by the backward kernels
+                    p.dmask[((((size_t)b * p.H + h) * p.NQ + q) * mtiles + (k0 >> 6)) * 4 + g] = (uint16_t)bits;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] *= alpha;
@@ -279,11 +290,24 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_mfma(const AttnParams 
     }
     const size_t sidx = ((size_t)b * p.H + h) * p.NQ + q;
     const float lse_q = qv ? p.lse[sidx] : 0.f;
+    // keep bits of (this workgroup's 128 queries) x (the chunk's 4 key tiles): 32 B per query = 4 KiB per chunk = four 1-KiB DMA
+    // pieces, issued by waves 0-3 with the chunk (always: a null / zero-sized mask reads as zeros without traffic, and the
+    // counted waits stay the same); piece `wave`, lane l -> query 32 wave + l / 2, 16-byte half l & 1
+    const bool use_bits = p.drop.thresh && p.dmask != nullptr;
+    const int mtiles = mebt_attn_dmask_tiles(p.NK);
+    const size_t mrow0 = ((size_t)b * p.H + h) * p.NQ;
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(p.dmask ? p.dmask + mrow0 * mtiles * 4 : (const uint16_t*)p.q, use_bits ? (size_t)p.NQ * mtiles * 8 : 0);
+    const uint32_t moff = (uint32_t)((blockIdx.x * BLOCK_ROWS + 32 * (wave & 3) + (lane >> 1)) * mtiles * 8 + (lane & 1) * 16);
+    auto issue_mask = [&](char* stage, int chunk) {
+        if (wave < 4) dma16(rmask, lds_addr_of(stage + MASK_OFF + wave * 1024), moff + (uint32_t)chunk * 32);
+    };
     lk.issue(smem, 0, wave);
     lv.issue(smem + CHUNK_BYTES, 0, wave);
+    issue_mask(smem, 0);
     if (nchunks > 1) {
         lk.issue(smem + STAGE_BYTES, 1, wave);
         lv.issue(smem + STAGE_BYTES + CHUNK_BYTES, 1, wave);
+        issue_mask(smem + STAGE_BYTES, 1);
     }
     float delta = 0.f;
 #pragma unroll
@@ -300,15 +324,17 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_mfma(const AttnParams 
 #pragma unroll
     for (int e = 0; e < 4; ++e) dq[e] = f32x4{0, 0, 0, 0};
     const uint64_t drow = (((uint64_t)b * p.H + h) * p.NQ + q) * p.NK;     // dropout index of (q, key 0)
+    const int mlds = (wave * 16 + (lane & 15)) * 32 + g * 2;                // this lane's field of tile 0 in the staged mask
     for (int ch = 0; ch < nchunks; ++ch) {
         char* stage = smem + (ch & 1) * STAGE_BYTES;
-        if (ch + 1 < nchunks) wait_vm<DMA_PER_WAVE>(); else wait_vm<0>();
+        if (ch + 1 < nchunks) { if (wave < 4) wait_vm<DMA_PER_WAVE + 1>(); else wait_vm<DMA_PER_WAVE>(); } else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         const int nt = min(CHUNK_TILES, (p.NK - ch * CHUNK + TILE - 1) / TILE);
         for (int t = 0; t < nt; ++t) {
             const char* sK = stage + t * TILE_BYTES;
             const char* sV = stage + CHUNK_BYTES + t * TILE_BYTES;
             const int k0 = ch * CHUNK + t * TILE;
+            const uint32_t bits = use_bits ? *reinterpret_cast<const uint16_t*>(stage + MASK_OFF + mlds + t * 8) : 0u;
             f32x4 ds[4];
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
@@ -319,7 +345,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_mfma(const AttnParams 
                     dp = MFMA(fo.row_frag(sV, kb, ks), gf[ks], dp);    // dP^T[key][q] = V dO^T
                 }
                 f32x4 keep = {1.f, 1.f, 1.f, 1.f};
-                if (p.drop.thresh) keep = drop_keep4(p.drop, drow + (uint64_t)(k0 + 16 * kb + 4 * g));
+                if (use_bits) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) keep[r] = ((bits >> (4 * kb + r)) & 1u) ? p.drop.inv_keep : 0.f;
+                } else if (p.drop.thresh) {
+                    keep = drop_keep4(p.drop, drow + (uint64_t)(k0 + 16 * kb + 4 * g));
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = k0 + 16 * kb + 4 * g + r;
@@ -339,6 +370,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_mfma(const AttnParams 
             __builtin_amdgcn_s_barrier();
             lk.issue(stage, ch + 2, wave);
             lv.issue(stage + CHUNK_BYTES, ch + 2, wave);
+            issue_mask(stage, ch + 2);
         }
     }
     if (qv) {
@@ -370,10 +402,18 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_mfma(const AttnParams
     // lse / delta of a chunk: 256 floats = one 1-KiB piece each, copied by waves 0 and 1 (zero beyond NQ)
     const __amdgpu_buffer_rsrc_t rstat = make_rsrc(wave == 0 ? L : Dl, (size_t)p.NQ * 4);
     const int nchunks = (p.NQ + CHUNK - 1) / CHUNK;
+    // keep bits of (the chunk's 256 queries) x (this workgroup's 2 key tiles): 16 B per query = 4 KiB per chunk = four 1-KiB DMA
+    // pieces issued by waves 0-3 (always, see the dQ kernel); piece `wave`, lane l -> query 64 wave + l of the chunk
+    const bool use_bits = p.drop.thresh && p.dmask != nullptr;
+    const int mtiles = mebt_attn_dmask_tiles(p.NK);
+    const size_t mrow0 = ((size_t)b * p.H + h) * p.NQ;
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc(p.dmask ? p.dmask + mrow0 * mtiles * 4 : (const uint16_t*)p.q, use_bits ? (size_t)p.NQ * mtiles * 8 : 0);
+    const uint32_t moff = (uint32_t)((64 * (wave & 3) + lane) * mtiles * 8 + blockIdx.x * 16);
     auto issue = [&](char* stage, int chunk) {
         lq.issue(stage, chunk, wave);
         lg.issue(stage + CHUNK_BYTES, chunk, wave);
         if (wave < 2) dma16(rstat, lds_addr_of(stage + 2 * CHUNK_BYTES + wave * STAT_BYTES), (uint32_t)(chunk * CHUNK * 4 + lane * 16));
+        if (wave < 4) dma16(rmask, lds_addr_of(stage + MASK_OFF + wave * 1024), moff + (uint32_t)chunk * CHUNK * (uint32_t)mtiles * 8);
     };
     bf16x8 kf[2], vf[2];
 #pragma unroll
@@ -394,13 +434,16 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_mfma(const AttnParams
     for (int ch = 0; ch < nchunks; ++ch) {
         char* stage = smem + (ch & 1) * STAGE_BYTES;
         if (ch + 1 < nchunks) {
-            if (wave < 2) wait_vm<DMA_PER_WAVE + 1>(); else wait_vm<DMA_PER_WAVE>();
+            if (wave < 2) wait_vm<DMA_PER_WAVE + 2>(); else if (wave < 4) wait_vm<DMA_PER_WAVE + 1>(); else wait_vm<DMA_PER_WAVE>();
         } else {
             wait_vm<0>();
         }
         __builtin_amdgcn_s_barrier();
         const float* cl = reinterpret_cast<const float*>(stage + 2 * CHUNK_BYTES);
         const float* cd = cl + CHUNK;
+        // this lane's key is bit 4 (wave & 3) + (lane & 3) of field [q][key tile wave >> 2][(lane >> 2) & 3]
+        const char* cm = stage + MASK_OFF + (wave >> 2) * 8 + ((lane >> 2) & 3) * 2;
+        const int mbit = 4 * (wave & 3) + (lane & 3);
         const int nt = min(CHUNK_TILES, (p.NQ - ch * CHUNK + TILE - 1) / TILE);
         for (int t = 0; t < nt; ++t) {
             const char* sQ = stage + t * TILE_BYTES;
@@ -422,7 +465,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_mfma(const AttnParams
                     const int qi = q0 + 16 * qb + 4 * g + r;
                     // padded query rows (qi >= NQ): Q and dO rows are zero-filled, so whatever p is they add nothing
                     const float pv = fast_exp2(fmaf(s[r], c, -l4[r] * LOG2E));
-                    const float keep = p.drop.thresh ? drop_keep(p.drop, dcol + (uint64_t)(uint32_t)qi * (uint32_t)p.NK) : 1.0f;
+                    float keep = 1.0f;
+                    if (use_bits) keep = ((*reinterpret_cast<const uint16_t*>(cm + (t * TILE + 16 * qb + 4 * g + r) * 16) >> mbit) & 1u) ? p.drop.inv_keep : 0.f;
+                    else if (p.drop.thresh) keep = drop_keep(p.drop, dcol + (uint64_t)(uint32_t)qi * (uint32_t)p.NK);
                     ds[qb][r] = pv * (dp[r] * keep - d4[r]) * 0.125f;
                     pr[qb][r] = pv * keep;
                 }

@@ -35,6 +35,7 @@ struct Carve {   // bump allocator over the workspace; query mode when base == n
 struct LayerAct {   // saved activations of one block
     void *qn, *kn, *q, *k, *v, *att, *x, *hn, *pre, *u, *out;
     float *mean1q, *rstd1q, *mean1k, *rstd1k, *mean2, *rstd2, *lse;
+    uint16_t* dmask = nullptr;   // attention-dropout keep bits written by the MFMA forward, read by its two backward kernels (AttnParams::dmask)
     const void* q_in;   // LN1 input of the query side (previous stream value); maskgit: the contexts stream
     const void* k_in;   // LN1 input of the key side (enc: contexts, dec: sos); lt2l uses S and T; maskgit: the targets stream
     void *c_out, *t_out;   // maskgit: the block output split back into contiguous contexts / targets (gpt.py:191-192)
@@ -77,6 +78,7 @@ struct mebt_model {
     int64_t head_w = 0, lnf_w = 0, lnf_b = 0, mask_emb = 0, sos_emb = 0, pos_emb = 0, tok_emb = 0;
     float *W = nullptr, *gW = nullptr, *P = nullptr, *gP = nullptr;
     void* Wlp = nullptr;
+    bool attn_bits = true;     // fixed at creation (workspace layout): MEBT_ATTN_DROP_BITS=0 -> the backward kernels re-hash the mask
     bool tune_flush = true;    // fixed at creation (the workspace layout depends on it): was in-situ GEMM tuning on?
     void* gWb = nullptr;       // mebt_model_bind_wire_grads: bf16 gradient buffer laid out like gW; when set, the Linear weight
                                // gradients are stored there (and ONLY there) straight from the MFMA accumulators
@@ -221,6 +223,7 @@ extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) 
     }
     mebt_model* m = new mebt_model();
     m->tune_flush = mebt_gemm_autotune_enabled() != 0;
+    { const char* e = getenv("MEBT_ATTN_DROP_BITS"); m->attn_bits = !(e && e[0] == '0'); }
     m->d = d;
     const int64_t dd = (int64_t)d.n_embd * d.n_embd, e = d.n_embd;
     int64_t w = 0, p = 0;
@@ -374,6 +377,8 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
         }
         a.att = c.take(Mq * d * e);
         a.lse = (float*)c.take((int64_t)B * H * a.NQ * 4);
+        a.dmask = (training && m->d.attn_pdrop > 0.f && m->d.dtype == MEBT_BF16 && d / H == 64 && m->attn_bits)
+                      ? (uint16_t*)c.take((int64_t)mebt_attn_dmask_bytes(B, (int)H, a.NQ, a.NK)) : nullptr;
         a.x = c.take(Mq * d * e);
         a.mean2 = (float*)c.take(Mq * 4); a.rstd2 = (float*)c.take(Mq * 4);
         a.hn = c.take(Mq * d * e);
@@ -607,6 +612,7 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         ap.B = B; ap.H = H; ap.NQ = a.NQ; ap.NK = a.NK; ap.HD = d / H;
         ap.ldq = a.ldqkv_q; ap.ldk = a.ldqkv_k; ap.ldv = a.ldqkv_k; ap.ldo = d;
         ap.drop = make_drop(dropout_seed, 16 * i + SITE_ATTN, p_att);   // gpt.py:135
+        ap.dmask = (p_att > 0.f && training) ? a.dmask : nullptr;
         RC(launch_attn_fwd(ap, dt, st));
         // x = LN1(query) + proj(att)   — residual on the NORMALISED query (gpt.py:180,184)
         {
@@ -915,7 +921,8 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     else if (p_res > 0.f) RC(launch_apply_dropout(dout, sc.dout_m, (size_t)Mq * d, f32, f32, make_drop(x.drop_seed, 16 * i + SITE_MLP, p_res), st));
     else MEBT_HIP_CHECK(hipMemcpyAsync(sc.dout_m, dout, (size_t)Mq * d * esz, hipMemcpyDeviceToDevice, st));
     const void* dmlp = sc.dout_m;
-    const bool bg = dt == MEBT_BF16;           // bias gradients inside the grouped weight-gradient launch
+    static const bool bias_in_wgrad = [] { const char* e = getenv("MEBT_BIAS_IN_WGRAD"); return !(e && e[0] == '0'); }();
+    const bool bg = dt == MEBT_BF16 && bias_in_wgrad;           // bias gradients inside the grouped weight-gradient launch
     lv.wgrad(dmlp, d, a.u, 4 * d, m->gW + o.w2, d, 4 * d, Mq, m->gP + o.b2, bg);
     const int64_t dd = (int64_t)d * d;
     RC(dgrad(m, dmlp, d, o.w2, sc.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, st, o.w1, 4 * dd));   // d(pre) = (dmlp W2) * gelu'(pre)
@@ -945,6 +952,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     ap.ldq = a.ldqkv_q; ap.ldk = a.ldqkv_k; ap.ldv = a.ldqkv_k; ap.ldo = d;
     ap.d_o = x.datt; ap.lddo = d; ap.delta = x.delta;
     ap.drop = make_drop(x.drop_seed, 16 * i + SITE_ATTN, p_att);
+    ap.dmask = p_att > 0.f ? a.dmask : nullptr;
     if (mode == MEBT_MODE_LATENT_SELF || ismg) {
         ap.dq = sc.dqkv_q; ap.dk = (char*)sc.dqkv_q + (size_t)d * esz; ap.dv = (char*)sc.dqkv_q + (size_t)2 * d * esz;
         ap.lddq = ap.lddk = ap.lddv = 3 * d;

@@ -205,7 +205,15 @@ struct AttnParams {
     // backward
     const void* d_o; void* dq; void* dk; void* dv; float* delta; int lddo, lddq, lddk, lddv;
     DropCfg drop;        // attn_pdrop on the probabilities (reference gpt.py:135); element = ((b*H+h)*NQ+q)*NK+key
+    // MFMA kernels, training with attention dropout: the forward writes the keep bits it evaluated, the two backward kernels read
+    // them instead of re-hashing every element (the mask was hashed three times per step: forward, dQ, dK/dV).  Layout:
+    // 16-bit fields [(b*H+h)][q][key tile of 64, padded to a multiple of 4 tiles][g = 0..3]; field bit 4*kb + r <-> key
+    // 64*tile + 16*kb + 4*g + r (the 16 score elements one lane of the forward / dQ kernels holds per tile).
+    // mebt_attn_dmask_bytes() bytes, or null: hash everywhere.
+    uint16_t* dmask = nullptr;
 };
+__host__ __device__ static inline int mebt_attn_dmask_tiles(int NK) { return 4 * ((NK + 255) / 256); }
+static inline size_t mebt_attn_dmask_bytes(int B, int H, int NQ, int NK) { return (size_t)B * H * NQ * mebt_attn_dmask_tiles(NK) * 8; }
 int launch_attn_fwd(const AttnParams& p, int dtype, hipStream_t stream);
 int launch_attn_bwd(const AttnParams& p, int dtype, hipStream_t stream);
 void mebt_attn_force_generic(int on);
