@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.29 TB/s measured with a float4 copy, same guide)
-TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 --pmc summaries, newest first
+TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 --pmc summaries, newest first
 
 
 def synthetic_batch(B, shape, rank, device):
@@ -447,19 +447,25 @@ def main():
         # HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (separate
         # FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction: tools/pmc_traffic.py).  PMC counters cannot be
         # collected inside this process; the source file is named so that a stale figure is visible.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_stale = None, None, None
         if args.dtype == "bf16" and world == 1:
+            from mebt_amd.launch import csrc_fingerprint
             for fn in TRAFFIC_FILES:
                 try:
                     with open(os.path.join(ROOT, "profiles", fn)) as f:
-                        traffic = round(json.load(f)["gemm_bf16"]["hbm_bytes_per_launch"])
+                        prof = json.load(f)
+                    traffic = round(prof["gemm_bf16"]["hbm_bytes_per_launch"])
                     traffic_src = "profiles/" + fn
+                    # a PMC profile belongs to the kernel sources it was taken on: anything else is reported as stale, not as a number
+                    traffic_stale = prof.get("_csrc_sha256") != csrc_fingerprint()
+                    if traffic_stale:
+                        traffic = None
                     break
                 except (OSError, KeyError, ValueError):
                     continue
         achieved = fl.value / (tms.value * 1e-3) / 1e12 if tms.value > 0 else 0.0
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                 "algorithmic_bytes_per_launch": round(by.value / max(1.0, nb.value)),
                 "kernel": "bf16 MFMA GEMM family (gemm_bf16_dma[_ks2] / gemm_pair / wgrad_grouped incl. its fused AdamW epilogue)" if args.dtype == "bf16" else "gemm_f32_kernel",
                 "launches_per_step": n.value / 2, "gemm_ms_per_step": round(tms.value / 2, 3),

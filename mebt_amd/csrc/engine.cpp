@@ -255,6 +255,10 @@ extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) 
             case MEBT_MODE_MASKGIT: m->live[i] = 1; m->tok_live = true; m->has_maskgit = true; break;   // gT is always defined here
         }
     }
+    // MEBT_HOST_ONLY=1 (sanitizer / layout tests on machines without a GPU): the handle answers the host-side queries
+    // (offset tables, workspace sizes, argument validation); anything that launches returns the HIP error of its first call
+    static const bool host_only = [] { const char* e = getenv("MEBT_HOST_ONLY"); return e && e[0] == '1'; }();
+    if (host_only) { m->use_side = false; *out = m; return MEBT_OK; }
     int rc = gemm_init_attributes();
     if (rc) { delete m; return rc; }
     {   // lowest priority: the leaves must never delay the critical path on the caller's stream
@@ -425,7 +429,9 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
 
 extern "C" int64_t mebt_workspace_bytes(const mebt_model* m, int32_t B, int32_t NC, int32_t NT, int32_t training) {
     if (!m || B < 0 || NC < 0 || NT < 0) return -1;
-    Carve c{nullptr, 0};
+    // measuring pass over a never-dereferenced, non-null base: sub-buffer pointers are derived by arithmetic on what take()
+    // returns, and arithmetic on a null pointer is undefined behaviour (found by the UBSan host build, `make asan`)
+    Carve c{reinterpret_cast<char*>((uintptr_t)1 << 30), 0};
     FwdCtx x;
     carve(m, c, x, B, NC, NT, training);
     return c.off + 256;

@@ -52,3 +52,18 @@ def spawn_ranks_if_needed(n_ranks, script, argv, module=False):
     rc = proc.wait()
     print(f"[launch] child exited with {rc}; parent cuda_initialized={torch.cuda.is_initialized()}", file=sys.stderr, flush=True)
     return rc
+
+
+def csrc_fingerprint():
+    """sha256 over the kernel / engine sources (mebt_amd/csrc/*.{hip,h,inc,cpp}, sorted by name): stored with a committed PMC
+    traffic profile so that bench.py can tell a stale figure (tools/pmc_traffic.py writes it, bench.py compares it)"""
+    import glob
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*"))):
+        if f.endswith((".hip", ".h", ".inc", ".cpp")):
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()

@@ -561,3 +561,20 @@ def test_golden_fixtures_regenerate_bit_identically(tmp_path):
         assert sorted(a.files) == sorted(b.files), f
         for k in a.files:
             assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), (f, k)
+
+
+def test_host_layer_under_asan_ubsan():
+    """SURVEY §5 "sanitizers" / VERDICT r02 #14: the sequencing + C-ABI layer (engine.cpp, capi.cpp, errors.cpp — workspace carving,
+    offset tables, argument validation) built with host-side AddressSanitizer + UBSan (`make -C mebt_amd/csrc asan`) and driven
+    through its host-only paths in a subprocess (tests/asan_host_driver.py; LD_PRELOAD = clang's asan runtime, MEBT_HOST_ONLY=1).
+    A finding aborts the subprocess.  (GPU sanitizers are not available on this pool; the device code is the regular build.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mk = subprocess.run(["make", "-C", os.path.join(root, "mebt_amd", "csrc"), "-j8", "asan"], capture_output=True, text=True, timeout=1500)
+    assert mk.returncode == 0, mk.stdout[-2000:] + mk.stderr[-2000:]
+    rt = subprocess.run(["/opt/rocm/bin/hipcc", "--print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    assert os.path.isfile(rt), rt
+    env = dict(os.environ, MEBT_HOST_ONLY="1", LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "asan_host_driver.py"), os.path.join(root, "mebt_amd", "lib", "libmebt_hip_asan.so"), root],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "no sanitizer finding" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]

@@ -32,4 +32,8 @@ for k in sorted(ft, key=lambda k: -ft[k]):        # every kernel (the embed gath
               "hbm_bytes_per_launch": fetch + write}
     print(f"{k:60s} n={fn[k]:5d} fetch {fetch / 1e6:8.2f} MB  write {write / 1e6:8.2f} MB per launch")
 if len(sys.argv) > 3:
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mebt_amd.launch import csrc_fingerprint
+    out["_csrc_sha256"] = csrc_fingerprint()        # bench.py nulls `roofline.traffic` when the kernels changed after this profile
     json.dump(out, open(sys.argv[3], "w"), indent=1)
