@@ -194,6 +194,14 @@ int mebt_op_sample(const float* logits, const float* noise, float temperature, i
  * interface for golden tests. */
 int mebt_op_sample_seeded(const float* logits, uint64_t seed, float temperature, int32_t top_k, float top_p, int64_t* ids,
                           float* score, float* probs, int32_t rows, int32_t V, mebt_stream_t stream);
+/* The weight gradients of one block in ONE launch (the autograd backward of nn.Linear weights and biases, gpt.py:126-128,140,150-155):
+ * item i: dW_i[n_out_i, k_in_i] = dY_i^T X_i over tokens_i rows (bf16 row-major operands) -> gW + w_off[i] (fp32); bias[i] (or NULL)
+ * += column sums of dY_i (atomic adds: zero it first).  fused != 0 applies AdamW in place of the store (optimizer-in-backward,
+ * transformer.py:665-681,790-797): W, mW, vW (+ bf16 mirror Wlp, may be NULL) at the same offsets.  n <= 8. */
+int mebt_op_wgrad_grouped(int32_t n, const void* const* dY, const void* const* X, const int32_t* n_out, const int32_t* k_in,
+                          const int32_t* tokens, const int64_t* w_off, float* const* bias, float* W, float* gW, float* mW, float* vW,
+                          void* Wlp, int32_t fused, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                          float grad_scale, mebt_stream_t stream);
 /* kth[r] = the top_k-th largest value of row r of logits [rows, V] (1 <= top_k < V): the threshold of the reference's module-level
  * `top_k_logits` (transformer.py:891-895: everything below it becomes -inf, ties are kept).  ids_scratch: [rows] int64. */
 int mebt_op_topk_threshold(const float* logits, int32_t top_k, float* kth, int64_t* ids_scratch, int32_t rows, int32_t V,

@@ -2,6 +2,7 @@
 // the kernel launchers.  The model-level entry points live in engine.cpp.
 #include "common.h"
 #include "kernels.h"
+#include <cmath>
 #include "../../include/mebt_hip.h"
 #include <string.h>
 
@@ -30,6 +31,33 @@ extern "C" int mebt_op_gemm(int32_t dtype, const void* A, const void* B, void* C
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux; p.a_kc = a_kc; p.b_kc = b_kc;
     p.epilogue = epilogue; p.c_f32 = c_f32; p.beta = beta; p.split_k = split_k;
     return launch_gemm(p, dtype, S(stream));
+}
+
+// The grouped weight-gradient launch of one block as an operator (tests, benchmarks): item i is dW_i[n_out_i, k_in_i] = dY_i^T X_i over
+// tokens_i rows (dY_i [tokens, n_out] bf16, X_i [tokens, k_in] bf16), written at gW + w_off[i] (fp32); bias[i] (or NULL) += column sums of
+// dY_i.  fused != 0: AdamW (torch semantics, step >= 1) is applied to W / mW / vW (+ the bf16 mirror Wlp) at the same offsets instead.
+extern "C" int mebt_op_wgrad_grouped(int32_t n, const void* const* dY, const void* const* X, const int32_t* n_out, const int32_t* k_in,
+                                     const int32_t* tokens, const int64_t* w_off, float* const* bias, float* W, float* gW, float* mW, float* vW,
+                                     void* Wlp, int32_t fused, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                                     float grad_scale, mebt_stream_t stream) {
+    if (n < 1 || n > MEBT_MAX_GROUP || !dY || !X || !n_out || !k_in || !tokens || !w_off || !gW) { mebt_set_error("wgrad_grouped: bad arguments"); return MEBT_EINVAL; }
+    if (fused && (!W || !mW || !vW || step < 1)) { mebt_set_error("wgrad_grouped: fused AdamW needs W, mW, vW and step >= 1"); return MEBT_EINVAL; }
+    static bool inited = false;
+    if (!inited) { if (int rc = gemm_init_attributes()) return rc; inited = true; }
+    GroupedWgrad w;
+    w.n = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!dY[i] || !X[i] || n_out[i] <= 0 || k_in[i] <= 0 || tokens[i] <= 0 || (n_out[i] % 8) || (k_in[i] % 8)) { mebt_set_error("wgrad_grouped: bad item"); return MEBT_ESHAPE; }
+        GroupedWgrad::Item& it = w.g[w.n++];
+        it.A = dY[i]; it.B = X[i]; it.C = gW + w_off[i]; it.M = n_out[i]; it.N = k_in[i]; it.K = tokens[i];
+        it.lda = n_out[i]; it.ldb = k_in[i]; it.ldc = k_in[i]; it.ntx = 0; it.bias = bias ? bias[i] : nullptr;
+    }
+    w.gW = gW;
+    if (fused) {
+        w.fused = 1; w.W = W; w.mW = mW; w.vW = vW; w.Wlp = Wlp;
+        w.opt = {lr, beta1, beta2, eps, weight_decay, (float)(1.0 - pow((double)beta1, step)), (float)(1.0 - pow((double)beta2, step)), grad_scale};
+    }
+    return launch_wgrad_grouped(w, MEBT_BF16, S(stream));
 }
 
 extern "C" int mebt_op_layernorm_fwd(int32_t dtype, const void* x, void* y, const float* gamma, const float* beta, float* mean,

@@ -400,3 +400,62 @@ def test_top_k_logits_helper_matches_reference_semantics():
     assert torch.equal(top_k_logits(lg2.to(DEV), 16384).cpu(), lg2)        # k = V: nothing is dropped
     with pytest.raises(RuntimeError, match="no CPU path"):
         top_k_logits(lg2, 5)
+
+
+def _grouped_call(items, fused, step=1, lr=1e-3, wd=0.05, with_bias=True, seed=0):
+    """items: [(n_out, k_in, tokens)]; returns (gW, bias grads, W, mW, vW, Wlp, refs)"""
+    import ctypes as C
+    g = torch.Generator().manual_seed(seed)
+    n = len(items)
+    offs, tot = [], 0
+    for no, ki, _ in items:
+        offs.append(tot)
+        tot += no * ki
+    dYs = [(torch.randn(t, no, generator=g) * 0.5).to(torch.bfloat16).to(DEV) for no, ki, t in items]
+    Xs = [(torch.randn(t, ki, generator=g) * 0.5).to(torch.bfloat16).to(DEV) for no, ki, t in items]
+    W = (torch.randn(tot, generator=g) * 0.02).to(DEV)
+    mW, vW = (torch.randn(tot, generator=g) * 1e-3).to(DEV), (torch.rand(tot, generator=g) * 1e-5).to(DEV)
+    gW = torch.zeros(tot, device=DEV)
+    Wlp = W.to(torch.bfloat16)
+    biases = [torch.zeros(no, device=DEV) for no, _, _ in items]
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    i32 = lambda vs: (C.c_int32 * n)(*vs)
+    ref = {"W": W.clone(), "m": mW.clone(), "v": vW.clone()}
+    check(lib().mebt_op_wgrad_grouped(n, arr(dYs), arr(Xs), i32([i[0] for i in items]), i32([i[1] for i in items]), i32([i[2] for i in items]),
+                                      (C.c_int64 * n)(*offs), arr(biases) if with_bias else None, ptr(W), ptr(gW), ptr(mW), ptr(vW), ptr(Wlp),
+                                      1 if fused else 0, lr, 0.9, 0.95, 1e-8, wd, step, 1.0, cur_stream()))
+    torch.cuda.synchronize()
+    grads = [dY.float().t() @ X.float() for dY, X in zip(dYs, Xs)]
+    bsum = [dY.float().sum(0) for dY in dYs]
+    return gW, biases, W, mW, vW, Wlp, offs, grads, bsum, ref
+
+
+@pytest.mark.parametrize("items", [[(256, 128, 200), (128, 512, 200), (128, 128, 77)], [(64, 64, 24), (256, 64, 24), (64, 256, 9)],
+                                   [(1024, 1024, 384), (4096, 1024, 384), (1024, 4096, 384), (2048, 1024, 768)]])
+def test_wgrad_grouped_operator(items):
+    """`mebt_op_wgrad_grouped`: the weight gradients of a block in one launch against fp32 matmuls of the same bf16 operands —
+    the stored gradients, the bias gradients added up inside the launch (tile column 0, ones-fragment MFMA), and the
+    optimizer-in-backward form against torch-semantics AdamW on those gradients.  Ragged tiles (64-wide weights under 128-wide
+    tiles) and ragged reductions (tokens not a multiple of the 64-deep k-tile)."""
+    gW, biases, W, mW, vW, Wlp, offs, grads, bsum, ref = _grouped_call(items, fused=False)
+    for (no, ki, t), o, gr, b, bs in zip(items, offs, grads, biases, bsum):
+        got = gW[o:o + no * ki].view(no, ki)
+        assert (got - gr).abs().max().item() <= 2e-4 * max(1.0, gr.abs().max().item()), (no, ki, t)
+        assert (b - bs).abs().max().item() <= 2e-4 * max(1.0, bs.abs().max().item()), (no, ki, t)
+    assert torch.equal(W, ref["W"]) and torch.equal(mW, ref["m"])
+    # fused AdamW, step 3: p, m, v, bf16 mirror from the same gradients (torch.optim.AdamW semantics)
+    lr, wd, b1, b2, step = 1e-3, 0.05, 0.9, 0.95, 3
+    gW2, biases2, W2, mW2, vW2, Wlp2, offs, grads, bsum, ref = _grouped_call(items, fused=True, step=step, lr=lr, wd=wd)
+    assert float(gW2.abs().max()) == 0.0                       # the gradient is applied, not stored
+    for (no, ki, t), o, gr, b, bs in zip(items, offs, grads, biases2, bsum):
+        sl = slice(o, o + no * ki)
+        g_ = gr.reshape(-1)
+        m_ = b1 * ref["m"][sl] + (1 - b1) * g_
+        v_ = b2 * ref["v"][sl] + (1 - b2) * g_ * g_
+        p_ = ref["W"][sl] * (1 - lr * wd) - (lr / (1 - b1 ** step)) * m_ / (v_.sqrt() / (1 - b2 ** step) ** 0.5 + 1e-8)
+        assert (mW2[sl] - m_).abs().max().item() <= 2e-4 * m_.abs().max().item()
+        assert (vW2[sl] - v_).abs().max().item() <= 4e-4 * v_.abs().max().item()
+        # |dp| per step is bounded by ~lr; where v is tiny the quotient amplifies the gradient's summation-order noise
+        assert (W2[sl] - p_).abs().max().item() <= 2e-2 * lr, (no, ki, t, (W2[sl] - p_).abs().max().item())
+        assert torch.equal(Wlp2[sl], W2[sl].to(torch.bfloat16))
+        assert (b - bs).abs().max().item() <= 2e-4 * max(1.0, bs.abs().max().item())
