@@ -475,8 +475,8 @@ def sample(P, cfg, x, n_steps, temperature, top_k, top_p, context_temperature, n
             partial_probs.scatter_(1, ti.unsqueeze(-1).expand(-1, -1, probs.shape[-1]), probs)
         ctemp = context_temperature * ctemp_factor(ctemp_schedule, t_next)  # :440
         if trace is not None:
-            trace.append({"NC": ci.shape[1], "NT": ti.shape[1], "ids": ids.clone(),
-                          "ci": ci.clone(), "ti": ti.clone()})
+            trace.append({"NC": ci.shape[1], "NT": ti.shape[1], "ids": ids.clone(), "ci": ci.clone(), "ti": ti.clone(),
+                          "scores": scores.clone(), "ctemp": float(ctemp), "n_masked": int(n_masked[0])})
         rn = noise_fn("randn", scores.shape) if strategy in ("random", "bootstrap") else None
         ci, ti = generate_next_mask(ci, ti, scores, n_masked[0].long(), strategy, ctemp,
                                     lambda: noise_fn("mask", scores.shape), rn)   # :444
