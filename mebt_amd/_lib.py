@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmebt_hip.so")
+# MEBT_HIP_LIB: another BUILD of the same library (tools/ab_bench.sh times two builds on one box); same ABI, same failure if absent
+LIB_PATH = os.environ.get("MEBT_HIP_LIB") or os.path.join(_HERE, "lib", "libmebt_hip.so")
 
 MEBT_MAX_LAYERS = 128
 F32, BF16, F16 = 0, 1, 2

@@ -2,6 +2,7 @@
 // per-layout translation units (gemm_kk/kr/rr/rk.hip, which hold the bf16 kernel instantiations; the device code and
 // the design notes are in gemm_kernels.h).  The fp32 parity kernel and the split-K reduce kernel are instantiated here.
 #include "gemm_kernels.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -20,6 +21,10 @@ void mebt_gemm_w8_kk(const GemmParams&, int, hipStream_t);
 void mebt_gemm_w8_kr(const GemmParams&, int, hipStream_t);
 void mebt_gemm_w8_rr(const GemmParams&, int, hipStream_t);
 void mebt_gemm_w8_rk(const GemmParams&, int, hipStream_t);
+void mebt_gemm_pp_kk(const GemmParams&, hipStream_t);
+void mebt_gemm_pp_kr(const GemmParams&, hipStream_t);
+void mebt_gemm_pp_rr(const GemmParams&, hipStream_t);
+void mebt_gemm_pp_rk(const GemmParams&, hipStream_t);
 int mebt_gemm_attrs_kk(); int mebt_gemm_attrs_kr(); int mebt_gemm_attrs_rr(); int mebt_gemm_attrs_rk();
 void mebt_gemm_pair_kk(GemmPair&, int, int, int, hipStream_t);
 void mebt_gemm_pair_kr(GemmPair&, int, int, int, hipStream_t);
@@ -67,6 +72,10 @@ extern "C" void mebt_debug_gemm_scratch(void* buf, int64_t bytes) {
     g_default_scratch = {buf, MEBT_TUNE_FLUSH_BYTES, (float*)((char*)buf + MEBT_TUNE_FLUSH_BYTES), (size_t)bytes - MEBT_TUNE_FLUSH_BYTES};
 }
 static void launch_bf16_config(const GemmParams& p, int tbm, int tbn, int staging, int split, hipStream_t stream) {
+    if (tbm == 256 && tbn == 256 && staging == 9 && p.a_kc && p.K % BK == 0) {   // two staggered wave groups (gemm_bf16_pp_kernel)
+        if (p.b_kc) mebt_gemm_pp_kk(p, stream); else mebt_gemm_pp_kr(p, stream);
+        return;
+    }
     if (tbm == 256 && tbn == 256) {   // the 8-wave tile: whole reduction in the workgroup, ring 2
         if (p.a_kc && p.b_kc) mebt_gemm_w8_kk(p, 2, stream);
         else if (p.a_kc && !p.b_kc) mebt_gemm_w8_kr(p, 2, stream);
@@ -218,6 +227,8 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
     static const int tiles[7][2] = {{192, 128}, {128, 128}, {96, 128}, {128, 64}, {64, 128}, {96, 64}, {64, 64}};
     const long out = (long)p.M * p.N;
     float best = 1e30f;
+    struct Cand { float ms; int bm, bn, staging; };
+    std::vector<Cand> cands;
     for (int t = 0; t < 7; ++t) {
         const int bm = tiles[t][0], bn = tiles[t][1];
         const long nt = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
@@ -227,6 +238,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
             float ms = 0.f;
             if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, st, 1, stream); }, stream, tr, ms)) return rc;
             if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d: %.1f us\n", bm, bn, st, ms * 1e3f);
+            cands.push_back({ms, bm, bn, st});
             if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = st; }
         }
         for (int st = 2; st <= 4 && !few; ++st) {                                 // software-pipelined main loop (staging 8 + ring depth)
@@ -234,6 +246,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
             float ms = 0.f;
             if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, 8 + st, 1, stream); }, stream, tr, ms)) return rc;
             if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d pipelined: %.1f us\n", bm, bn, st, ms * 1e3f);
+            cands.push_back({ms, bm, bn, 8 + st});
             if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = 8 + st; }
         }
         if (!p.c_f32 && p.C && nt <= 256 && (long)bm * bn >= 128 * 128)          // split-K into fp32 slabs + reduce/epilogue kernel (staging 32 * log2(S) + ring)
@@ -246,6 +259,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
                     if (int rc = time_cold([&] { rc2 |= launch_bf16_splitk(p, bm, bn, st, S, stream); }, stream, tr, ms)) return rc;
                     if (rc2) return rc2;
                     if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d split-K %d: %.1f us\n", bm, bn, st, S, ms * 1e3f);
+                    cands.push_back({ms, bm, bn, (S == 2 ? 32 : 64) + st});
                     if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = (S == 2 ? 32 : 64) + st; }
                 }
             }
@@ -255,6 +269,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
                 float ms = 0.f;
                 if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, 16 + st, 1, stream); }, stream, tr, ms)) return rc;
                 if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d x2 pipelines: %.1f us\n", bm, bn, st, ms * 1e3f);
+                cands.push_back({ms, bm, bn, 16 + st});
                 if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = 16 + st; }
             }
     }
@@ -262,7 +277,39 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
         float ms = 0.f;
         if (int rc = time_cold([&] { launch_bf16_config(p, 256, 256, 2, 1, stream); }, stream, tr, ms)) return rc;
         if (g_tune_log >= 2) fprintf(stderr, "    cand 256x256 (8 waves): %.1f us\n", ms * 1e3f);
+        cands.push_back({ms, 256, 256, 2});
         if (ms < best) { best = ms; tbm = 256; tbn = 256; staging = 2; }
+        if (p.a_kc && p.K % BK == 0) {                     // the same tile as two staggered wave groups (staging code 9)
+            if (int rc = time_cold([&] { launch_bf16_config(p, 256, 256, 9, 1, stream); }, stream, tr, ms)) return rc;
+            if (g_tune_log >= 2) fprintf(stderr, "    cand 256x256 (2 x 4 waves, staggered): %.1f us\n", ms * 1e3f);
+            cands.push_back({ms, 256, 256, 9});
+            if (ms < best) { best = ms; tbm = 256; tbn = 256; staging = 9; }
+        }
+    }
+    // Second round.  The sweep's minimum over ~40 two-sample means is biased towards a lucky sample (run-to-run the choice moved
+    // between neighbours and the step time with it, +-0.1 ms at config 2): the four fastest are timed again, three more cold pairs
+    // each, and the best mean of all eight samples wins.
+    std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.ms < b.ms; });
+    const int finalists = (int)std::min<size_t>(4, cands.size());
+    if (finalists > 1) {
+        best = 1e30f;
+        for (int c = 0; c < finalists; ++c) {
+            Cand& k = cands[c];
+            float sum = k.ms;
+            for (int r = 0; r < 3; ++r) {
+                float ms = 0.f;
+                int rc2 = MEBT_OK;
+                if (int rc = time_cold([&] {
+                        if (k.staging >= 32 && k.bm != 256) rc2 |= launch_bf16_splitk(p, k.bm, k.bn, k.staging & 15, k.staging >= 64 ? 4 : 2, stream);
+                        else launch_bf16_config(p, k.bm, k.bn, k.staging, 1, stream);
+                    }, stream, tr, ms)) return rc;
+                if (rc2) return rc2;
+                sum += ms;
+            }
+            k.ms = sum / 4;
+            if (g_tune_log >= 2) fprintf(stderr, "    finalist %dx%d code %d: %.1f us (mean of 8)\n", k.bm, k.bn, k.staging, k.ms * 1e3f);
+            if (k.ms < best) { best = k.ms; tbm = k.bm; tbn = k.bn; staging = k.staging; }
+        }
     }
     if (g_tune_log)
         fprintf(stderr, "[mebt gemm autotune] M=%d N=%d K=%d a_kc=%d b_kc=%d epi=%d c_f32=%d -> %dx%d ring %d%s (%.1f us cold)\n", p.M, p.N, p.K,
@@ -272,6 +319,8 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
 
 int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     GemmParams p = p_in;
+    static const int narrow = [] { const char* e = getenv("MEBT_EPI_NARROW"); return (e && e[0] == '1') ? 1 : 0; }();
+    p.narrow_store = narrow;
     if (p.M <= 0 || p.N <= 0) return MEBT_OK;
     drop_mark_small(p.drop, (uint64_t)p.M * p.ldc);        // the residual epilogue's dropout indexes row * ldc + column
     if (p.N % 4 != 0) { mebt_set_error("gemm: N must be a multiple of 4"); return MEBT_ESHAPE; }

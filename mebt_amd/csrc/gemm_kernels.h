@@ -138,6 +138,24 @@ __device__ __forceinline__ void epilogue_adamw(const GemmParams& p, const f32x4 
     }
 }
 
+// Stores of the plain epilogues.  Every lane owns EIGHT consecutive columns of a row, so that a bf16 output leaves as one 16-byte
+// store per lane: the store tail of a tile is bound by store INSTRUCTIONS, not bytes (8-byte stores: ≈7 B/clk/CU — 128 KiB of a
+// 256 x 256 bf16 tile took ≈9 us, as long as its whole K = 1024 main loop; profiles/r03_pp_bench_components.txt), and 16-byte stores
+// halve the count.  `wide` = the row pitch and the column keep 16-byte alignment; otherwise (N or ldc not a multiple of 8) the two
+// 4-column halves go out separately, each only if its columns exist.
+template <typename T>
+__device__ __forceinline__ void store8(T* c, const f32x4& lo, const f32x4& hi, bool ok_hi, bool wide) {
+    if constexpr (sizeof(T) == 2) {
+        if (wide && ok_hi) {
+            const bf16x8 o = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3], (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+            *reinterpret_cast<bf16x8*>(c) = o;
+            return;
+        }
+    }
+    store4<T>(c, lo);
+    if (ok_hi) store4<T>(c + 4, hi);
+}
+
 template <int TM, int TN, bool SYNC = true>
 __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x4 (&acc)[TM][TN], char* smem, int wave, int lane,
                                                  int mbase, int nbase, bool add_bias, bool atomic) {
@@ -145,25 +163,37 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x
     if (p.epilogue == EPI_ADAMW) { epilogue_adamw<TM, TN>(p, acc, smem, wave, lane, mbase, nbase); return; }
     constexpr int COLS = TN * 16, LD = COLS + 4;          // fp32 elements per staged row
     float* st = reinterpret_cast<float*>(smem) + wave * (16 * LD);   // one 16-row slab per wave (<= 4.3 KiB)
-    constexpr int LPR = COLS / 4;                         // lanes per row
+    constexpr int LPR = COLS / 8;                         // lanes per row (8 columns each)
     constexpr int RPI = 64 / LPR;                         // rows per pass
     constexpr int NPASS = 16 / RPI;
-    const int r0 = lane / LPR, c4 = (lane % LPR) * 4;
-    const int n = nbase + c4;
-    const bool n_ok = n < p.N;
-    const int nc = n_ok ? n : 0;
+    static_assert(NPASS >= 1, "wave tiles are at least 32 columns wide");
+    const int r0 = lane / LPR, c8 = (lane % LPR) * 8;
+    const int n = nbase + c8;
+    const bool n_ok = n < p.N, hi_ok = n + 4 < p.N;
+    const bool wide = !p.narrow_store && (p.ldc & 7) == 0 && (p.ld_aux & 7) == 0 && (((size_t)p.C | (size_t)p.C2 | (size_t)p.aux) & 15) == 0;
+    const int nc = n_ok ? n : 0, nh = hi_ok ? n + 4 : nc;
     const bool need_aux = p.epilogue == EPI_RESID || p.epilogue == EPI_GELU_BWD;
-    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (add_bias && p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + nc);
-    bf16x4 auxr[TM][NPASS];
+    f32x4 bias_lo = {0.f, 0.f, 0.f, 0.f}, bias_hi = {0.f, 0.f, 0.f, 0.f};
+    if (add_bias && p.bias) {
+        bias_lo = *reinterpret_cast<const f32x4*>(p.bias + nc);
+        bias_hi = *reinterpret_cast<const f32x4*>(p.bias + nh);
+    }
+    bf16x4 aux_lo[TM][NPASS], aux_hi[TM][NPASS];
     if (need_aux) {
-        const TA* aux = reinterpret_cast<const TA*>(p.aux) + nc;
+        const TA* aux = reinterpret_cast<const TA*>(p.aux);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < NPASS; ++r) {
                 const int m = min(mbase + i * 16 + r * RPI + r0, p.M - 1);
-                auxr[i][r] = *reinterpret_cast<const bf16x4*>(aux + (size_t)m * p.ld_aux);
+                if (wide && hi_ok) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(aux + (size_t)m * p.ld_aux + nc);
+                    aux_lo[i][r] = bf16x4{a[0], a[1], a[2], a[3]};
+                    aux_hi[i][r] = bf16x4{a[4], a[5], a[6], a[7]};
+                } else {
+                    aux_lo[i][r] = *reinterpret_cast<const bf16x4*>(aux + (size_t)m * p.ld_aux + nc);
+                    aux_hi[i][r] = *reinterpret_cast<const bf16x4*>(aux + (size_t)m * p.ld_aux + nh);
+                }
             }
     }
     if (SYNC) __syncthreads();                            // every wave is done reading the last k-tile
@@ -178,40 +208,49 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x
 #pragma unroll
         for (int r = 0; r < NPASS; ++r) {
             const int row = r * RPI + r0;
-            f32x4 v = *reinterpret_cast<const f32x4*>(st + row * LD + c4);
+            f32x4 lo = *reinterpret_cast<const f32x4*>(st + row * LD + c8);
+            f32x4 hi = *reinterpret_cast<const f32x4*>(st + row * LD + c8 + 4);
             const int m = mbase + i * 16 + row;
             if (!(m < p.M && n_ok)) continue;
-            v += bias;
+            lo += bias_lo;
+            hi += bias_hi;
             const size_t ci = (size_t)m * p.ldc + n;
             if (atomic) {
                 float* c = reinterpret_cast<float*>(p.C) + ci;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) atomicAdd(c + j, v[j]);
+                for (int j = 0; j < 4; ++j) atomicAdd(c + j, lo[j]);
+                if (hi_ok)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) atomicAdd(c + 4 + j, hi[j]);
                 continue;
             }
             if (p.epilogue == EPI_GELU) {
-                f32x4 g;
+                f32x4 glo, ghi;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = gelu_fast(v[j]);
-                store4<TA>(reinterpret_cast<TA*>(p.C2) + ci, g);
+                for (int j = 0; j < 4; ++j) { glo[j] = gelu_fast(lo[j]); ghi[j] = gelu_fast(hi[j]); }
+                store8<TA>(reinterpret_cast<TA*>(p.C2) + ci, glo, ghi, hi_ok, wide);
             } else if (p.epilogue == EPI_RESID) {
                 if (p.drop.thresh) {
                     const uint64_t e0 = (uint64_t)m * p.N + n;
-                    v *= drop_keep4(p.drop, e0);
+                    lo *= drop_keep4(p.drop, e0);
+                    hi *= drop_keep4(p.drop, e0 + 4);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += (float)auxr[i][r][j];
+                for (int j = 0; j < 4; ++j) { lo[j] += (float)aux_lo[i][r][j]; hi[j] += (float)aux_hi[i][r][j]; }
             } else if (p.epilogue == EPI_GELU_BWD) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= gelu_grad_fast((float)auxr[i][r][j]);
+                for (int j = 0; j < 4; ++j) { lo[j] *= gelu_grad_fast((float)aux_lo[i][r][j]); hi[j] *= gelu_grad_fast((float)aux_hi[i][r][j]); }
             }
             if (!p.C) continue;                 // EPI_GELU in inference: only gelu(C) is needed
             if (p.c_f32) {
                 float* c = reinterpret_cast<float*>(p.C) + ci;
-                if (p.beta) v += *reinterpret_cast<const f32x4*>(c);
-                *reinterpret_cast<f32x4*>(c) = v;
+                if (p.beta) {
+                    lo += *reinterpret_cast<const f32x4*>(c);
+                    if (hi_ok) hi += *reinterpret_cast<const f32x4*>(c + 4);
+                }
+                store8<float>(c, lo, hi, hi_ok, wide);
             } else {
-                store4<TA>(reinterpret_cast<TA*>(p.C) + ci, v);
+                store8<TA>(reinterpret_cast<TA*>(p.C) + ci, lo, hi, hi_ok, wide);
             }
         }
     }
@@ -788,6 +827,148 @@ __global__ __launch_bounds__(512) void gemm_bf16_w8_kernel(const GemmParams p) {
     prefetch_sink(p, pfr);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves in two staggered groups ("ping-pong"): while the four waves of one group (one per SIMD) issue their
+// 16 MFMAs of a phase, the four waves of the other group read the fragments of their next phase from LDS and issue the LDS-DMA
+// of a later k-tile; at the next s_barrier the roles swap.  Every SIMD's matrix pipe then has a wave ready in every slot — the
+// structure the one-barrier-per-k-tile loops above lack when only one workgroup fits a CU (their waves read, wait and multiply
+// in lock-step: 38 % MFMA issue rate at 192 x 256).  Geometry: waves 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4
+// fragments, processed as four quadrant phases of 64 x 32 x 64 (16 MFMAs); k-tile 64; LDS = 2 k-tile buffers x {B half 0, B half 1,
+// A half 0, A half 1} x 16 KiB = 128 KiB.  Group g = wave >> 2 owns A half g; the waves of both groups read both B halves.
+//
+// Slots (one s_barrier each).  Slot s = 8 t + 2 ph + g is the LOAD part of phase ph of k-tile t for group g and the MFMA part of
+// the other group's previous phase.  Reads of k-tile t: B in slots 8t .. 8t+3 (phases 0, 1; B of quadrant column 0 is kept in
+// registers for phase 3), A half 0 in 8t and 8t+4, A half 1 in 8t+1 and 8t+5.  Its buffer is refilled with k-tile t + 2 in 8-KiB
+// chunks, one per slot, issued by the loading group (2 pieces per wave): chunk c (B0 lo, B0 hi, B1 lo, B1 hi, A0 lo, ...) in slot
+// 8t + 5 + c — at least two slots after the last read of what it overwrites, at least four before its first read.  Each group
+// waits once per k-tile, at the end of its phase-3 LOAD part (g = 0: vmcnt(2), g = 1: vmcnt(4): everything but the pieces of
+// k-tile t + 3 it has just issued), one slot before the first read of k-tile t + 1's successor.
+// ------------------------------------------------------------------------------------------------
+// DBG (tools/pp_bench.hip only): bit 0 = no refill DMA in the loop, bit 1 = no MFMAs, bit 2 = no fragment reads
+template <bool B_KC, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HALF = 128 * BK * 2;                       // one half-tile image: 16 KiB
+    constexpr int TILE = 4 * HALF;                           // [B0 | B1 | A0 | A1]
+    const int ntx = gridDim.x, nty = gridDim.y;
+    const PrefetchRegs pfr = prefetch_next(p, blockIdx.y * ntx + blockIdx.x, ntx * nty, 512);
+    int tr, tc;
+    xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
+    const int m0 = tr * 256, n0 = tc * 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;                // group = A half; wq = the wave's 64-column slice of the tile
+    const int nk = p.K / BK;
+
+    // ---- DMA addressing.  Piece i (0 .. 15) of a half-tile = 1 KiB: KC: rows 8 i .. 8 i + 7 x 128 B;  RC: k-rows 4 i .. 4 i + 3 x 256 B.
+    // Per lane the offset of piece i is base(i & 1 pattern) + (i >> 1) * stride2: the swizzle term repeats with period 2 (KC) / 1 (RC).
+    const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* Bb = reinterpret_cast<const bf16_t*>(p.B);
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(Ab + (size_t)m0 * p.lda, (size_t)(p.M - m0) * p.lda * 2);
+    const __amdgpu_buffer_rsrc_t rB = B_KC ? make_rsrc(Bb + (size_t)n0 * p.ldb, (size_t)(p.N - n0) * p.ldb * 2) : make_rsrc(Bb, (size_t)p.K * p.ldb * 2);
+    auto kc_off = [&](int piece, int ld) -> uint32_t {       // byte offset of this lane's 16 B of piece `piece` inside a KC half-tile at k-tile 0
+        const int row = 8 * piece + (lane >> 3), slot = lane & 7;
+        return ((uint32_t)row * ld + 8 * (slot ^ ((row >> 1) & 7))) * 2;
+    };
+    auto rc_off = [&](int piece, int half) -> uint32_t {     // B stored [K][N]: image [64 k][128 columns]
+        const int id = 64 * piece + lane, krow = id >> 4, slot = id & 15;
+        const int col = n0 + 128 * half + 8 * (slot ^ rc_swizzle<128>(krow));
+        return col < p.N ? ((uint32_t)krow * p.ldb + col) * 2 : (uint32_t)MEBT_OOB;
+    };
+    const uint32_t a_step = BK * 2, b_step = B_KC ? BK * 2 : (uint32_t)BK * p.ldb * 2;
+    // chunk c of a k-tile: half-tile c >> 1 (0, 1 = B halves; 2, 3 = A halves), pieces 8 (c & 1) + 2 wq + {0, 1}
+    auto issue_chunk = [&](char* buf, int c, int kt) {
+        const int h = c >> 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = 8 * (c & 1) + 2 * wq + j;
+            const unsigned dst = (unsigned)(size_t)(lds_char_ptr)(buf + h * HALF + piece * 1024);
+            if (h >= 2) dma16(rA, dst, kc_off(piece, p.lda) + (uint32_t)(h - 2) * 128 * p.lda * 2 + (uint32_t)kt * a_step);
+            else if (B_KC) dma16(rB, dst, kc_off(piece, p.ldb) + (uint32_t)h * 128 * p.ldb * 2 + (uint32_t)kt * b_step);
+            else { const uint32_t o = rc_off(piece, h); dma16(rB, dst, o == (uint32_t)MEBT_OOB ? o : o + (uint32_t)kt * b_step); }
+        }
+    };
+    // prologue: k-tiles 0 and 1 completely (each wave: its two pieces of every chunk position of its parity ... simply all 8 chunks,
+    // the two groups taking the low / high half of every half-tile: chunk parity = group)
+    for (int t0 = 0; t0 < 2 && t0 < nk && !(DBG & 16); ++t0)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) issue_chunk(smem + t0 * TILE, 2 * h + grp, t0);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();              // the stagger: group 1 runs one slot behind group 0
+
+    const int bhalf = wq >> 1, bblk = (wq & 1) * 4;          // the wave's B fragments: half-tile wq >> 1, 16-row blocks bblk .. bblk + 3
+    bf16x8 af[2][4] = {}, bq0[2][2] = {}, bq1[2][2] = {};
+    for (int t = 0; t < nk; ++t) {
+        char* buf = smem + (t & 1) * TILE;
+        const char* sB = buf + bhalf * HALF;
+        const char* sA = buf + (2 + grp) * HALF;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            // ------------------------------------------------ LOAD part of phase ph (slot s = 8 t + 2 ph + grp)
+            if (ph == 0 && !(DBG & 4)) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) bq0[ks][jj] = read_frag<B_KC, 128>(sB, bblk + jj, ks, lane);
+            }
+            if (ph == 1 && !(DBG & 4)) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) bq1[ks][jj] = read_frag<B_KC, 128>(sB, bblk + 2 + jj, ks, lane);
+            }
+            if ((ph == 0 || ph == 2) && !(DBG & 4)) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) af[ks][ii] = read_frag<true, 128>(sA, (ph >> 1) * 4 + ii, ks, lane);
+            }
+            if (!(DBG & 1)) {   // one 8-KiB chunk of k-tile tau = (s - 5) / 8 + 2 per slot
+                const int u = 8 * t + 2 * ph + grp - 5;
+                if (u >= 0) {
+                    const int tau = (u >> 3) + 2;
+                    if (tau < nk) issue_chunk(smem + (tau & 1) * TILE, u & 7, tau);
+                }
+            }
+            if (ph == 3) {                                   // every piece of k-tile t + 1 this wave issued has landed; still in flight: its pieces of t + 2
+                if (t + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (none of those in the tail)
+                else if (grp == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ------------------------------------------------ MFMA part of phase ph: quadrant (ph >> 1, (ph == 1 || ph == 2))
+            __builtin_amdgcn_s_setprio(1);
+            if (!(DBG & 2))
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int i = (ph >> 1) * 4 + ii;
+                        if (ph == 1 || ph == 2) acc[i][2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq1[ks][jj], af[ks][ii], acc[i][2 + jj], 0, 0, 0);
+                        else acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq0[ks][jj], af[ks][ii], acc[i][jj], 0, 0, 0);
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();              // group 0 waits for group 1's last slot
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(DBG & 8)) epilogue_via_lds<8, 4>(p, acc, smem, wave, lane, m0 + grp * 128, n0 + wq * 64, true, false);
+    else if (acc[0][0][0] == 123.f) *reinterpret_cast<float*>(p.C) = acc[7][3][1];
+    prefetch_sink(p, pfr);
+}
+
 // two pipelines per workgroup (KS = 2): whole reduction in one workgroup, K a multiple of 128
 template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE>
 __global__ __launch_bounds__(512) void gemm_bf16_dma_ks2_kernel(const GemmParams p) {
@@ -1171,6 +1352,13 @@ static void layout_launch_w8(const GemmParams& p, int ring, hipStream_t stream) 
     hipLaunchKernelGGL((gemm_bf16_w8_kernel<AK, BKC, 2>), grid, dim3(512), 2 * 512 * BK * 2, stream, p);
 }
 
+// the staggered two-group 256 x 256 kernel: A KC only, K a multiple of 64
+template <bool AK, bool BKC>
+static void layout_launch_pp(const GemmParams& p, hipStream_t stream) {
+    const dim3 grid((p.N + 255) / 256, (p.M + 255) / 256, 1);
+    if (AK) hipLaunchKernelGGL((gemm_bf16_pp_kernel<BKC>), grid, dim3(512), 8 * 128 * BK * 2, stream, p);
+}
+
 // dynamic-LDS attributes of every instantiation of one operand layout (called once per process)
 template <bool AK, bool BKC>
 static int layout_set_attrs() {
@@ -1203,6 +1391,7 @@ static int layout_set_attrs() {
     SET_PIPE(128, 128); SET_PIPE(192, 128); SET_PIPE(96, 128); SET_PIPE(96, 64); SET_PIPE(128, 64); SET_PIPE(64, 128); SET_PIPE(64, 64);
 #undef SET_PIPE
     MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w8_kernel<AK, BKC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * BK * 2));
+    if (AK) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * BK * 2));
     SET_K(96, 64); SET_K(64, 64); SET_K(96, 128); SET_K(64, 128); SET_K(128, 64);
 #undef SET_K
 #undef SET_D

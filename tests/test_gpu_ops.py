@@ -89,6 +89,24 @@ def test_gemm_every_tile_variant(tile, a_kc, b_kc, staging):
     assert torch.equal(out.double(), ref), (out.double() - ref).abs().max()
 
 
+@pytest.mark.parametrize("b_kc", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(328, 200, 64), (256, 256, 128), (520, 776, 192), (300, 264, 320), (1024, 512, 1024), (513, 1032, 2048)])
+def test_gemm_staggered_groups_256(M, N, K, b_kc):
+    """the 256 x 256 tile as two staggered 4-wave groups (variant 9; A row-major-in-k only): every k-tile count from the
+    prologue-only cases (1, 2) through the refill schedule's steady state, ragged M / N, exact on integers"""
+    Am, Bm = rnd(M, K, seed=31, ints=True), rnd(N, K, seed=32, ints=True)
+    ref = Am.double() @ Bm.double().t()
+    B = Bm if b_kc else Bm.t().contiguous()
+    lib().mebt_debug_gemm_tile(256, 256)
+    lib().mebt_debug_gemm_variant(9)
+    try:
+        out, _ = run_gemm(_lib.BF16, Am, B, M, N, K, 1, b_kc, c_f32=1)
+    finally:
+        lib().mebt_debug_gemm_tile(0, 0)
+        lib().mebt_debug_gemm_variant(-1)
+    assert torch.equal(out.double(), ref), (out.double() - ref).abs().max()
+
+
 @pytest.mark.parametrize("ring", [2, 3])
 @pytest.mark.parametrize("tile", [(96, 64), (64, 64), (96, 128), (64, 128), (128, 64)])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0), (0, 1)])
