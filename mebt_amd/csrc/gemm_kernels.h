@@ -838,11 +838,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_w8_kernel(const GemmParams p) {
 //
 // Slots (one s_barrier each).  Slot s = 8 t + 2 ph + g is the LOAD part of phase ph of k-tile t for group g and the MFMA part of
 // the other group's previous phase.  Reads of k-tile t: B in slots 8t .. 8t+3 (phases 0, 1; B of quadrant column 0 is kept in
-// registers for phase 3), A half 0 in 8t and 8t+4, A half 1 in 8t+1 and 8t+5.  Its buffer is refilled with k-tile t + 2 in 8-KiB
-// chunks, one per slot, issued by the loading group (2 pieces per wave): chunk c (B0 lo, B0 hi, B1 lo, B1 hi, A0 lo, ...) in slot
-// 8t + 5 + c — at least two slots after the last read of what it overwrites, at least four before its first read.  Each group
-// waits once per k-tile, at the end of its phase-3 LOAD part (g = 0: vmcnt(2), g = 1: vmcnt(4): everything but the pieces of
-// k-tile t + 3 it has just issued), one slot before the first read of k-tile t + 1's successor.
+// registers for phase 3), A half 0 in 8t and 8t+4, A half 1 in 8t+1 and 8t+5.  Its buffer is refilled with k-tile t + 2 as early as
+// the reads allow, a whole 16-KiB half-tile per slot issued by the loading group (4 pieces per wave): B half 0 in slot 8t+4 (group
+// 0, phase 2), B half 1 in 8t+5 (group 1, phase 2), A half 0 in 8t+6 (group 0, phase 3), A half 1 in 8t+7 (group 1, phase 3) —
+// a full k-tile (64 KiB) is in flight for eight slots, the depth the fill needs (issued -> landed is ~0.8 us under load; spreading
+// the same pieces evenly over slots 8t+5 .. 8t+12 left the last ones three slots and the loop waited for them: 1.6 instead of 1.0 us
+// per k-tile, profiles/r03_pp_bench_components.txt).  The B reads of phase 1 are drained before that slot's barrier, so every
+// overwrite is issued at least one barrier after the last read of its target has completed.  Each group waits once per k-tile, at
+// the end of its phase-3 LOAD part: vmcnt(8) = everything but the two half-tile shares of k-tile t + 2 it has just issued.
 // ------------------------------------------------------------------------------------------------
 // DBG (tools/pp_bench.hip only): bit 0 = no refill DMA in the loop, bit 1 = no MFMAs, bit 2 = no fragment reads
 template <bool B_KC, int DBG = 0>
@@ -876,23 +879,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         return col < p.N ? ((uint32_t)krow * p.ldb + col) * 2 : (uint32_t)MEBT_OOB;
     };
     const uint32_t a_step = BK * 2, b_step = B_KC ? BK * 2 : (uint32_t)BK * p.ldb * 2;
-    // chunk c of a k-tile: half-tile c >> 1 (0, 1 = B halves; 2, 3 = A halves), pieces 8 (c & 1) + 2 wq + {0, 1}
-    auto issue_chunk = [&](char* buf, int c, int kt) {
-        const int h = c >> 1;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int piece = 8 * (c & 1) + 2 * wq + j;
-            const unsigned dst = (unsigned)(size_t)(lds_char_ptr)(buf + h * HALF + piece * 1024);
-            if (h >= 2) dma16(rA, dst, kc_off(piece, p.lda) + (uint32_t)(h - 2) * 128 * p.lda * 2 + (uint32_t)kt * a_step);
-            else if (B_KC) dma16(rB, dst, kc_off(piece, p.ldb) + (uint32_t)h * 128 * p.ldb * 2 + (uint32_t)kt * b_step);
-            else { const uint32_t o = rc_off(piece, h); dma16(rB, dst, o == (uint32_t)MEBT_OOB ? o : o + (uint32_t)kt * b_step); }
-        }
+    // byte offset (k-tile 0) of this lane's 16 B of piece `piece` of half-tile h (0, 1 = B halves; 2, 3 = A halves)
+    auto piece_off = [&](int h, int piece) -> uint32_t {
+        if (h >= 2) return kc_off(piece, p.lda) + (uint32_t)(h - 2) * 128 * p.lda * 2;
+        if (B_KC) return kc_off(piece, p.ldb) + (uint32_t)h * 128 * p.ldb * 2;
+        return rc_off(piece, h);
     };
-    // prologue: k-tiles 0 and 1 completely (each wave: its two pieces of every chunk position of its parity ... simply all 8 chunks,
-    // the two groups taking the low / high half of every half-tile: chunk parity = group)
+    auto issue_piece = [&](char* buf, int h, int piece, uint32_t off0, int kt) {
+        const unsigned dst = (unsigned)(size_t)(lds_char_ptr)(buf + h * HALF + piece * 1024);
+        dma16(h >= 2 ? rA : rB, dst, off0 == (uint32_t)MEBT_OOB ? off0 : off0 + (uint32_t)kt * (h >= 2 ? a_step : b_step));
+    };
+    // prologue: k-tiles 0 and 1 completely, two pieces of every half-tile per wave
     for (int t0 = 0; t0 < 2 && t0 < nk && !(DBG & 16); ++t0)
 #pragma unroll
-        for (int h = 0; h < 4; ++h) issue_chunk(smem + t0 * TILE, 2 * h + grp, t0);
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) issue_piece(smem + t0 * TILE, h, 2 * wave + j, piece_off(h, 2 * wave + j), t0);
+    // the refill of the main loop: this wave always issues pieces 4 wq .. 4 wq + 3 of B half `grp` (phase 2) and of A half `grp` (phase 3)
+    uint32_t offB[4], offA[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { offB[j] = piece_off(grp, 4 * wq + j); offA[j] = piece_off(2 + grp, 4 * wq + j); }
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -930,17 +936,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) af[ks][ii] = read_frag<true, 128>(sA, (ph >> 1) * 4 + ii, ks, lane);
             }
-            if (!(DBG & 1)) {   // one 8-KiB chunk of k-tile tau = (s - 5) / 8 + 2 per slot
-                const int u = 8 * t + 2 * ph + grp - 5;
-                if (u >= 0) {
-                    const int tau = (u >> 3) + 2;
-                    if (tau < nk) issue_chunk(smem + (tau & 1) * TILE, u & 7, tau);
-                }
+            if (!(DBG & 1) && ph >= 2 && t + 2 < nk) {       // refill: a whole half-tile of k-tile t + 2 per LOAD part, 4 pieces per wave
+#pragma unroll
+                for (int j = 0; j < 4; ++j) issue_piece(buf, ph == 2 ? grp : 2 + grp, 4 * wq + j, ph == 2 ? offB[j] : offA[j], t + 2);
             }
-            if (ph == 3) {                                   // every piece of k-tile t + 1 this wave issued has landed; still in flight: its pieces of t + 2
-                if (t + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (none of those in the tail)
-                else if (grp == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (ph == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the last reads of this k-tile's B are done before the slot the other group may overwrite it in
+            if (ph == 3) {                                   // every piece of k-tile t + 1 this wave issued has landed; still in flight: its 8 pieces of t + 2
+                if (t + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();
