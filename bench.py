@@ -367,6 +367,13 @@ def main():
     stats = stats.cpu()
     n_targets = int(stats[3])                                  # masked tokens scored per rank per step
     ms = 1e3 * elapsed / args.steps
+    # host side of a step: wall time of two step() calls that only enqueue (empty queue in front, no synchronisation inside)
+    sync()
+    h0 = time.perf_counter()
+    for _ in range(2):
+        loop.step(x, idx, t=args.t)
+    host_enqueue_ms = 1e3 * (time.perf_counter() - h0) / 2
+    sync()
     value = world * n_targets * args.steps / elapsed
     wire_bytes_per_step = (reducer.bytes_on_wire - wire0) / max(1, args.steps)
 
@@ -477,6 +484,7 @@ def main():
                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "per_gpu": round(value / world, 1),
+               "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
                "config": {"workload": "Sky-Timelapse 16f MeBT train step: 24L/1024d/16h, 1024 VQ tokens + 256 latents, "
                                       f"batch {args.batch}/GPU, t={args.t} (NC=NT={n_targets // args.batch}), "
                                       "fwd + masked CE + bwd + AdamW" + ((f" + reduce-scatter / sharded AdamW / all-gather ({reducer.wire} wire)" if reducer.mode == "sharded" else " + bucketed fp32 all-reduce") if reducer.active else ""),
