@@ -11,7 +11,8 @@
 // 2^k ordinary "sub-lattice" convolutions: the outputs of one parity class o = 2 o' + pi use a fixed subset of the taps
 // (k == (pi + 1) mod 2), so each class is an implicit GEMM with 1/8 (or 1/4) of the taps and no zero-stuffing.
 //
-// Kernels: conv3d_mfma_f16 (v_mfma_f32_16x16x32_f16, 128 x 64 x 32 tiles, register-staged double buffer; Cin % 32 == 0,
+// Kernels: conv3d_mfma_f16_dma (v_mfma_f32_16x16x32_f16, LDS-DMA ring with per-lane gather addresses; Cin, Cout % 64 == 0),
+// conv3d_mfma_f16 (the first version: 128 x 64 x 32 tiles, register-staged double buffer; Cin % 32 == 0,
 // Cout % 64 == 0), conv3d_direct (any shape / dtype, fp32 FMA: the parity mode, the 3-channel first / last layers and odd
 // channel counts), group-norm statistics + normalise/SiLU, codebook distance arg-min on an exact-fp32 MFMA score matrix,
 // embedding rows.
@@ -19,6 +20,8 @@
 #include "kernels.h"
 #include "../../include/mebt_hip.h"
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -263,6 +266,151 @@ __global__ __launch_bounds__(256) void conv3d_mfma_f16_kernel(const mebt_conv3d_
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same implicit GEMM on the Linear layers' machinery (gemm_kernels.h): k-steps of 64 channels of one tap, both operands
+// copied global -> LDS by LDS-DMA into a ring of NST stages (counted vmcnt waits, one raw s_barrier per k-step), KC images
+// [row][64 k] with the XOR swizzle chunk ^ (row >> 1 & 7) read with ds_read_b128, TBM x TBN tiles (128 x 128 for the 128- and
+// 256-channel layers, 256 x 64 for the 64-channel ones), 4 waves of 64 rows each (32 MFMAs per k-step against 8 in the
+// register-staged kernel above), epilogue staged through LDS so that every lane stores 8 consecutive channels (16 bytes).
+// An A row of a k-step is the 128 contiguous bytes in[vox(m, tap)][c0 .. c0 + 63]: each lane of a DMA piece supplies its own
+// source address (row base of ITS row, recomputed when the tap changes — replicate padding is the clamp inside in_voxel), so
+// the gather costs no register pass.  Cin % 64 == 0, Cout % 64 == 0.
+// ------------------------------------------------------------------------------------------------
+template <int TBM, int TBN, int NST>
+__global__ __launch_bounds__(256) void conv3d_mfma_f16_dma_kernel(const mebt_conv3d_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KB = 64;
+    constexpr int STAGE = (TBM + TBN) * KB * 2;
+    constexpr int PA = TBM / 32, PB = TBN / 32;           // DMA pieces (8 rows x 128 B) per wave and stage
+    constexpr int LPT = PA + PB;
+    constexpr int WM = TBM / 64, WN = 4 / WM;             // waves over rows x columns: a wave always owns 64 rows
+    constexpr int TM = 4, TN = TBN / (16 * WN);           // 16 x 16 fragments per wave
+    constexpr int AHEAD = NST - 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const long Mcls = (long)p.B * p.cT * p.cH * p.cW;
+    const long m0 = (long)blockIdx.x * TBM;
+    const int n0 = blockIdx.y * TBN;
+    const int kc = p.Cin / KB, nk = p.ntaps * kc;
+    const size_t in_bytes = (size_t)p.B * p.Ti * p.Hi * p.Wi * p.Cin * 2, w_bytes = (size_t)p.Cout * p.ntaps * p.Cin * 2;
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.in, in_bytes), rB = make_rsrc(p.w, w_bytes);
+
+    // this lane's rows: piece q = wave + 4 i covers tile rows 8 q .. 8 q + 7, lane -> row 8 q + (lane >> 3), 16-byte slot lane & 7
+    Vox va[PA];
+    uint32_t aoff[PA], boff[PB];
+    unsigned alds[PA], blds[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = 8 * (wave + 4 * i) + (lane >> 3);
+        long m = m0 + row;
+        if (m >= Mcls) m = Mcls - 1;
+        va[i] = decode_vox(p, m);
+        aoff[i] = 0;
+        alds[i] = (wave + 4 * i) * 1024;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int row = 8 * (wave + 4 * i) + (lane >> 3);
+        const int ch = (lane & 7) ^ ((row >> 1) & 7);
+        boff[i] = (uint32_t)(n0 + row) * p.ntaps * p.Cin * 2 + ch * 16;
+        blds[i] = TBM * KB * 2 + (wave + 4 * i) * 1024;
+    }
+    int cur_tap = -1;
+    auto issue = [&](int kk) {
+        char* st = smem + (kk % NST) * STAGE;
+        const int j = kk / kc, c0 = (kk - j * kc) * KB;
+        if (j != cur_tap) {
+            cur_tap = j;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int row = 8 * (wave + 4 * i) + (lane >> 3);
+                const int ch = (lane & 7) ^ ((row >> 1) & 7);
+                aoff[i] = (uint32_t)(in_voxel(p, va[i], j) * p.Cin * 2) + ch * 16;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PA; ++i) dma16(rA, (unsigned)(size_t)(lds_char_ptr)(st + alds[i]), aoff[i] + c0 * 2);
+        const uint32_t bk = ((uint32_t)j * p.Cin + c0) * 2;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) dma16(rB, (unsigned)(size_t)(lds_char_ptr)(st + blds[i]), boff[i] + bk);
+    };
+    auto frag = [&](const char* tile, int blk16, int ks) -> f16x8 {
+        const int row = blk16 * 16 + (lane & 15);
+        const int c = 4 * ks + (lane >> 4);
+        return *reinterpret_cast<const f16x8*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a)
+        if (a < nk) issue(a);
+    for (int t = 0; t < nk; ++t) {
+        const int younger = min(AHEAD - 1, nk - 1 - t);
+        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + AHEAD < nk) issue(t + AHEAD);
+        const char* sA = smem + (t % NST) * STAGE;
+        const char* sB = sA + TBM * KB * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = frag(sA, wm * TM + i, ks);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = frag(sB, wn * TN + j, ks);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: a 16-row fp32 slab per wave through LDS, then 8 consecutive channels per lane
+    constexpr int COLS = TN * 16, LD = COLS + 4, LPR = COLS / 8, RPI = 64 / LPR, NPASS = 16 / RPI;
+    __syncthreads();
+    float* st = reinterpret_cast<float*>(smem) + wave * (16 * LD);
+    const int r0 = lane / LPR, c8 = (lane % LPR) * 8;
+    const int n = n0 + wn * COLS + c8;
+    f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) { b_lo = *reinterpret_cast<const f32x4*>(p.bias + n); b_hi = *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(st + (lane & 15) * LD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < NPASS; ++r) {
+            const int row = r * RPI + r0;
+            f32x4 lo = *reinterpret_cast<const f32x4*>(st + row * LD + c8);
+            f32x4 hi = *reinterpret_cast<const f32x4*>(st + row * LD + c8 + 4);
+            const long m = m0 + wm * 64 + i * 16 + row;
+            if (m >= Mcls) continue;
+            const size_t oi = out_voxel(p, decode_vox(p, m)) * p.Cout + n;
+            lo += b_lo; hi += b_hi;
+            if (p.resid) {
+                const f16x8 rv = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16_t*>(p.resid) + oi);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { lo[q] += (float)rv[q]; hi[q] += (float)rv[4 + q]; }
+            }
+            if (p.out_mode == 1) {
+                float* o = reinterpret_cast<float*>(p.out) + oi;
+                *reinterpret_cast<f32x4*>(o) = lo;
+                *reinterpret_cast<f32x4*>(o + 4) = hi;
+            } else {
+                const f16x8 o = {(f16_t)lo[0], (f16_t)lo[1], (f16_t)lo[2], (f16_t)lo[3], (f16_t)hi[0], (f16_t)hi[1], (f16_t)hi[2], (f16_t)hi[3]};
+                *reinterpret_cast<f16x8*>(reinterpret_cast<f16_t*>(p.out) + oi) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slab is rewritten by the next row block
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // GroupNorm (32 groups, eps 1e-6) + SiLU, channels-last
 // ------------------------------------------------------------------------------------------------
 // pass 1: stats[b][g] = {sum, sum of squares}.  A workgroup takes a slab of voxels of one sample: thread = 4 consecutive
@@ -407,7 +555,32 @@ extern "C" int mebt_op_conv3d(int32_t dtype, const mebt_conv3d_desc* d, int32_t 
     const bool chan_ok = p.in_mode == 1 || p.Cin % 4 == 0;
     const int maxc = p.Cout <= 4 ? 4 : (p.Cout <= 32 && p.in_mode == 1 ? 32 : 0);
     const size_t vlds = (size_t)p.ntaps * p.Cin * maxc * 4;
-    if (mfma) {
+    static const int conv_dma = [] { const char* e = getenv("MEBT_CONV_DMA"); return (e && e[0] == '0') ? 0 : 1; }();   // 0: the first (register-staged) kernel
+    if (mfma && conv_dma && p.Cin % 64 == 0 && p.Cout % 64 == 0 && (size_t)p.B * p.Ti * p.Hi * p.Wi * p.Cin * 2 < (1ull << 32)) {
+        // tile: 128 x 128 (two workgroups per CU at ring depth 2) where Cout allows, else 256 x 64; MEBT_CONV_TILE=bm,bn,ring (experiments)
+        static int force[3] = {0, 0, 0};
+        static const int attrs = [] {
+#define CONV_ATTR(BM_, BN_, ST_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_f16_dma_kernel<BM_, BN_, ST_>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_ * (BM_ + BN_) * 128)
+            CONV_ATTR(128, 128, 2); CONV_ATTR(128, 128, 3); CONV_ATTR(128, 64, 2); CONV_ATTR(128, 64, 3); CONV_ATTR(256, 64, 2); CONV_ATTR(256, 64, 3);
+            CONV_ATTR(256, 128, 2);
+#undef CONV_ATTR
+            if (const char* e = getenv("MEBT_CONV_TILE")) sscanf(e, "%d,%d,%d", &force[0], &force[1], &force[2]);
+            return 0;
+        }();
+        (void)attrs;
+        int bm = p.Cout % 128 == 0 ? 128 : 256, bn = p.Cout % 128 == 0 ? 128 : 64, ring = 2;
+        if (force[0] && p.Cout % force[1] == 0) { bm = force[0]; bn = force[1]; ring = force[2]; }
+        const dim3 grid((unsigned)((mcls + bm - 1) / bm), p.Cout / bn);
+#define CONV_GO(BM_, BN_, ST_) hipLaunchKernelGGL((conv3d_mfma_f16_dma_kernel<BM_, BN_, ST_>), grid, dim3(256), ST_ * (BM_ + BN_) * 128, S(stream), p)
+        if (bm == 128 && bn == 128 && ring == 2) CONV_GO(128, 128, 2);
+        else if (bm == 128 && bn == 128) CONV_GO(128, 128, 3);
+        else if (bm == 128 && bn == 64 && ring == 2) CONV_GO(128, 64, 2);
+        else if (bm == 128 && bn == 64) CONV_GO(128, 64, 3);
+        else if (bm == 256 && bn == 64 && ring == 2) CONV_GO(256, 64, 2);
+        else if (bm == 256 && bn == 64) CONV_GO(256, 64, 3);
+        else CONV_GO(256, 128, 2);
+#undef CONV_GO
+    } else if (mfma) {
         const dim3 grid((unsigned)((mcls + CBM - 1) / CBM), p.Cout / CBN);
         hipLaunchKernelGGL(conv3d_mfma_f16_kernel, grid, dim3(256), 0, S(stream), p);
     } else if (allow_mfma && maxc && chan_ok && vlds <= 64 * 1024) {
