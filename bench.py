@@ -252,11 +252,31 @@ def secondary_metrics(args, cfg, model, loop, x, idx, device, lib, level):
         dec = lambda: tm.first_stage_model.decode(code2.view(4, 4, 16, 16))
         rec = dec()
         stages["vqgan_decode_ms"] = round(timed(dec, 3, sync) * 1e3, 3)
+        # per-stage roofline (MFMA-bound stages): the sampler stages once more with the GEMM family bracketed by HIP events —
+        # exact algorithmic FLOPs of its launches and their summed duration; `achieved` = those FLOPs / the stage's wall time
+        # (so it also charges attention, LayerNorm and the sampling kernels to the GEMMs: conservative)
+        stage_roof = {}
+        for name, fn in (("sample_64_steps", draft), ("revise_8x2", rev)):
+            lib.mebt_profile_enable(1)
+            fn()
+            sync()
+            n, tms, fl = C.c_double(), C.c_double(), C.c_double()
+            _lib.check(lib.mebt_profile_read(0, C.byref(n), C.byref(tms), C.byref(fl)))
+            lib.mebt_profile_enable(0)
+            wall = stages[name + "_ms"] * 1e-3
+            stage_roof[name] = {"bound": "mfma", "achieved": round(fl.value / wall / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(fl.value / wall / 1e12 / PEAK_BF16_TFLOPS, 4), "gemm_launches": n.value,
+                                "gemm_gflop": round(fl.value / 1e9, 1), "gemm_ms_by_events": round(tms.value, 2)}
+        for name, gflop in (("vqgan_encode", 4 * 2 * 23.83), ("vqgan_decode", 4 * 2 * 347.17)):
+            tf = gflop / stages[name + "_ms"]                     # GFLOP / ms = TFLOP/s
+            stage_roof[name] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(tf / PEAK_BF16_TFLOPS, 4), "conv_gflop": round(gflop, 1)}
     assert tuple(rec.shape) == (4, 3, 16, 128, 128) and tuple(toks.shape) == (4, 1024)
     total = sum(stages.values())
     stages.update({"batch": 4, "total_ms": round(total, 2), "videos_per_s": round(4 / (total * 1e-3), 2),
                    "vqgan_encode_tflops": round(4 * 2 * 23.83e9 / (stages["vqgan_encode_ms"] * 1e-3) / 1e12, 1),
                    "vqgan_decode_tflops": round(4 * 2 * 347.17e9 / (stages["vqgan_decode_ms"] * 1e-3) / 1e12, 1),
+                   "roofline_by_stage": stage_roof,
                    "note": "16 frames x 128 x 128 per video; VQGAN fp16 (conv3d implicit GEMM on v_mfma_f32_16x16x32_f16), transformer " + args.dtype})
     out["c5_taichi_end_to_end"] = stages
     return out
