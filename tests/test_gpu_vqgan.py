@@ -37,9 +37,12 @@ def build(name, dtype):
 
 @pytest.mark.parametrize("kind,k,stride,cin,cout", [("conv", 3, (1, 1, 1), 32, 64), ("conv", 4, (2, 2, 2), 32, 64), ("conv", 4, (1, 2, 2), 64, 128),
                                                    ("conv", 1, (1, 1, 1), 64, 64), ("conv", 3, (1, 1, 1), 16, 24),
+                                                   ("conv", 3, (1, 1, 1), 64, 64), ("conv", 3, (1, 1, 1), 128, 256),
                                                    ("convt", 4, (2, 2, 2), 64, 64), ("convt", 4, (1, 2, 2), 128, 64), ("convt", 4, (2, 2, 2), 16, 8)])
 def test_conv3d_operator(kind, k, stride, cin, cout):
-    """mebt_op_conv3d (direct fp32, direct fp16, MFMA fp16) vs the oracle's SamePadConv3d / SamePadConvTranspose3d"""
+    """mebt_op_conv3d (direct fp32, direct fp16, MFMA fp16: the LDS-DMA kernel where Cin and Cout are multiples of 64 — 256 x 64 and
+    128 x 128 tiles, two column tiles at Cout 256, 480 voxels = ragged row tiles — the first MFMA kernel otherwise) vs the oracle's
+    SamePadConv3d / SamePadConvTranspose3d"""
     from mebt_amd.vqgan import VQGAN, SamePadConv3d, SamePadConvTranspose3d, _Conv
     g = torch.Generator().manual_seed(k * 100 + cin)
     B, dims = 2, (4, 6, 10)
