@@ -729,3 +729,24 @@ def top_k_logits(logits, k):
     scratch = torch.empty(R, dtype=torch.long, device=lg.device)
     _lib.check(_lib.load().mebt_op_topk_threshold(_lib.ptr(lg), int(k), _lib.ptr(thr), _lib.ptr(scratch), R, V, _lib.cur_stream()))
     return logits.masked_fill(logits.to(torch.float32) < thr.view(*logits.shape[:-1], 1), -float("Inf"))
+
+
+def top_p_probs(probs, p):
+    """reference :898-910: nucleus filter of a probability tensor (*, C) -> renormalised probabilities (the smallest prefix of
+    the descending order whose mass reaches p is kept).  Runs on the sampler kernel (its top-p stage on log(probs) at
+    temperature 1, csrc/sampler.hip): device tensors only."""
+    if not probs.is_cuda:
+        raise RuntimeError("mebt_amd has no CPU path: top_p_probs needs a tensor on the MI355X (cuda) device")
+    logits = torch.log(probs.to(torch.float32).clamp_min(0))
+    _, _, out = sample_from_logits_scored(logits, 1.0, None, float(p), None, want_probs=True, seed=0)
+    return out.to(probs.dtype)
+
+
+def gumbel_sort(prob, noise=None):
+    """reference :826-841: indices (*, C) in descending order of (prob / sum) / q with q ~ Exp(1), entries of probability 0 last.
+    API parity only — the sampling path never sorts (`sample_from_logits` takes the arg-max inside its kernel); `noise` replaces
+    the draw for tests."""
+    prob = prob / prob.sum(-1, keepdim=True)
+    q = torch.empty_like(prob).exponential_() if noise is None else noise.to(prob)
+    keyed = (prob / q) * (prob > 0).to(prob.dtype)
+    return keyed.sort(dim=-1, descending=True)[1]

@@ -420,6 +420,31 @@ def test_top_k_logits_helper_matches_reference_semantics():
         top_k_logits(lg2, 5)
 
 
+def test_top_p_probs_and_gumbel_sort_helpers():
+    """module-level helpers the reference exposes (transformer.py:826-841, :898-910) against the oracle's restatement"""
+    from mebt_amd.transformer import top_p_probs, gumbel_sort
+    from oracle import mebt_oracle as orc
+    g = torch.Generator().manual_seed(9)
+    probs = torch.softmax(torch.randn(5, 16384, generator=g) * 3.0, -1)
+    for p in (0.3, 0.9):
+        out = top_p_probs(probs.to(DEV), p).cpu()
+        ref = orc.top_p_probs(probs.clone(), p)
+        kept, rkept = out > 0, ref > 0
+        # the two orders of summation may disagree on the entry at which the cumulative mass crosses p: at most that one per row
+        assert int((kept != rkept).sum(-1).max()) <= 1
+        both = kept & rkept
+        assert (out[both] / ref[both] - 1).abs().max() < 2e-3 and abs(float(out.sum(-1).min()) - 1) < 1e-5
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        top_p_probs(probs, 0.9)
+    pr = torch.rand(3, 4, 97, generator=g)
+    pr[0, 0, :10] = 0.0                                             # zero-probability entries sort last
+    q = torch.empty_like(pr).exponential_(generator=g)
+    idx = gumbel_sort(pr.to(DEV), noise=q.to(DEV)).cpu()
+    key = (pr / pr.sum(-1, keepdim=True)) / q * (pr > 0).float()
+    assert torch.equal(torch.gather(key, -1, idx), key.sort(-1, descending=True)[0])
+    assert set(idx[0, 0, -10:].tolist()) == set(range(10))
+
+
 def _grouped_call(items, fused, step=1, lr=1e-3, wd=0.05, with_bias=True, seed=0):
     """items: [(n_out, k_in, tokens)]; returns (gW, bias grads, W, mW, vW, Wlp, refs)"""
     import ctypes as C
