@@ -156,12 +156,15 @@ __device__ __forceinline__ void store8(T* c, const f32x4& lo, const f32x4& hi, b
     if (ok_hi) store4<T>(c + 4, hi);
 }
 
-template <int TM, int TN, bool SYNC = true>
+// SWZ: the slab rows are 64 floats without padding, the 16-byte chunk index XORed with the row (exactly 4 KiB per wave: the
+// persistent 256 x 256 kernel has 32 KiB of LDS left beside its ring); `pre_bias`: bias values the caller loaded earlier.
+template <int TM, int TN, bool SYNC = true, bool SWZ = false>
 __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x4 (&acc)[TM][TN], char* smem, int wave, int lane,
-                                                 int mbase, int nbase, bool add_bias, bool atomic) {
+                                                 int mbase, int nbase, bool add_bias, bool atomic, const f32x4* pre_bias = nullptr) {
     typedef bf16_t TA;
-    if (p.epilogue == EPI_ADAMW) { epilogue_adamw<TM, TN>(p, acc, smem, wave, lane, mbase, nbase); return; }
-    constexpr int COLS = TN * 16, LD = COLS + 4;          // fp32 elements per staged row
+    if (!SWZ && p.epilogue == EPI_ADAMW) { epilogue_adamw<TM, TN>(p, acc, smem, wave, lane, mbase, nbase); return; }
+    constexpr int COLS = TN * 16, LD = SWZ ? COLS : COLS + 4;          // fp32 elements per staged row
+    static_assert(!SWZ || COLS == 64, "the swizzled slab is 16 chunks wide");
     float* st = reinterpret_cast<float*>(smem) + wave * (16 * LD);   // one 16-row slab per wave (<= 4.3 KiB)
     constexpr int LPR = COLS / 8;                         // lanes per row (8 columns each)
     constexpr int RPI = 64 / LPR;                         // rows per pass
@@ -174,7 +177,8 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x
     const int nc = n_ok ? n : 0, nh = hi_ok ? n + 4 : nc;
     const bool need_aux = p.epilogue == EPI_RESID || p.epilogue == EPI_GELU_BWD;
     f32x4 bias_lo = {0.f, 0.f, 0.f, 0.f}, bias_hi = {0.f, 0.f, 0.f, 0.f};
-    if (add_bias && p.bias) {
+    if (pre_bias) { bias_lo = pre_bias[0]; bias_hi = pre_bias[1]; }
+    else if (add_bias && p.bias) {
         bias_lo = *reinterpret_cast<const f32x4*>(p.bias + nc);
         bias_hi = *reinterpret_cast<const f32x4*>(p.bias + nh);
     }
@@ -201,15 +205,15 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, const f32x
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            *reinterpret_cast<f32x4*>(st + (lane & 15) * LD + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+            *reinterpret_cast<f32x4*>(st + (lane & 15) * LD + (SWZ ? (((j * 4 + (lane >> 4)) ^ (lane & 15)) << 2) : j * 16 + 4 * (lane >> 4))) = acc[i][j];
         // the same wave reads back what it wrote (LDS operations of a wave execute in order): only its LDS
         // queue has to drain, no workgroup barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int r = 0; r < NPASS; ++r) {
             const int row = r * RPI + r0;
-            f32x4 lo = *reinterpret_cast<const f32x4*>(st + row * LD + c8);
-            f32x4 hi = *reinterpret_cast<const f32x4*>(st + row * LD + c8 + 4);
+            f32x4 lo = *reinterpret_cast<const f32x4*>(st + row * LD + (SWZ ? ((((c8 >> 2)) ^ (row & 15)) << 2) : c8));
+            f32x4 hi = *reinterpret_cast<const f32x4*>(st + row * LD + (SWZ ? ((((c8 >> 2) + 1) ^ (row & 15)) << 2) : c8 + 4));
             const int m = mbase + i * 16 + row;
             if (!(m < p.M && n_ok)) continue;
             lo += bias_lo;
@@ -847,28 +851,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_w8_kernel(const GemmParams p) {
 // overwrite is issued at least one barrier after the last read of its target has completed.  Each group waits once per k-tile, at
 // the end of its phase-3 LOAD part: vmcnt(8) = everything but the two half-tile shares of k-tile t + 2 it has just issued.
 // ------------------------------------------------------------------------------------------------
+// Persistent over the tile list (one workgroup per CU, tiles w, w + G, ...): after the main loop of tile i the prologue DMA of
+// tile i + 1 is issued, then the epilogue of tile i runs out of 8 x 4 KiB swizzled slabs beside the ring (128 + 32 = 160 KiB of
+// LDS), and the wait in front of the next main loop is vmcnt(16 | 32): everything but this wave's own store instructions of the
+// epilogue — the 128 KiB store burst of a tile drains behind the next tile's MFMAs instead of in front of them (config 4's
+// 31 744 x 2048 x 1024: 147 -> 126-136 us, the 31 744 x 16 384 head 1230 -> 1040 us = 1.02 PFLOP/s).  The counted wait is only
+// taken where the instruction count after the DMA is known (full tile, plain epilogue, no accumulation); otherwise vmcnt(0).
 // DBG (tools/pp_bench.hip only): bit 0 = no refill DMA in the loop, bit 1 = no MFMAs, bit 2 = no fragment reads
 template <bool B_KC, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HALF = 128 * BK * 2;                       // one half-tile image: 16 KiB
     constexpr int TILE = 4 * HALF;                           // [B0 | B1 | A0 | A1]
-    const int ntx = gridDim.x, nty = gridDim.y;
-    const PrefetchRegs pfr = prefetch_next(p, blockIdx.y * ntx + blockIdx.x, ntx * nty, 512);
-    int tr, tc;
-    xcd_tile(blockIdx.y * ntx + blockIdx.x, ntx, nty, p.M, p.N, tr, tc);
-    const int m0 = tr * 256, n0 = tc * 256;
+    char* slabs = smem + 2 * TILE;                           // 8 x 4 KiB: the epilogue's swizzled staging slabs, outside the ring
+    const int ntx = (p.N + 255) / 256, nty = (p.M + 255) / 256, ntiles = ntx * nty;
+    const int G = gridDim.x;                                 // persistent: workgroup w takes tiles w, w + G, w + 2 G, ...
+    const PrefetchRegs pfr = prefetch_next(p, blockIdx.x, G, 512);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3;                // group = A half; wq = the wave's 64-column slice of the tile
     const int nk = p.K / BK;
-
-    // ---- DMA addressing.  Piece i (0 .. 15) of a half-tile = 1 KiB: KC: rows 8 i .. 8 i + 7 x 128 B;  RC: k-rows 4 i .. 4 i + 3 x 256 B.
-    // Per lane the offset of piece i is base(i & 1 pattern) + (i >> 1) * stride2: the swizzle term repeats with period 2 (KC) / 1 (RC).
     const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* Bb = reinterpret_cast<const bf16_t*>(p.B);
-    const __amdgpu_buffer_rsrc_t rA = make_rsrc(Ab + (size_t)m0 * p.lda, (size_t)(p.M - m0) * p.lda * 2);
-    const __amdgpu_buffer_rsrc_t rB = B_KC ? make_rsrc(Bb + (size_t)n0 * p.ldb, (size_t)(p.N - n0) * p.ldb * 2) : make_rsrc(Bb, (size_t)p.K * p.ldb * 2);
+    const uint32_t a_step = BK * 2, b_step = B_KC ? BK * 2 : (uint32_t)BK * p.ldb * 2;
+
+    // ---- DMA addressing of one output tile.  Piece i (0 .. 15) of a half-tile = 1 KiB: KC: rows 8 i .. 8 i + 7 x 128 B;
+    // RC: k-rows 4 i .. 4 i + 3 x 256 B.  The per-lane offsets of the pieces this wave issues are kept in registers.
+    int m0 = 0, n0 = 0;
+    __amdgpu_buffer_rsrc_t rA, rB;
+    uint32_t offB[4], offA[4];                               // main-loop refill: pieces 4 wq .. 4 wq + 3 of B half `grp` / A half `grp`
     auto kc_off = [&](int piece, int ld) -> uint32_t {       // byte offset of this lane's 16 B of piece `piece` inside a KC half-tile at k-tile 0
         const int row = 8 * piece + (lane >> 3), slot = lane & 7;
         return ((uint32_t)row * ld + 8 * (slot ^ ((row >> 1) & 7))) * 2;
@@ -878,9 +889,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         const int col = n0 + 128 * half + 8 * (slot ^ rc_swizzle<128>(krow));
         return col < p.N ? ((uint32_t)krow * p.ldb + col) * 2 : (uint32_t)MEBT_OOB;
     };
-    const uint32_t a_step = BK * 2, b_step = B_KC ? BK * 2 : (uint32_t)BK * p.ldb * 2;
-    // byte offset (k-tile 0) of this lane's 16 B of piece `piece` of half-tile h (0, 1 = B halves; 2, 3 = A halves)
-    auto piece_off = [&](int h, int piece) -> uint32_t {
+    auto piece_off = [&](int h, int piece) -> uint32_t {     // half-tile h: 0, 1 = B halves; 2, 3 = A halves
         if (h >= 2) return kc_off(piece, p.lda) + (uint32_t)(h - 2) * 128 * p.lda * 2;
         if (B_KC) return kc_off(piece, p.ldb) + (uint32_t)h * 128 * p.ldb * 2;
         return rc_off(piece, h);
@@ -889,86 +898,115 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         const unsigned dst = (unsigned)(size_t)(lds_char_ptr)(buf + h * HALF + piece * 1024);
         dma16(h >= 2 ? rA : rB, dst, off0 == (uint32_t)MEBT_OOB ? off0 : off0 + (uint32_t)kt * (h >= 2 ? a_step : b_step));
     };
-    // prologue: k-tiles 0 and 1 completely, two pieces of every half-tile per wave
-    for (int t0 = 0; t0 < 2 && t0 < nk && !(DBG & 16); ++t0)
+    // make `tile` the current one and issue its prologue: k-tiles 0 and 1 completely, two pieces of every half-tile per wave
+    auto begin_tile = [&](int tile) {
+        int tr, tc;
+        xcd_tile(tile, ntx, nty, p.M, p.N, tr, tc);
+        m0 = tr * 256; n0 = tc * 256;
+        rA = make_rsrc(Ab + (size_t)m0 * p.lda, (size_t)(p.M - m0) * p.lda * 2);
+        rB = B_KC ? make_rsrc(Bb + (size_t)n0 * p.ldb, (size_t)(p.N - n0) * p.ldb * 2) : make_rsrc(Bb, (size_t)p.K * p.ldb * 2);
+        for (int t0 = 0; t0 < 2 && t0 < nk && !(DBG & 16); ++t0)
 #pragma unroll
-        for (int h = 0; h < 4; ++h)
+            for (int h = 0; h < 4; ++h)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) issue_piece(smem + t0 * TILE, h, 2 * wave + j, piece_off(h, 2 * wave + j), t0);
-    // the refill of the main loop: this wave always issues pieces 4 wq .. 4 wq + 3 of B half `grp` (phase 2) and of A half `grp` (phase 3)
-    uint32_t offB[4], offA[4];
+                for (int j = 0; j < 2; ++j) issue_piece(smem + t0 * TILE, h, 2 * wave + j, piece_off(h, 2 * wave + j), t0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { offB[j] = piece_off(grp, 4 * wq + j); offA[j] = piece_off(2 + grp, 4 * wq + j); }
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();              // the stagger: group 1 runs one slot behind group 0
+        for (int j = 0; j < 4; ++j) { offB[j] = piece_off(grp, 4 * wq + j); offA[j] = piece_off(2 + grp, 4 * wq + j); }
+    };
 
     const int bhalf = wq >> 1, bblk = (wq & 1) * 4;          // the wave's B fragments: half-tile wq >> 1, 16-row blocks bblk .. bblk + 3
-    bf16x8 af[2][4] = {}, bq0[2][2] = {}, bq1[2][2] = {};
-    for (int t = 0; t < nk; ++t) {
-        char* buf = smem + (t & 1) * TILE;
-        const char* sB = buf + bhalf * HALF;
-        const char* sA = buf + (2 + grp) * HALF;
+    int tile = blockIdx.x;
+    if (tile < ntiles) begin_tile(tile);
+    int pending = 0;                                         // store instructions of the previous tile's epilogue that may still be in flight (0, 16 or 32)
+    while (tile < ntiles) {
+        f32x4 acc[8][4];
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            // ------------------------------------------------ LOAD part of phase ph (slot s = 8 t + 2 ph + grp)
-            if (ph == 0 && !(DBG & 4)) {
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the prologue of this tile has landed; the previous tile's stores (younger than it) need not have
+        if (pending == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (pending == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();          // the stagger: group 1 runs one slot behind group 0
+        const int cur_m0 = m0, cur_n0 = n0;
+
+        bf16x8 af[2][4] = {}, bq0[2][2] = {}, bq1[2][2] = {};
+        for (int t = 0; t < nk; ++t) {
+            char* buf = smem + (t & 1) * TILE;
+            const char* sB = buf + bhalf * HALF;
+            const char* sA = buf + (2 + grp) * HALF;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                // ------------------------------------------------ LOAD part of phase ph (slot s = 8 t + 2 ph + grp)
+                if (ph == 0 && !(DBG & 4)) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) bq0[ks][jj] = read_frag<B_KC, 128>(sB, bblk + jj, ks, lane);
+                }
+                if (ph == 1 && !(DBG & 4)) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) bq1[ks][jj] = read_frag<B_KC, 128>(sB, bblk + 2 + jj, ks, lane);
+                }
+                if ((ph == 0 || ph == 2) && !(DBG & 4)) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) af[ks][ii] = read_frag<true, 128>(sA, (ph >> 1) * 4 + ii, ks, lane);
+                }
+                if (!(DBG & 1) && ph >= 2 && t + 2 < nk) {   // refill: a whole half-tile of k-tile t + 2 per LOAD part, 4 pieces per wave
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) issue_piece(buf, ph == 2 ? grp : 2 + grp, 4 * wq + j, ph == 2 ? offB[j] : offA[j], t + 2);
+                }
+                if (ph == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the last reads of this k-tile's B are done before the slot the other group may overwrite it in
+                if (ph == 3) {                               // every piece of k-tile t + 1 this wave issued has landed; still in flight: its 8 pieces of t + 2
+                    if (t + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                // ------------------------------------------------ MFMA part of phase ph: quadrant (ph >> 1, (ph == 1 || ph == 2))
+                __builtin_amdgcn_s_setprio(1);
+                if (!(DBG & 2))
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) bq0[ks][jj] = read_frag<B_KC, 128>(sB, bblk + jj, ks, lane);
+                    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int i = (ph >> 1) * 4 + ii;
+                            if (ph == 1 || ph == 2) acc[i][2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq1[ks][jj], af[ks][ii], acc[i][2 + jj], 0, 0, 0);
+                            else acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq0[ks][jj], af[ks][ii], acc[i][jj], 0, 0, 0);
+                        }
+                __builtin_amdgcn_s_setprio(0);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
-            if (ph == 1 && !(DBG & 4)) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) bq1[ks][jj] = read_frag<B_KC, 128>(sB, bblk + 2 + jj, ks, lane);
-            }
-            if ((ph == 0 || ph == 2) && !(DBG & 4)) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) af[ks][ii] = read_frag<true, 128>(sA, (ph >> 1) * 4 + ii, ks, lane);
-            }
-            if (!(DBG & 1) && ph >= 2 && t + 2 < nk) {       // refill: a whole half-tile of k-tile t + 2 per LOAD part, 4 pieces per wave
-#pragma unroll
-                for (int j = 0; j < 4; ++j) issue_piece(buf, ph == 2 ? grp : 2 + grp, 4 * wq + j, ph == 2 ? offB[j] : offA[j], t + 2);
-            }
-            if (ph == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the last reads of this k-tile's B are done before the slot the other group may overwrite it in
-            if (ph == 3) {                                   // every piece of k-tile t + 1 this wave issued has landed; still in flight: its 8 pieces of t + 2
-                if (t + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            }
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // ------------------------------------------------ MFMA part of phase ph: quadrant (ph >> 1, (ph == 1 || ph == 2))
-            __builtin_amdgcn_s_setprio(1);
-            if (!(DBG & 2))
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int i = (ph >> 1) * 4 + ii;
-                        if (ph == 1 || ph == 2) acc[i][2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq1[ks][jj], af[ks][ii], acc[i][2 + jj], 0, 0, 0);
-                        else acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq0[ks][jj], af[ks][ii], acc[i][jj], 0, 0, 0);
-                    }
-            __builtin_amdgcn_s_setprio(0);
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
         }
+        if (grp == 0) __builtin_amdgcn_s_barrier();          // group 0 waits for group 1's last slot: every wave is past its reads of the ring
+        // the bias is fetched (and waited for) BEFORE the next tile's prologue is issued: a compiler-inserted wait on a load
+        // younger than those DMA pieces would also wait for them
+        const int nb = cur_n0 + wq * 64 + (lane % 8) * 8;
+        f32x4 bias2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (p.bias) {
+            bias2[0] = *reinterpret_cast<const f32x4*>(p.bias + (nb < p.N ? nb : 0));
+            bias2[1] = *reinterpret_cast<const f32x4*>(p.bias + (nb + 4 < p.N ? nb + 4 : 0));
+            asm volatile("" ::"v"(bias2[0]), "v"(bias2[1]) : "memory");
+        }
+        const int next = tile + G;
+        // the store burst of this tile drains behind the next tile's main loop when nothing but plain stores follows the
+        // prologue DMA in this wave's memory queue (full tile, plain epilogue: exactly 16 (bf16) or 32 (fp32) store instructions per wave)
+        const bool counted = next < ntiles && cur_m0 + 256 <= p.M && cur_n0 + 256 <= p.N && p.epilogue == EPI_NONE && !p.beta && p.C != nullptr;
+        if (next < ntiles) begin_tile(next);
+        if (!(DBG & 8)) epilogue_via_lds<8, 4, false, true>(p, acc, slabs, wave, lane, cur_m0 + grp * 128, cur_n0 + wq * 64, true, false, bias2);
+        else if (acc[0][0][0] == 123.f) *reinterpret_cast<float*>(p.C) = acc[7][3][1];
+        pending = (counted && !(DBG & 8)) ? (p.c_f32 ? 32 : 16) : 0;       // fp32 output: two 16-byte stores per lane and pass
+        tile = next;
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();              // group 0 waits for group 1's last slot
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(DBG & 8)) epilogue_via_lds<8, 4>(p, acc, smem, wave, lane, m0 + grp * 128, n0 + wq * 64, true, false);
-    else if (acc[0][0][0] == 123.f) *reinterpret_cast<float*>(p.C) = acc[7][3][1];
     prefetch_sink(p, pfr);
 }
 
@@ -1358,8 +1396,9 @@ static void layout_launch_w8(const GemmParams& p, int ring, hipStream_t stream) 
 // the staggered two-group 256 x 256 kernel: A KC only, K a multiple of 64
 template <bool AK, bool BKC>
 static void layout_launch_pp(const GemmParams& p, hipStream_t stream) {
-    const dim3 grid((p.N + 255) / 256, (p.M + 255) / 256, 1);
-    if (AK) hipLaunchKernelGGL((gemm_bf16_pp_kernel<BKC>), grid, dim3(512), 8 * 128 * BK * 2, stream, p);
+    const int tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256);
+    const dim3 grid(tiles < 256 ? tiles : 256, 1, 1);          // persistent over the tile list: one workgroup per CU
+    if (AK) hipLaunchKernelGGL((gemm_bf16_pp_kernel<BKC>), grid, dim3(512), 8 * 128 * BK * 2 + 8 * 4096, stream, p);
 }
 
 // dynamic-LDS attributes of every instantiation of one operand layout (called once per process)
@@ -1394,7 +1433,7 @@ static int layout_set_attrs() {
     SET_PIPE(128, 128); SET_PIPE(192, 128); SET_PIPE(96, 128); SET_PIPE(96, 64); SET_PIPE(128, 64); SET_PIPE(64, 128); SET_PIPE(64, 64);
 #undef SET_PIPE
     MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w8_kernel<AK, BKC, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * BK * 2));
-    if (AK) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * BK * 2));
+    if (AK) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 128 * BK * 2 + 8 * 4096));
     SET_K(96, 64); SET_K(64, 64); SET_K(96, 128); SET_K(64, 128); SET_K(128, 64);
 #undef SET_K
 #undef SET_D

@@ -107,6 +107,37 @@ def test_gemm_staggered_groups_256(M, N, K, b_kc):
     assert torch.equal(out.double(), ref), (out.double() - ref).abs().max()
 
 
+@pytest.mark.parametrize("b_kc", [1, 0])
+@pytest.mark.parametrize("out", ["f32", "bf16", "bf16+bias+gelu", "bf16 ragged"])
+def test_gemm_staggered_groups_256_persistent_tile_loop(out, b_kc):
+    """more than 256 tiles: the workgroups of the staggered 256 x 256 kernel loop over tiles, issue the next tile's prologue in
+    front of the epilogue and wait for it with a counted vmcnt (16 bf16 / 32 fp32 stores stay in flight) — the fp32 result is exact
+    on integers, the bf16 one to its rounding; a GELU epilogue and a ragged edge take the uncounted path inside the same loop"""
+    M, N, K = (4608, 4352, 192) if out != "bf16 ragged" else (4600, 4360, 192)          # 18 x 17 = 306 tiles (18 x 18 ragged)
+    Am, Bm = rnd(M, K, seed=51, ints=True), rnd(N, K, seed=52, ints=True)
+    ref = Am.double() @ Bm.double().t()
+    B = Bm if b_kc else Bm.t().contiguous()
+    bias = rnd(N, seed=53, ints=True) if "bias" in out else None
+    lib().mebt_debug_gemm_tile(256, 256)
+    lib().mebt_debug_gemm_variant(9)
+    try:
+        if out == "f32":
+            got, _ = run_gemm(_lib.BF16, Am, B, M, N, K, 1, b_kc, c_f32=1)
+            assert torch.equal(got.double(), ref), (got.double() - ref).abs().max()
+        elif "gelu" in out:
+            got, got2 = run_gemm(_lib.BF16, Am * 0.25, B, M, N, K, 1, b_kc, bias=bias, epilogue=_lib.EPI_GELU)
+            pre = ref * 0.25 + bias.double()
+            assert (got.double() - pre).abs().max() <= pre.abs().max() / 128
+            g = F.gelu(pre.float()).double()
+            assert (got2.double() - g).abs().max() <= g.abs().max() / 100
+        else:
+            got, _ = run_gemm(_lib.BF16, Am, B, M, N, K, 1, b_kc)
+            assert (got.double() - ref).abs().max() <= ref.abs().max() / 256 and torch.equal(got.double()[ref.abs() <= 256], ref[ref.abs() <= 256])
+    finally:
+        lib().mebt_debug_gemm_tile(0, 0)
+        lib().mebt_debug_gemm_variant(-1)
+
+
 @pytest.mark.parametrize("ring", [2, 3])
 @pytest.mark.parametrize("tile", [(96, 64), (64, 64), (96, 128), (64, 128), (128, 64)])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0), (0, 1)])

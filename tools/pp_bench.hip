@@ -11,9 +11,10 @@ namespace {
 template <int DBG>
 void run(const char* name, const GemmParams& p) {
     auto k = gemm_bf16_pp_kernel<true, DBG>;
-    const int lds = 8 * 128 * BK * 2;
+    const int lds = 8 * 128 * BK * 2 + 8 * 4096;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    const dim3 grid((p.N + 255) / 256, (p.M + 255) / 256);
+    const int all_tiles = ((p.N + 255) / 256) * ((p.M + 255) / 256);
+    const dim3 grid(all_tiles < 256 ? all_tiles : 256);      // persistent over the tile list
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(512), lds, 0, p);
@@ -29,7 +30,7 @@ void run(const char* name, const GemmParams& p) {
         best = ms < best ? ms : best; tot += ms;
     }
     const hipError_t err = hipGetLastError();
-    const int tiles = grid.x * grid.y, rounds = (tiles + 255) / 256, nk = p.K / BK;
+    const int tiles = all_tiles, rounds = (tiles + 255) / 256, nk = p.K / BK;
     printf("  %-52s best %7.1f us  avg %7.1f us  %6.0f TF/s-equivalent   %6.0f ns per k-tile per round %s\n", name, best * 1e3, tot / iters * 1e3,
            2.0 * p.M * p.N * p.K / (best * 1e-3) / 1e12, best * 1e6 / (rounds * nk), err == hipSuccess ? "" : hipGetErrorString(err));
 }
