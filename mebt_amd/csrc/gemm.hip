@@ -313,7 +313,8 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
     }
     if (g_tune_log)
         fprintf(stderr, "[mebt gemm autotune] M=%d N=%d K=%d a_kc=%d b_kc=%d epi=%d c_f32=%d -> %dx%d ring %d%s (%.1f us cold)\n", p.M, p.N, p.K,
-                p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, (staging >= 8 && staging < 16) ? staging - 8 : (staging & 15), staging >= 64 ? " split-K 4" : staging >= 32 ? " split-K 2" : staging >= 16 ? " x2 pipelines" : staging >= 8 ? " pipelined" : "", best * 1e3f);
+                p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, (tbm == 256 && staging == 9) ? 2 : (staging >= 8 && staging < 16) ? staging - 8 : (staging & 15),
+                (tbm == 256 && staging == 9) ? " two staggered groups, persistent" : staging >= 64 ? " split-K 4" : staging >= 32 ? " split-K 2" : staging >= 16 ? " x2 pipelines" : staging >= 8 ? " pipelined" : "", best * 1e3f);
     return MEBT_OK;
 }
 
