@@ -98,6 +98,11 @@ int mebt_gpt_backward(mebt_model* m, void* ws, const float* dlogits, float* d_so
  * label_smoothing) and utils.accuracy (transformer.py:726-731, utils.py:80-94).
  * out4 (device, 4 doubles) = { CE sum, #top-1 hits, #top-5 hits, #rows }. */
 int mebt_loss(mebt_model* m, void* ws, const float* logits, double* out4, mebt_stream_t stream);
+/* The same, and additionally the gradient of (CE sum * loss_scale) with respect to the logits from the same pass over them (kept
+ * in the workspace): a following mebt_backward_head with the same loss_scale and no upstream skips its cross-entropy backward
+ * (F.cross_entropy forward + backward of transformer.py:726 in one read of the logits).  Vocabulary sizes the fused kernel does
+ * not cover behave like mebt_loss. */
+int mebt_loss_with_grad(mebt_model* m, void* ws, const float* logits, double* out4, float loss_scale, mebt_stream_t stream);
 /* Backward of loss = CE_sum * loss_scale (* *upstream if non-NULL, a device scalar), split so the
  * caller can overlap the data-parallel all-reduce of finished gradient buckets with the rest
  * (reference: DDP reducer, train_transformer.py:39-41).  Order: head, layers hi..lo descending, embed. */

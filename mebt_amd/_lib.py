@@ -40,6 +40,7 @@ PROTOTYPES = {
     "mebt_gpt_forward_train": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.c_uint64, c_vp]),
     "mebt_gpt_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mebt_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mebt_loss_with_grad": (c_i32, [c_vp, c_vp, c_vp, c_vp, C.c_float, c_vp]),
     "mebt_backward_head": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     "mebt_backward_head_dlogits": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
     "mebt_backward_layers": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),

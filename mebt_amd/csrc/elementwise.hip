@@ -574,6 +574,62 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const CeParams p) {
     }
 }
 
+// The same loss statistics AND the gradient of (loss_sum * scale) with respect to the logits from ONE pass over the row: the
+// 16384 logits of a row stay in registers (16 float4 per thread), so the row is read from HBM once instead of three times
+// (ce_fwd twice — the second time from L2 —, ce_bwd once).  Same per-thread summation order and the same expressions as
+// ce_fwd_kernel / ce_bwd_kernel: statistics and gradient agree with the two-kernel path to fp32 rounding.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ce_fused_kernel(const CeParams p) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x;
+    const int b = row / p.NT, j = row % p.NT;
+    const long pos = p.ti[(size_t)b * p.NT + j];
+    const long tgt = p.x_ids[(size_t)b * p.N + pos];
+    const float* l = p.logits + (size_t)row * p.V;
+    f32x4 v[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) v[c] = *reinterpret_cast<const f32x4*>(l + threadIdx.x * 4 + 1024 * c);
+    const float lt = l[tgt];
+    float mx = -INFINITY, sum = 0.f;
+    int rank = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e = threadIdx.x * 4 + 1024 * c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mx = fmaxf(mx, v[c][q]);
+            sum += v[c][q];
+            rank += (v[c][q] > lt) || (v[c][q] == lt && (e + q) < tgt);
+        }
+    }
+    mx = block_max(mx, sh);
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) se += __expf(v[c][q] - mx);
+    se = block_sum(se, sh);
+    sum = block_sum(sum, sh);
+    const float rk = block_sum((float)rank, sh);
+    const float lse = mx + logf(se);
+    const float eps = p.label_smoothing;
+    if (threadIdx.x == 0) {
+        p.row_lse[row] = lse;
+        p.row_loss[row] = (1.f - eps) * (lse - lt) + eps * (lse - sum / p.V);
+        p.row_rank[row] = (int)(rk + 0.5f);
+    }
+    T* d = reinterpret_cast<T*>(p.dlogits) + (size_t)row * p.V;
+    const float sc = p.grad_scale, u = eps / p.V;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e = threadIdx.x * 4 + 1024 * c;
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (__expf(v[c][q] - lse) - ((e + q) == tgt ? 1.f - eps : 0.f) - u) * sc;
+        store4<T>(d + e, o);
+    }
+}
+
 __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* row_loss, const int* row_rank, int rows, double* out) {
     __shared__ double sd[3][256];
     double s = 0, t1 = 0, t5 = 0;
@@ -843,7 +899,12 @@ int launch_colsum_grouped(GroupedColsum& c, int dtype, hipStream_t stream) {
 int launch_ce_fwd(const CeParams& p, hipStream_t stream) {
     if (p.V % 4) { mebt_set_error("cross-entropy: V must be a multiple of 4"); return MEBT_ESHAPE; }
     if (p.rows > 0) {
-        hipLaunchKernelGGL(ce_fwd_kernel, dim3(p.rows), dim3(256), 0, stream, p);
+        if (p.dlogits && ce_fwd_can_fuse_grad(p.V)) {
+            if (p.dl_bf16) hipLaunchKernelGGL((ce_fused_kernel<bf16_t, 16>), dim3(p.rows), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((ce_fused_kernel<float, 16>), dim3(p.rows), dim3(256), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL(ce_fwd_kernel, dim3(p.rows), dim3(256), 0, stream, p);
+        }
         CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, stream, p.row_loss, p.row_rank, p.rows, p.out);

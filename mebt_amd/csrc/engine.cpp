@@ -54,6 +54,8 @@ struct FwdCtx {
     float* logits_ws = nullptr;
     float *row_lse = nullptr, *row_loss = nullptr; int* row_rank = nullptr; double* loss_out = nullptr;
     bool loss_done = false;
+    bool dlogits_ready = false;      // mebt_loss_with_grad has already written x.dlogits for `dlogits_scale`
+    float dlogits_scale = 0.f;
     // backward scratch
     void *g_S = nullptr, *g_T = nullptr; float* g_C = nullptr;
     void* g_cat = nullptr;     // maskgit: cat[g_C, g_T], the gradient of a block output that spans both streams
@@ -665,6 +667,7 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
     m->fw_waits.clear();                                   // one-shot
     x.valid = training != 0;
     x.loss_done = false;
+    x.dlogits_ready = false;
     return MEBT_OK;
 }
 
@@ -688,7 +691,7 @@ extern "C" int mebt_gpt_forward_train(mebt_model* m, void* ws, int64_t ws_bytes,
     return forward_impl(m, ws, ws_bytes, B, 1, NC, NT, nullptr, nullptr, nullptr, e, logits, 1 | (dropout ? 2 : 0), dropout_seed, stream);
 }
 
-extern "C" int mebt_loss(mebt_model* m, void* ws, const float* logits, double* out4, mebt_stream_t stream) {
+static int loss_impl(mebt_model* m, void* ws, const float* logits, double* out4, bool with_grad, float loss_scale, mebt_stream_t stream) {
     if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("loss: no training-mode forward on this workspace"); return MEBT_EINVAL; }
     FwdCtx& x = m->ctx;
     if (!x.x_ids) { mebt_set_error("loss: the last forward ran on caller-embedded inputs (no token ids to score against)"); return MEBT_EINVAL; }
@@ -697,7 +700,18 @@ extern "C" int mebt_loss(mebt_model* m, void* ws, const float* logits, double* o
     CeParams p;
     p.logits = logits; p.x_ids = x.x_ids; p.ti = x.ti; p.rows = x.B * x.NT; p.V = m->d.vocab; p.B = x.B; p.N = x.N; p.NT = x.NT;
     p.label_smoothing = m->d.label_smoothing; p.row_lse = x.row_lse; p.row_loss = x.row_loss; p.row_rank = x.row_rank; p.out = out4;
+    x.dlogits_ready = false;
+    if (with_grad && x.dlogits && ce_fwd_can_fuse_grad(p.V)) {     // other vocabulary sizes: statistics only, mebt_backward_head runs the CE backward
+        p.dlogits = x.dlogits; p.grad_scale = loss_scale; p.dl_bf16 = m->d.dtype == MEBT_BF16;
+        x.dlogits_ready = true; x.dlogits_scale = loss_scale;
+    }
     return launch_ce_fwd(p, S(stream));
+}
+extern "C" int mebt_loss(mebt_model* m, void* ws, const float* logits, double* out4, mebt_stream_t stream) {
+    return loss_impl(m, ws, logits, out4, false, 0.f, stream);
+}
+extern "C" int mebt_loss_with_grad(mebt_model* m, void* ws, const float* logits, double* out4, float loss_scale, mebt_stream_t stream) {
+    return loss_impl(m, ws, logits, out4, true, loss_scale, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -773,6 +787,10 @@ extern "C" int mebt_backward_head(mebt_model* m, void* ws, const float* logits, 
     RC(backward_prologue(m, ws, st));
     FwdCtx& x = m->ctx;
     const int V = m->d.vocab, dt = m->d.dtype, R = x.B * x.NT;
+    if (x.dlogits_ready && !upstream && x.dlogits_scale == loss_scale) {     // mebt_loss_with_grad already wrote the same dlogits
+        x.dlogits_ready = false;
+        return head_backward_common(m, st);
+    }
     if (!x.loss_done) RC(mebt_loss(m, ws, logits, nullptr, stream));   // the CE backward needs the per-row logsumexp
     CeBwdParams cp;
     cp.logits = logits; cp.x_ids = x.x_ids; cp.ti = x.ti; cp.row_lse = x.row_lse; cp.dlogits = x.dlogits; cp.upstream = upstream;

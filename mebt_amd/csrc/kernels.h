@@ -176,8 +176,15 @@ struct CeParams {
     float* row_loss;          // [rows]
     int* row_rank;            // [rows] number of classes ranked above the target
     double* out;              // [4]: loss_sum, n_top1, n_top5, rows
+    // optional: also d(loss_sum * grad_scale)/dlogits [rows,V] (bf16 if dl_bf16 else fp32) from the same pass over the row — what
+    // launch_ce_bwd computes (same expressions; agrees to fp32 rounding), without reading the 200 MB of logits a second time.  Only for V = 16384
+    // (launch_ce_fwd returns with `dlogits` untouched otherwise: check ce_fwd_can_fuse_grad first).
+    void* dlogits = nullptr;
+    float grad_scale = 0.f;
+    int dl_bf16 = 0;
 };
 int launch_ce_fwd(const CeParams& p, hipStream_t stream);
+inline bool ce_fwd_can_fuse_grad(int V) { return V == 16384; }
 struct CeBwdParams {
     const float* logits; const int64_t* x_ids; const int64_t* ti; const float* row_lse;
     void* dlogits;            // [rows,V] T

@@ -190,10 +190,15 @@ class NativeModel:
         check(self.lib.mebt_gpt_backward(self.h, ptr(self.ws), ptr(dlogits), *[ptr(o) if o.numel() else None for o in outs], cur_stream()))
         return outs
 
-    def loss_stats(self, logits):
-        """device tensor [4] float64: CE sum, #top-1, #top-5, #rows (of the last training forward)."""
+    def loss_stats(self, logits, grad_scale=None):
+        """device tensor [4] float64: CE sum, #top-1, #top-5, #rows (of the last training forward).  `grad_scale`: the loss
+        scale the following backward will use — the cross-entropy gradient is then produced by the same pass over the logits
+        (mebt_loss_with_grad) and `backward(logits, grad_scale)` skips its own cross-entropy backward."""
         out = torch.empty(4, device=self.device, dtype=torch.float64)
-        check(self.lib.mebt_loss(self.h, ptr(self.ws), ptr(logits), ptr(out), cur_stream()))
+        if grad_scale is None:
+            check(self.lib.mebt_loss(self.h, ptr(self.ws), ptr(logits), ptr(out), cur_stream()))
+        else:
+            check(self.lib.mebt_loss_with_grad(self.h, ptr(self.ws), ptr(logits), ptr(out), float(grad_scale), cur_stream()))
         return out
 
     def backward_head(self, logits, loss_scale, upstream=None):

@@ -72,7 +72,9 @@ class TrainLoop:
         scale = 1.0 / (B * seq_len * ratio ** m.config.avg_loss)
         lr = m.learning_rate * m.lr_scale()
         logits = nm.forward(x_ids, ci, ti, training=True, dropout_seed=m._next_seed())
-        stats = nm.loss_stats(logits)
+        # loss statistics and d(loss)/d(logits) from one pass over the logits (the scale every backward call below uses)
+        fused_ce = os.environ.get("MEBT_FUSED_CE", "1") != "0"      # 0: separate cross-entropy forward / backward kernels (A/B)
+        stats = nm.loss_stats(logits, grad_scale=(scale / self.accum if self.accum > 1 else scale) if fused_ce else None)
         if self.accum > 1:
             self._micro += 1
             nm.set_grad_accumulate(self._micro > 1)

@@ -354,6 +354,35 @@ def test_trainloop_fused_optimizer(name):
         assert d <= 1e-6 * max(1.0, a.abs().max().item()), (what, d)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_cross_entropy_forward_and_gradient(dtype, monkeypatch):
+    """`mebt_loss_with_grad` (loss statistics + d loss / d logits from one pass over the logits, the default of `TrainLoop.step`)
+    against the separate cross-entropy forward / backward kernels (`MEBT_FUSED_CE=0`): the same expressions in the same summation
+    order, so statistics and parameters after three steps agree to fp32 rounding (measured: 2.6e-8 on the weights; the compiler
+    contracts the two kernels' arithmetic differently), incl. a run with gradient accumulation."""
+    from mebt_amd.trainer import TrainLoop
+    g = load_golden("train_micro")
+    finals = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MEBT_FUSED_CE", fused)
+        for accum in (1, 2):
+            model = build_product("micro", dtype).train()
+            model.learning_rate, model.weight_decay, model.warmup_steps, model.cosine_lr = float(g["lr"]), float(g["wd"]), 0, False
+            loop = TrainLoop(model, fused_optimizer=False, accumulate_grad_batches=accum)
+            stats = []
+            for s, t in enumerate(g["ts"]):
+                x, idx = torch.from_numpy(g[f"s{s}_x"]).to(DEV), torch.from_numpy(g[f"s{s}_indices"]).to(DEV)
+                stats.append(loop.step(x, idx, t=float(t)).cpu())
+            torch.cuda.synchronize()
+            nm = loop.native
+            finals.append((fused, accum, torch.stack(stats), nm.W.clone(), nm.P.clone()))
+    for a, b in ((finals[0], finals[2]), (finals[1], finals[3])):
+        assert a[1] == b[1] and a[0] != b[0]
+        assert (a[2] - b[2]).abs().max() <= 1e-6 * a[2].abs().max(), (a[1], a[2], b[2])
+        tol = 1e-6 if dtype == "f32" else 2e-5                      # bf16 engine: a last-bit difference in dlogits can flip a bf16 rounding downstream
+        assert (a[3] - b[3]).abs().max() <= tol * a[3].abs().max() and (a[4] - b[4]).abs().max() <= tol * max(1.0, float(a[4].abs().max())), (a[1], (a[3] - b[3]).abs().max())
+
+
 def test_launcher_trains_from_token_file(tmp_path):
     """`python -m mebt_amd.train` (counterpart of train_transformer.py) on a token file in the reference's vtokens
     container layout: runs, logs finite losses, writes a Lightning-layout checkpoint that loads back."""
