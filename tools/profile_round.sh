@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-round profiling recipe (run on the GPU box through gpurun):  tools/profile_round.sh <tag>
 #   1. populate the GEMM tune cache (so the profiled runs launch no tuning candidates),
-#   2. rocprofv3 --kernel-trace --stats of `bench.py` (19 steps in all: 5 warm-up + 10 timed + 2 host-enqueue-timed + 2 event-profiled),
+#   2. rocprofv3 --kernel-trace --stats of `bench.py` (20 steps in all: 1 priming (tuner) + 5 warm-up + 10 timed + 2 host-enqueue-timed + 2 event-profiled; the round-3 CSV predates the priming step: 19),
 #   3. three separate --pmc passes (FETCH_SIZE, WRITE_SIZE, MFMA busy cycles) as MI355X_MICROARCH.md prescribes.
 # Summaries land in gpurun_out/<tag>/; copy what is to be judged into profiles/.
 TAG=${1:-prof}
