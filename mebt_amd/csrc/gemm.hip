@@ -207,8 +207,14 @@ static int time_cold(F&& launch, hipStream_t stream, const TuneRun& tr, float& b
     hipEvent_t e0 = tr.e0, e1 = tr.e1;
     launch();                                                                    // code object, TLBs
     static const int warm = [] { const char* e = getenv("MEBT_GEMM_TUNE_WARM"); return e ? atoi(e) : 0; }();   // experiment: time candidates on warm caches
+    // How cold?  In the step a product's weights were prefetched into the Infinity Cache by its predecessor and its activations
+    // were just written: L2-cold, Infinity-Cache-warm.  A 384 MB flush also empties the 256 MB Infinity Cache and ranks the
+    // candidates for a situation that never occurs: fresh-tuned steps were 0.2-0.3 ms slower than with 96-256 MB flushes
+    // (three boxes, profiles/r03_tuner_flush_size_ab.txt).  128 MB evicts the L2s (32 MB) several times over and leaves the
+    // just-touched operands in the Infinity Cache.  MEBT_GEMM_TUNE_FLUSH_MB overrides.
+    static const size_t flush_cap = [] { const char* e = getenv("MEBT_GEMM_TUNE_FLUSH_MB"); return (size_t)(e ? atol(e) : 128) << 20; }();
     for (int r = 0; r < 2; ++r) {
-        if (!warm) MEBT_HIP_CHECK(hipMemsetAsync(tr.sc->flush, r, tr.sc->flush_bytes, stream));
+        if (!warm) MEBT_HIP_CHECK(hipMemsetAsync(tr.sc->flush, r, tr.sc->flush_bytes < flush_cap ? tr.sc->flush_bytes : flush_cap, stream));
         MEBT_HIP_CHECK(hipEventRecord(e0, stream));
         launch();
         MEBT_HIP_CHECK(hipEventRecord(e1, stream));
