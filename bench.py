@@ -9,7 +9,8 @@ step    : embed -> 24 blocks -> head -> masked-token CE (+top-1/5) -> full backw
           (reduce-scatter / sharded AdamW / all-gather when N>1) -> AdamW.  Inputs are resident in HBM
           before timing starts.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--secondary none|light|full]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--secondary none|light|full|c4|c5]
+  (--secondary c4 / c5: ONLY that configuration's legs, no headline step — the process a rocprofv3 profile of config 4 / 5 wraps)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `roofline` = the GEMM kernel family (93 % of the step's FLOPs),
@@ -36,7 +37,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.29 TB/s measured with a float4 copy, same guide)
-TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 --pmc summaries, newest first
+TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 --pmc summaries, newest first
 
 
 def synthetic_batch(B, shape, rank, device):
@@ -112,6 +113,8 @@ def secondary_metrics(args, cfg, model, loop, x, idx, device, lib, level):
     sync = torch.cuda.synchronize
     B = args.batch
     out = {}
+    if level in ("c4", "c5"):                  # one configuration only (no model of the headline config exists in this process)
+        return secondary_c4(args, device, lib) if level == "c4" else secondary_c5(args, device, lib)
     ocfg = cfg.model.params
     forward_flops_per_sample = presets.forward_flops_per_sample
 
@@ -209,9 +212,35 @@ def secondary_metrics(args, cfg, model, loop, x, idx, device, lib, level):
     model.mask_sampler.schedule = cfg.model.mask.params.schedule
     model.train()
 
+    del sep
+    # (6b) the reference's own arithmetic: the same step on the exact-fp32 engine (every GEMM on v_mfma_f32_32x32x2_f32, fp32
+    # attention; train_transformer.py sets no precision, so the reference trains in fp32) — parity-tested, here timed
+    torch.manual_seed(0)
+    fm = presets.build_model(cfg, compute_dtype="f32").to(device).train()
+    fl = TrainLoop(fm, fused_optimizer=False)
+    for _ in range(2):
+        fl.step(x, idx, t=args.t)
+    dt = timed(lambda: fl.step(x, idx, t=args.t), 5, sync)
+    flops = 3 * forward_flops_per_sample(ocfg, 512, 512) * B
+    out["fp32_step"] = {"ms_per_step": round(dt * 1e3, 3), "masked_tokens_per_s": round(B * 512 / dt, 1), "tflops": round(flops / dt / 1e12, 1),
+                        "frac_of_fp32_mfma_peak": round(flops / dt / 1e12 / PEAK_F32_TFLOPS, 4),
+                        "note": "exact-fp32 engine (the 1e-3 parity gate), separate AdamW; peak = 157.3 TFLOP/s fp32 MFMA"}
+    del fm, fl
+    torch.cuda.empty_cache()
+    out.update(secondary_c4(args, device, lib))
+    out.update(secondary_c5(args, device, lib))
+    return out
+
+
+def secondary_c4(args, device, lib):
+    """BASELINE.json configs[3]: UCF-101 128f geometry (block 8192) — the shipped inference schedules and one train step."""
+    from mebt_amd import presets, _lib
+    from mebt_amd.trainer import TrainLoop
+    sync = torch.cuda.synchronize
+    forward_flops_per_sample = presets.forward_flops_per_sample
+    out = {}
     # (7) C4: UCF-101 128f geometry (block 8192), the revise schedule of the shipped script: M = 2 x 32 revise forwards at
     # (NC, NT) = (7936, 256), batch 4
-    del sep
     ucfg = presets.ucf_128f()
     torch.manual_seed(1)
     um = presets.build_model(ucfg, compute_dtype=args.dtype).to(device).eval()
@@ -233,8 +262,45 @@ def secondary_metrics(args, cfg, model, loop, x, idx, device, lib, level):
         f()
         dt = timed(f, 1, sync)
     out["c4_sample_30_steps"] = {"batch": 4, "s": round(dt, 3), "sampler_steps_per_s": round(30 / dt, 1), "tokens_per_s": round(4 * 8192 / dt, 1)}
+    # the shipped UCF-128f draft producer (scripts/valid_dnr_config_ckpt_exp_ucf_128f.sh:10-15 -> sample_vqgan_transformer_videos.py:22-94):
+    # bidirect_sample with --bootstrap 64 --top_k 32, then 32 MaskGIT steps; FLOP model of SURVEY.md §8d (107.8 + 36.5 TFLOP/sample)
+    from mebt_amd.sampling import bidirect_sample
+    with torch.no_grad():
+        f = lambda: bidirect_sample(um, 4, 128, 128, 128, temperature=1.0, top_k=32, top_p=None, vid_n_steps=32, vid_c_temp=2.0, bootstrap=64)
+        f()
+        dt = timed(f, 1, sync)
+    fl = 4 * (107.8e12 + 36.5e12)
+    out["c4_bootstrap64_topk32"] = {"batch": 4, "s": round(dt, 3), "forwards": 96, "tflops": round(fl / dt / 1e12, 1),
+                                    "frac_of_bf16_mfma_peak": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "videos_per_s": round(4 / dt, 3),
+                                    "note": "bidirect_sample(bootstrap=64, top_k=32, vid_n_steps=32, vid_c_temp=2.0) at block 8192 incl. the [4, 8192, 16384] "
+                                            "probability maps of debug=True; FLOPs = SURVEY.md §8d's 107.8 + 36.5 TFLOP per sample"}
+    um.mask_sampler.schedule = ucfg.model.mask.params.schedule
     del um
+    torch.cuda.empty_cache()
+    # TRAINING at block 8192 (configs/ucf/mebt_128f.yaml:4-57): B = 4, t = 0.5 on the full sequence -> NC = NT = 4096
+    torch.manual_seed(1)
+    tm = presets.build_model(ucfg, compute_dtype=args.dtype).to(device).train()
+    tm.t_prior = lambda lengths, step: __import__("numpy").eye(len(lengths))[-1]      # always the full 32 latent frames (the curriculum's end state)
+    tl = TrainLoop(tm)
+    xt, it = synthetic_batch(4, [32, 16, 16], 0, device)
+    for _ in range(3):
+        tl.step(xt, it, t=0.5)
+    dt = timed(lambda: tl.step(xt, it, t=0.5), 5, sync)
+    fl = 3 * 4 * forward_flops_per_sample(uo, 4096, 4096)
+    out["c4_train_step"] = {"batch": 4, "NC": 4096, "NT": 4096, "ms_per_step": round(dt * 1e3, 3), "masked_tokens_per_s": round(4 * 4096 / dt, 1),
+                            "tflops": round(fl / dt / 1e12, 1), "frac_of_bf16_mfma_peak": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+                            "optimizer": "in-backward" if tl.fused_optimizer else "separate"}
+    del tm, tl
+    torch.cuda.empty_cache()
 
+    return out
+
+
+def secondary_c5(args, device, lib):
+    """BASELINE.json configs[4]: Taichi 16f end to end."""
+    from mebt_amd import presets, _lib
+    sync = torch.cuda.synchronize
+    out = {}
     # (8) C5 (BASELINE.json configs[4]): Taichi 16f end to end — pixels -> 3D-VQGAN encode (fp16 MFMA, fp32 codebook search) ->
     # MeBT sampling as the shipped script runs it (64-step MaskGIT draft, then M = 8 x 2 revise forwards at T = 0.3) ->
     # 3D-VQGAN decode, batch 4, random-init weights
@@ -292,6 +358,8 @@ def secondary_metrics(args, cfg, model, loop, x, idx, device, lib, level):
     return out
 
 
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,7 +370,7 @@ def main():
     ap.add_argument("--t", type=float, default=0.5)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--secondary", default="full", choices=["none", "light", "full"])
+    ap.add_argument("--secondary", default="full", choices=["none", "light", "full", "c4", "c5"])
     ap.add_argument("--preset", default="sky_16f", choices=["sky_16f", "tiny"])
     args = ap.parse_args()
 
@@ -345,6 +413,13 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    if args.secondary in ("c4", "c5"):        # profiling aid: only that configuration's legs run in this process, no headline step
+        assert world == 1
+        lib = _lib.load()
+        sec = secondary_metrics(args, None, None, None, None, None, device, lib, args.secondary)
+        os.write(real_stdout, (json.dumps({"metric": "secondary legs only (profiling run)", "value": None, "only": args.secondary, "dtype": args.dtype,
+                                           "data": "synthetic", "secondary": sec}) + "\n").encode())
+        return
     # the Sky config trains with embd/resid/attn dropout 0.1 (configs/stl/mebt_16f.yaml:12-14): the measured
     # step includes it (counter-based masks, recomputed in backward)
     cfg = presets.sky_16f(vtokens=True, dropout=args.dropout) if args.preset == "sky_16f" else presets.tiny()
@@ -362,6 +437,8 @@ def main():
         try:
             loop.step(x, idx, t=args.t)
             torch.cuda.synchronize()
+            if os.environ.get("MEBT_BENCH_FAIL_SHARDED") == "1":      # tests: exercise the fallback below after a real (half-applied) sharded step
+                raise RuntimeError("injected failure of the sharded data-parallel step (MEBT_BENCH_FAIL_SHARDED=1)")
         except Exception as e:          # noqa: BLE001
             dp_fallback = f"{type(e).__name__}: {e}"
             print(f"[bench] sharded data-parallel step failed ({dp_fallback}); falling back to MEBT_DP_MODE=allreduce", file=sys.stderr, flush=True)
@@ -410,6 +487,50 @@ def main():
     sync()
     value = world * n_targets * args.steps / elapsed
     wire_bytes_per_step = (reducer.bytes_on_wire - wire0) / max(1, args.steps)
+
+    # dominant kernel family: MFMA GEMMs — time every launch of 2 more steps with HIP events on the
+    # launch stream (rank 0 records; every rank runs the steps because they contain collectives).  Taken BEFORE the
+    # data-parallel self-description below, whose elided / one-rank steps leave the ranks' weights inconsistent
+    lib = _lib.load()
+    if rank == 0:
+        lib.mebt_profile_enable(1)
+    for _ in range(2):
+        loop.step(x, idx, t=args.t)
+    sync()
+    roof = None
+    n, tms, fl = C.c_double(), C.c_double(), C.c_double()
+    if rank == 0:
+        _lib.check(lib.mebt_profile_read(0, C.byref(n), C.byref(tms), C.byref(fl)))
+        nb, tb, by = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(lib.mebt_profile_read(1, C.byref(nb), C.byref(tb), C.byref(by)))
+        lib.mebt_profile_enable(0)
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        # HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (separate
+        # FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction: tools/pmc_traffic.py).  PMC counters cannot be
+        # collected inside this process; the source file is named so that a stale figure is visible.
+        traffic, traffic_src, traffic_stale = None, None, None
+        if args.dtype == "bf16" and world == 1:
+            from mebt_amd.launch import csrc_fingerprint
+            for fn in TRAFFIC_FILES:
+                try:
+                    with open(os.path.join(ROOT, "profiles", fn)) as f:
+                        prof = json.load(f)
+                    traffic = round(prof["gemm_bf16"]["hbm_bytes_per_launch"])
+                    traffic_src = "profiles/" + fn
+                    # a PMC profile belongs to the kernel sources it was taken on: anything else is reported as stale, not as a number
+                    traffic_stale = prof.get("_csrc_sha256") != csrc_fingerprint()
+                    if traffic_stale:
+                        traffic = None
+                    break
+                except (OSError, KeyError, ValueError):
+                    continue
+        achieved = fl.value / (tms.value * 1e-3) / 1e12 if tms.value > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                "algorithmic_bytes_per_launch": round(by.value / max(1.0, nb.value)),
+                "kernel": "bf16 MFMA GEMM family (gemm_bf16_dma[_ks2] / gemm_pair / wgrad_grouped incl. its fused AdamW epilogue)" if args.dtype == "bf16" else "gemm_f32_kernel",
+                "launches_per_step": n.value / 2, "gemm_ms_per_step": round(tms.value / 2, 3),
+                "gemm_gflop_per_step": round(fl.value / 2 / 1e9, 1)}
 
     # data-parallel runs describe themselves: which path ran, how many ranks RCCL really spans, what went
     # over the wire, how much of the communication was NOT hidden, and the efficiency against this same GPU's one-rank step
@@ -468,49 +589,6 @@ def main():
               "scaling_efficiency_vs_fused": round(solo["fused_optimizer"] / ms, 4),
               "scaling_efficiency_note": "per-GPU throughput of this run / per-GPU throughput of ONE rank of this job alone on its GPU (rank 0's figure), "
                                          "separate_optimizer = gradients stored + streaming AdamW, fused = the N = 1 headline path"}
-
-    # dominant kernel family: MFMA GEMMs — time every launch of 2 more steps with HIP events on the
-    # launch stream (rank 0 records; every rank runs the steps because they contain collectives)
-    lib = _lib.load()
-    if rank == 0:
-        lib.mebt_profile_enable(1)
-    for _ in range(2):
-        loop.step(x, idx, t=args.t)
-    sync()
-    roof = None
-    n, tms, fl = C.c_double(), C.c_double(), C.c_double()
-    if rank == 0:
-        _lib.check(lib.mebt_profile_read(0, C.byref(n), C.byref(tms), C.byref(fl)))
-        nb, tb, by = C.c_double(), C.c_double(), C.c_double()
-        _lib.check(lib.mebt_profile_read(1, C.byref(nb), C.byref(tb), C.byref(by)))
-        lib.mebt_profile_enable(0)
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        # HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (separate
-        # FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction: tools/pmc_traffic.py).  PMC counters cannot be
-        # collected inside this process; the source file is named so that a stale figure is visible.
-        traffic, traffic_src, traffic_stale = None, None, None
-        if args.dtype == "bf16" and world == 1:
-            from mebt_amd.launch import csrc_fingerprint
-            for fn in TRAFFIC_FILES:
-                try:
-                    with open(os.path.join(ROOT, "profiles", fn)) as f:
-                        prof = json.load(f)
-                    traffic = round(prof["gemm_bf16"]["hbm_bytes_per_launch"])
-                    traffic_src = "profiles/" + fn
-                    # a PMC profile belongs to the kernel sources it was taken on: anything else is reported as stale, not as a number
-                    traffic_stale = prof.get("_csrc_sha256") != csrc_fingerprint()
-                    if traffic_stale:
-                        traffic = None
-                    break
-                except (OSError, KeyError, ValueError):
-                    continue
-        achieved = fl.value / (tms.value * 1e-3) / 1e12 if tms.value > 0 else 0.0
-        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
-                "algorithmic_bytes_per_launch": round(by.value / max(1.0, nb.value)),
-                "kernel": "bf16 MFMA GEMM family (gemm_bf16_dma[_ks2] / gemm_pair / wgrad_grouped incl. its fused AdamW epilogue)" if args.dtype == "bf16" else "gemm_f32_kernel",
-                "launches_per_step": n.value / 2, "gemm_ms_per_step": round(tms.value / 2, 3),
-                "gemm_gflop_per_step": round(fl.value / 2 / 1e9, 1)}
 
     if rank == 0:
         out = {"metric": "masked video tokens/sec/GPU (train step, 24L d=1024, 1024+256 tok)",

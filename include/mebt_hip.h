@@ -10,8 +10,10 @@
  * hipStream_t passed as an opaque pointer (NULL = default stream).  Entry points launch on that
  * stream only and do not synchronise with the host, with ONE exception: in bf16 mode the first
  * launch of a GEMM signature the process has not seen times its tile candidates on the caller's
- * stream (hipEventSynchronize) before it returns.  mebt_gemm_autotune(0), MEBT_GEMM_AUTOTUNE=0 or
- * a populated MEBT_GEMM_TUNE_CACHE remove that exception; then every entry point is capturable.
+ * stream (hipEventSynchronize) before it returns.  mebt_gemm_autotune(0), MEBT_GEMM_AUTOTUNE=0, a
+ * populated MEBT_GEMM_TUNE_CACHE or a table merged with mebt_gemm_tune_import (the Python host side
+ * merges the shipped mebt_amd/tune/gfx950.txt) remove that exception for the signatures they cover;
+ * then every entry point is capturable.
  * Re-entrancy: one thread per model handle + workspace; the tuned-configuration table shared by
  * all handles is a mutex-guarded shape -> configuration cache.
  *
@@ -226,6 +228,14 @@ int mebt_op_cast_bf16(const float* src, void* dst, int64_t n, mebt_stream_t stre
 /* 0: never time GEMM candidates (measured heuristic or cached choices only: no host synchronisation anywhere);
  * 1: tune unseen signatures at their first launch (default; environment MEBT_GEMM_AUTOTUNE). */
 void mebt_gemm_autotune(int32_t mode);
+/* The tuned-configuration table as text (one `n k_0 .. k_{n-1} value` entry per line + a version entry): export returns the bytes
+ * needed incl. the terminating 0 and writes them when `cap` suffices; import merges a text (overwrite = 1: its entries replace the
+ * ones this process holds; 2: the table is dropped first, i.e. replaced; 0: they only fill gaps) and returns the number of entries taken (0 for a text written by a build
+ * with other variant codes).  A data-parallel job broadcasts rank 0's table after its first step so that every rank launches
+ * identical kernels (reference train_transformer.py:39-46: DDP replicas run the same program); mebt_amd ships a default table
+ * (mebt_amd/tune/gfx950.txt) merged with overwrite = 0 at load time, so a fresh process does not stall on in-situ tuning. */
+int64_t mebt_gemm_tune_export(char* buf, int64_t cap);
+int32_t mebt_gemm_tune_import(const char* text, int32_t overwrite);
 
 /* ---- 3D-VQGAN first stage (reference mebt/vqgan.py:82-93,255-424, modules/codebook.py:52-62) ------------
  * Activations are channels-last [B, T, H, W, C] of `dtype` (MEBT_DTYPE_F16: MFMA fast mode, MEBT_DTYPE_F32: parity mode); the

@@ -10,6 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MEBT_HIP_LIB: another BUILD of the same library (tools/ab_bench.sh times two builds on one box); same ABI, same failure if absent
 LIB_PATH = os.environ.get("MEBT_HIP_LIB") or os.path.join(_HERE, "lib", "libmebt_hip.so")
 
+SHIPPED_TUNE = os.path.join(_HERE, "tune", "gfx950.txt")
+
 MEBT_MAX_LAYERS = 128
 F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_GELU_BWD = 0, 1, 2, 3
@@ -80,6 +82,8 @@ PROTOTYPES = {
     "mebt_debug_gemm_scratch": (None, [c_vp, c_i64]),
     "mebt_debug_gemm_stamps": (None, [c_vp]),
     "mebt_gemm_autotune": (None, [c_i32]),
+    "mebt_gemm_tune_export": (c_i64, [C.c_char_p, c_i64]),
+    "mebt_gemm_tune_import": (c_i32, [C.c_char_p, c_i32]),
     "mebt_profile_enable": (c_i32, [c_i32]),
     "mebt_profile_read": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -103,7 +107,26 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # the shipped table of tuned GEMM configurations (choices measured on MI355X for the shipped configs' signatures): merged
+    # WITHOUT overwriting, so MEBT_GEMM_TUNE_CACHE and in-situ tuning keep precedence and unseen signatures still tune at their
+    # first launch.  MEBT_GEMM_TUNE_SHIPPED=0 starts from an empty table (fresh-tuning runs).
+    if os.environ.get("MEBT_GEMM_TUNE_SHIPPED", "1") != "0" and os.path.exists(SHIPPED_TUNE):
+        with open(SHIPPED_TUNE, "rb") as f:
+            lib.mebt_gemm_tune_import(f.read(), 0)
     return lib
+
+
+def tune_table_text():
+    """the process-wide GEMM configuration table as text (include/mebt_hip.h: mebt_gemm_tune_export)"""
+    lib = load()
+    n = lib.mebt_gemm_tune_export(None, 0)
+    buf = C.create_string_buffer(int(n))
+    lib.mebt_gemm_tune_export(buf, n)
+    return buf.value.decode()
+
+
+def tune_table_merge(text, overwrite=True, replace=False):
+    return int(load().mebt_gemm_tune_import(text.encode() if isinstance(text, str) else text, 2 if replace else (1 if overwrite else 0)))
 
 
 class MebtError(RuntimeError):

@@ -806,6 +806,7 @@ extern "C" int mebt_backward_head_dlogits(mebt_model* m, void* ws, const float* 
     RC(backward_prologue(m, ws, st));
     FwdCtx& x = m->ctx;
     if (!dlogits) { mebt_set_error("backward: null dlogits"); return MEBT_EINVAL; }
+    x.dlogits_ready = false;       // x.dlogits is overwritten below: a later mebt_backward_head must not take it for the cross-entropy gradient
     const size_t n = (size_t)x.B * x.NT * m->d.vocab;
     if (m->d.dtype == MEBT_BF16) RC(launch_cast_f32_to_bf16(dlogits, x.dlogits, n, st));
     else MEBT_HIP_CHECK(hipMemcpyAsync(x.dlogits, dlogits, n * 4, hipMemcpyDeviceToDevice, st));

@@ -8,6 +8,8 @@
 #include <map>
 #include <mutex>
 #include <vector>
+#include <string>
+#include <cstring>
 
 void mebt_gemm_cfg_kk(const GemmParams&, int, int, int, int, hipStream_t);
 void mebt_gemm_cfg_kr(const GemmParams&, int, int, int, int, hipStream_t);
@@ -67,6 +69,22 @@ extern "C" void mebt_debug_gemm_tile(int bm, int bn) { g_gemm_force_tile = (bm &
 // process-wide buffer a benchmark tool installed through mebt_debug_gemm_scratch().
 static GemmScratch g_default_scratch = {nullptr, 0, nullptr, 0};
 static const GemmScratch* scratch_of(const GemmScratch* s) { return (s && s->flush) ? s : (g_default_scratch.flush ? &g_default_scratch : nullptr); }
+// Tuning needs the flush buffer at its real size: a model created while tuning was off carved 16 bytes (engine.cpp carve()), and
+// candidates timed behind a 16-byte "flush" are timed warm — the regime that measured worse picks.  Such a model
+// keeps the heuristic / cached configurations and says so once.
+static const GemmScratch* tune_scratch_of(const GemmScratch* s) {
+    const GemmScratch* sc = scratch_of(s);
+    if (sc && sc->flush_bytes < (64u << 20)) {
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "[mebt gemm autotune] tuning was switched on after this model's workspace was laid out without the cache-flush buffer: "
+                            "its launches keep the heuristic / cached configurations (create the model with tuning on to tune in situ)\n");
+        }
+        return nullptr;
+    }
+    return sc;
+}
 extern "C" void mebt_debug_gemm_scratch(void* buf, int64_t bytes) {
     if (!buf || bytes < (int64_t)(MEBT_TUNE_FLUSH_BYTES + MEBT_TUNE_SPLITK_BYTES)) { g_default_scratch = {nullptr, 0, nullptr, 0}; return; }
     g_default_scratch = {buf, MEBT_TUNE_FLUSH_BYTES, (float*)((char*)buf + MEBT_TUNE_FLUSH_BYTES), (size_t)bytes - MEBT_TUNE_FLUSH_BYTES};
@@ -138,6 +156,41 @@ static const char* g_tune_cache = nullptr;                       // MEBT_GEMM_TU
 
 // environment: MEBT_GEMM_AUTOTUNE=0 disables tuning, MEBT_GEMM_TUNE_LOG=1 prints choices, MEBT_GEMM_TUNE_CACHE=<file>
 // loads earlier choices at start-up and appends new ones (a later process then launches no tuning candidates)
+// Text form of the table (MEBT_GEMM_TUNE_CACHE files, mebt_gemm_tune_export / _import, the shipped mebt_amd/tune/*.txt): one entry
+// per line, `n k_0 ... k_{n-1} value`.  The entry with the key {-1} carries MEBT_TUNE_VERSION: a text written by a build whose
+// variant codes meant something else is ignored as a whole (an unversioned text is taken as version 1).
+#define MEBT_TUNE_VERSION 4
+static int tune_parse(const char* text, bool overwrite, bool replace = false) {
+    std::vector<std::pair<TuneKey, int>> ent;
+    int version = 1;
+    const char* c = text;
+    auto next_int = [&](int& v) -> bool {
+        char* e = nullptr;
+        const long x = strtol(c, &e, 10);
+        if (e == c) return false;
+        c = e; v = (int)x;
+        return true;
+    };
+    int n;
+    while (next_int(n) && n > 0 && n < 64) {
+        TuneKey k(n);
+        bool ok = true;
+        for (int i = 0; i < n && ok; ++i) ok = next_int(k[i]);
+        int v;
+        if (!ok || !next_int(v)) break;
+        if (n == 1 && k[0] == -1) version = v;
+        else ent.emplace_back(k, v);
+    }
+    if (version != MEBT_TUNE_VERSION) return 0;
+    if (replace) g_tuned.clear();
+    int taken = 0;
+    for (auto& e : ent) {
+        if (!overwrite && g_tuned.count(e.first)) continue;
+        g_tuned[e.first] = e.second;
+        ++taken;
+    }
+    return taken;
+}
 static void tune_init() {
     if (g_autotune >= 0) return;
     const char* e = getenv("MEBT_GEMM_AUTOTUNE");
@@ -146,18 +199,18 @@ static void tune_init() {
     g_tune_log = l ? atoi(l) : 0;                     // 1: decisions, 2: every candidate
     g_tune_cache = getenv("MEBT_GEMM_TUNE_CACHE");
     if (g_tune_cache && g_tune_cache[0]) {
-        if (FILE* f = fopen(g_tune_cache, "r")) {      // one entry per line: n k_0 ... k_{n-1} value
-            int n;
-            while (fscanf(f, "%d", &n) == 1 && n > 0 && n < 64) {
-                TuneKey k(n);
-                bool ok = true;
-                for (int i = 0; i < n; ++i) ok = ok && fscanf(f, "%d", &k[i]) == 1;
-                int v;
-                if (!ok || fscanf(f, "%d", &v) != 1) break;
-                g_tuned[k] = v;
-            }
+        bool fresh = true;
+        if (FILE* f = fopen(g_tune_cache, "r")) {
+            std::string text;
+            char buf[4096];
+            size_t got;
+            while ((got = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, got);
             fclose(f);
+            fresh = text.empty();
+            tune_parse(text.c_str(), true);
         }
+        if (fresh)
+            if (FILE* f = fopen(g_tune_cache, "a")) { fprintf(f, "1 -1 %d\n", MEBT_TUNE_VERSION); fclose(f); }
     } else {
         g_tune_cache = nullptr;
     }
@@ -170,6 +223,32 @@ static void tune_remember(const TuneKey& k, int v) {
         fprintf(f, " %d\n", v);
         fclose(f);
     }
+}
+// The table as text (see tune_parse): returns the bytes needed incl. the terminating 0; writes them when `cap` suffices.  A
+// data-parallel job broadcasts rank 0's table after the first step so that every rank launches the same kernels (VERDICT r03:
+// eight ranks tuning on their own can end with eight tables and a permanent straggler).
+extern "C" int64_t mebt_gemm_tune_export(char* buf, int64_t cap) {
+    std::lock_guard<std::mutex> lk(g_tune_mutex);
+    tune_init();
+    std::string text = "1 -1 " + std::to_string(MEBT_TUNE_VERSION) + "\n";
+    for (auto& e : g_tuned) {
+        text += std::to_string(e.first.size());
+        for (int x : e.first) { text += ' '; text += std::to_string(x); }
+        text += ' '; text += std::to_string(e.second); text += '\n';
+    }
+    const int64_t need = (int64_t)text.size() + 1;
+    if (buf && cap >= need) memcpy(buf, text.c_str(), (size_t)need);
+    return need;
+}
+// Merge a text table: overwrite = 1 replaces entries this process already holds, 2 drops the whole table first (a data-parallel
+// rank adopting rank 0's table: identical tables afterwards), 0 keeps them (a shipped default table never overrides what was
+// tuned here or loaded from MEBT_GEMM_TUNE_CACHE).  Returns the number of entries taken
+// (0 for a text of another MEBT_TUNE_VERSION), negative on a null argument.
+extern "C" int32_t mebt_gemm_tune_import(const char* text, int32_t overwrite) {
+    if (!text) return -1;
+    std::lock_guard<std::mutex> lk(g_tune_mutex);
+    tune_init();
+    return tune_parse(text, overwrite != 0, overwrite == 2);
 }
 // 0: never tune (heuristic / cached choices only; every entry point is then free of host synchronisation and
 // capture-safe), 1: tune unseen signatures at their first launch.  Default: MEBT_GEMM_AUTOTUNE (1).
@@ -363,7 +442,7 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
             const TuneKey key{p.a_kc | (p.b_kc << 1) | (p.epilogue << 2) | (p.c_f32 << 5) | ((p.bias != nullptr) << 6) | ((p.drop.thresh != 0) << 7),
                               tune_bucket(p.M), p.N, tune_bucket(p.K)};
             auto it = g_tuned.find(key);
-            if (it == g_tuned.end() && g_autotune && idempotent && scratch_of(p.scratch)) {
+            if (it == g_tuned.end() && g_autotune && idempotent && tune_scratch_of(p.scratch)) {
                 heuristic_config(p, tbm, tbn, staging);
                 if (int rc = autotune_config(p, stream, tbm, tbn, staging)) return rc;
                 it = g_tuned.emplace(key, (tbm << 20) | (tbn << 8) | staging).first;
@@ -421,7 +500,7 @@ int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipS
         const TuneKey key{0x20000000 | p0.b_kc | (p0.epilogue << 2) | (p1.epilogue << 5) | ((p0.drop.thresh != 0) << 8),
                           tune_bucket(p0.M), p0.N, tune_bucket(p0.K), tune_bucket(p1.M), p1.N, tune_bucket(p1.K)};
         auto it = g_tuned.find(key);
-        if (it == g_tuned.end() && g_autotune && scratch_of(p0.scratch)) {
+        if (it == g_tuned.end() && g_autotune && tune_scratch_of(p0.scratch)) {
             TuneRun tr;
             if (int rc = tr.begin(scratch_of(p0.scratch))) return rc;
             lk.unlock();            // the separate-launch baseline below goes through launch_gemm, which takes the lock itself
@@ -478,7 +557,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
         TuneKey key{0x40000000 | n | (c.fused ? 0x100 : 0) | (c.beta ? 0x200 : 0) | (c.Cb ? 0x400 : 0)};
         for (int i = 0; i < n; ++i) { key.push_back(c.g[i].M); key.push_back(c.g[i].N); key.push_back(tune_bucket(c.g[i].K)); }
         auto it = g_tuned.find(key);
-        if (it == g_tuned.end() && g_autotune && !c.beta && scratch_of(w.scratch)) {
+        if (it == g_tuned.end() && g_autotune && !c.beta && tune_scratch_of(w.scratch)) {
             TuneRun tr;
             if (int rc = tr.begin(scratch_of(w.scratch))) return rc;
             static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};

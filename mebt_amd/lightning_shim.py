@@ -17,8 +17,9 @@ import torch.nn as nn
 # a checkpoint must not need them: the unpickler below stands in for every class of `omegaconf.*` / `pytorch_lightning.*` /
 # `lightning*` with an inert record of the pickled state, and `plain()` rebuilds ordinary containers from OmegaConf's layout
 # (a container keeps its children in `_content`: a dict / list of nodes; a value node keeps its value in `_val`).  Everything
-# else a checkpoint may name is allow-listed (torch, numpy array reconstruction, collections, typing, argparse.Namespace,
-# builtins); any other global is refused instead of imported.
+# else a checkpoint may name is on an exact (module, attribute) allow-list (tensor / storage reconstruction, numpy array
+# reconstruction, OrderedDict, typing markers, argparse.Namespace, plain builtin types); any other global — and any dotted
+# attribute path — is refused instead of imported.
 class _Record:
     """inert stand-in for an instance of a class that is not installed: keeps the pickled state, runs no code of that class"""
 
@@ -49,8 +50,29 @@ class _RecordDict(dict):
 
 _STANDIN_PREFIXES = ("omegaconf", "pytorch_lightning", "lightning", "lightning_fabric")
 _DICT_LIKE = {"AttributeDict"}
-_ALLOWED_MODULES = ("torch", "numpy", "collections", "typing", "argparse", "builtins", "copyreg", "_codecs", "functools", "pathlib", "enum",
-                    "mebt_amd", "mebt", "__builtin__", "copy_reg")     # the last two: protocol-2 spellings (torch.save), mapped by pickle itself
+
+# Exact (module, name) allow-list (a root-module test is no boundary — pickle protocol 4 resolves dotted names, so
+# ('torch', 'os.system') went through it).  A name with a '.' in it is always refused.
+_TORCH_STORAGES = {"FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage", "ShortStorage",
+                   "CharStorage", "ByteStorage", "BoolStorage", "ComplexFloatStorage", "ComplexDoubleStorage", "UntypedStorage"}
+_ALLOWED = {
+    "torch._utils": {"_rebuild_tensor_v2", "_rebuild_tensor", "_rebuild_parameter", "_rebuild_parameter_with_state", "_rebuild_device_tensor_from_numpy"},
+    "torch": _TORCH_STORAGES | {"Size", "device", "Tensor", "dtype"},            # + every torch.dtype singleton, see find_class
+    "torch.nn.parameter": {"Parameter"},
+    "collections": {"OrderedDict"},
+    "numpy": {"ndarray", "dtype"},
+    "numpy.core.multiarray": {"_reconstruct", "scalar"}, "numpy._core.multiarray": {"_reconstruct", "scalar"},
+    "numpy.core.numeric": {"_frombuffer"}, "numpy._core.numeric": {"_frombuffer"},
+    "argparse": {"Namespace"},
+    "typing": {"Any", "Union", "Optional", "Dict", "List", "Tuple"},
+    "builtins": {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "slice", "range", "object"},
+    "copyreg": {"_reconstructor"},          # object.__new__(cls) of an allow-listed / stand-in class (protocol-2 instances)
+    "_codecs": {"encode"},                  # protocol-2 spelling of bytes
+    "pathlib": {"PosixPath", "PurePosixPath", "Path"},
+    "mebt_amd.config": {"AttrDict"},        # hyper-parameters of checkpoints this package saved itself
+}
+_ALLOWED["__builtin__"] = _ALLOWED["builtins"]          # protocol-2 spellings (torch.save default); pickle maps them to the py3 modules itself
+_ALLOWED["copy_reg"] = _ALLOWED["copyreg"]
 
 
 def _standin_class(module, name):
@@ -59,16 +81,23 @@ def _standin_class(module, name):
 
 
 class TolerantUnpickler(pickle.Unpickler):
+    """pickle.Unpickler that resolves ONLY the globals of `_ALLOWED` (exact module and attribute name) and turns every class of
+    omegaconf / pytorch_lightning into an inert record; anything else raises UnpicklingError before it is imported."""
+
     def find_class(self, module, name):
+        if "." in name:
+            raise pickle.UnpicklingError(f"checkpoint names {module}.{name} (a dotted attribute path): refused")
         root = module.split(".", 1)[0]
         if root in _STANDIN_PREFIXES:
             return _standin_class(module, name)
-        if root in _ALLOWED_MODULES:
-            if root in ("builtins", "__builtin__") and name in ("eval", "exec", "compile", "open", "__import__", "getattr", "setattr", "delattr", "input"):
-                raise pickle.UnpicklingError(f"checkpoint names builtins.{name}: refused")
+        ok = name in _ALLOWED.get(module, ())
+        if not ok and module == "torch":        # dtype singletons pickle as the global torch.<name>
+            ok = isinstance(getattr(torch, name, None), torch.dtype)
+        if ok:
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"checkpoint names {module}.{name}, which is outside what a MeBT checkpoint may contain "
-                                     "(torch / numpy / stdlib containers; omegaconf and pytorch_lightning classes are read through stand-ins)")
+                                     "(tensor / storage reconstruction, numpy arrays, stdlib containers; omegaconf and pytorch_lightning "
+                                     "classes are read through stand-ins)")
 
 
 _tolerant_pickle = types.SimpleNamespace(__name__="pickle", Unpickler=TolerantUnpickler, load=lambda f, **kw: TolerantUnpickler(f, **kw).load(),

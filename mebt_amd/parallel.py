@@ -359,6 +359,20 @@ class GradReducer:
         if getattr(native, "Wlp", None) is not None:
             native.sync_lowp(force=True)
 
+    def sync_tune_table(self, src=0):
+        """Every rank adopts rank `src`'s table of tuned GEMM configurations (a collective; TrainLoop calls it after the first
+        step, which is where the in-situ tuner runs).  Ranks that tune on their own can settle on different tiles for the same
+        product — a rank with a slower pick is then the straggler of every later step.  Returns the
+        table text every rank now holds."""
+        from . import _lib
+        if not self.active:
+            return _lib.tune_table_text()
+        box = [_lib.tune_table_text() if self.rank == src else None]
+        dist.broadcast_object_list(box, src=src, group=self.group)
+        if self.rank != src:
+            _lib.tune_table_merge(box[0], replace=True)
+        return box[0]
+
     def consolidate(self, native, optimizer_state=False):
         """Make the fp32 masters (and, on request, the AdamW moments) complete on every rank: after sharded steps each rank
         holds the current values of its own shards only.  A collective: call on ALL ranks (before state_dict / a checkpoint)."""

@@ -24,6 +24,42 @@ import numpy as np
 import torch
 
 
+def parse_gpus(spec, visible=None, device_count=None):
+    """Lightning's `--gpus` (reference scripts/train_config_log_gpus.sh: `--gpus 0,1,2,3,`): an int N = the first N devices,
+    -1 = all of them, a comma list (a trailing comma makes a single id a list: "3," is device 3) = exactly those.  Returns
+    (number of ranks, device mask or None).  Listed ids index the devices this process can see: with HIP_VISIBLE_DEVICES
+    already exported they select FROM that mask (as Lightning's indices do), and an id outside it raises instead of being
+    silently ignored."""
+    if spec is None or str(spec).strip() == "":
+        return 1, None
+    spec = str(spec).strip()
+    visible = os.environ.get("HIP_VISIBLE_DEVICES") if visible is None else visible
+    vis = [v for v in visible.split(",") if v != ""] if visible else None
+    if "," not in spec:
+        n = int(spec)
+        if n == -1:
+            if vis is not None:
+                return max(1, len(vis)), None
+            if device_count is None:
+                import torch
+                device_count = torch.cuda.device_count()       # does not initialise the GPU
+            return max(1, int(device_count)), None
+        if n < 0:
+            raise ValueError(f"--gpus {spec}: expected N >= 0, -1, or a comma-separated device list")
+        if vis is not None and n > len(vis):
+            raise ValueError(f"--gpus {n} but HIP_VISIBLE_DEVICES={visible} exposes {len(vis)} devices")
+        return max(1, n), None
+    ids = [g.strip() for g in spec.split(",") if g.strip() != ""]
+    if not ids:
+        return 1, None
+    if vis is not None:
+        try:
+            ids = [vis[int(i)] for i in ids]
+        except IndexError:
+            raise ValueError(f"--gpus {spec} selects a device outside HIP_VISIBLE_DEVICES={visible}") from None
+    return len(ids), ids
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--base", nargs="*", default=[], metavar="base_config.yaml")
@@ -42,13 +78,12 @@ def main():
     ap.add_argument("--limit_val_batches", type=int, default=0, help="0 = the whole validation set")
     args, unknown = ap.parse_known_args()
 
+    from .launch import spawn_ranks_if_needed, in_distributed_env
     ngpu = 1
-    if args.gpus:
-        ids = [g for g in str(args.gpus).strip(",").split(",") if g != ""]
-        ngpu = int(ids[0]) if len(ids) == 1 and "," not in str(args.gpus) and int(ids[0]) > 1 else len(ids)
-        if len(ids) > 1:
-            os.environ.setdefault("HIP_VISIBLE_DEVICES", ",".join(ids))     # rank r -> r-th listed device
-    from .launch import spawn_ranks_if_needed
+    if not in_distributed_env():          # a rank of the launched job inherits the mask its parent composed: do not apply it twice
+        ngpu, ids = parse_gpus(args.gpus)
+        if ids is not None:
+            os.environ["HIP_VISIBLE_DEVICES"] = ",".join(ids)       # rank r -> r-th listed device
     import sys
     rc = spawn_ranks_if_needed(ngpu, "mebt_amd.train", sys.argv[1:], module=True)      # before anything touches the GPU
     if rc is not None:
@@ -76,7 +111,8 @@ def main():
     model = presets.build_model(cfg, compute_dtype=args.dtype)
     ckpt = None
     if args.ckpt_path:
-        ckpt = torch.load(args.ckpt_path, map_location="cpu", weights_only=False)
+        from .lightning_shim import load_checkpoint_file      # reference checkpoints pickle OmegaConf / Lightning objects
+        ckpt = load_checkpoint_file(args.ckpt_path)
         model.load_state_dict(ckpt["state_dict"], strict=False)
     model = model.to(dev).train()
     accum = cfg.exp.get("accumulate_grad_batches", None) or args.accumulate_grad_batches or 1      # train_transformer.py:46-49
@@ -135,10 +171,16 @@ def main():
 
     t0 = time.perf_counter()
     opt_step = start_step
-    while opt_step < args.max_steps:
+
+    def fetch():
         try:
-            batch = next(it)
+            return next(it)
         except StopIteration:
+            return None
+
+    batch = fetch()
+    while opt_step < args.max_steps:
+        if batch is None:
             epoch += 1
             if args.check_val_every_n_epoch and epoch % args.check_val_every_n_epoch == 0:
                 vloss, v1, v5, nb = validate()
@@ -147,10 +189,11 @@ def main():
             if hasattr(loader.sampler, "set_epoch"):
                 loader.sampler.set_epoch(epoch)
             it = iter(loader)
-            batch = next(it)
+            batch = fetch()
         x, idx = batch["video"], batch["indices"]
-        before = loop.step_count
-        stats = loop.step(x.to(dev, non_blocking=True), idx.to(dev, non_blocking=True))
+        batch = fetch()                   # look ahead: the last batch of an epoch closes its accumulation group (Lightning steps
+        before = loop.step_count          # the optimizer on is_last_batch), so no group spans the validation pass
+        stats = loop.step(x.to(dev, non_blocking=True), idx.to(dev, non_blocking=True), flush=batch is None)
         micro += 1
         if loop.step_count == before:     # a non-final micro-batch of an accumulation group
             continue

@@ -57,9 +57,11 @@ class TrainLoop:
         if self.accum > 1:
             self.fused_optimizer = False
 
-    def step(self, x, indices, t=None):
+    def step(self, x, indices, t=None, flush=False):
         """x [B,T,H,W] int64 tokens, indices [B,N] permutations.  Returns a device tensor
-        [CE sum, #top1, #top5, #rows, loss] (float64) — read it only when you want to log."""
+        [CE sum, #top1, #top5, #rows, loss] (float64) — read it only when you want to log.
+        flush (gradient accumulation only): this is the last batch of the epoch — run the optimizer now even if the group
+        is short, as Lightning does (its accumulation scheduler steps on `is_last_batch`; the loss stays divided by k)."""
         m, nm, red = self.model, self.native, self.reducer
         B = x.shape[0]
         x_ids = x.reshape(B, -1)
@@ -78,7 +80,7 @@ class TrainLoop:
         if self.accum > 1:
             self._micro += 1
             nm.set_grad_accumulate(self._micro > 1)
-            if self._micro < self.accum:                   # not the last micro-batch: local accumulation only (DDP no_sync)
+            if self._micro < self.accum and not flush:     # not the last micro-batch: local accumulation only (DDP no_sync)
                 nm.backward(logits, scale / self.accum)
                 nm.set_grad_accumulate(False)
                 return torch.cat([stats, (stats[0] * scale).reshape(1)])
@@ -131,6 +133,8 @@ class TrainLoop:
             main.wait_stream(opt)                                   # the next forward reads the updated weights
         if self.accum > 1:
             nm.set_grad_accumulate(False)
+        if self.step_count == 1 and red.active and os.environ.get("MEBT_DP_SYNC_TUNE", "1") != "0":
+            red.sync_tune_table()       # the first backward tuned the GEMM tiles in situ on every rank: rank 0's choices win
         m.trainer.global_step += 1
         m.global_step += 1
         return torch.cat([stats, (stats[0] * scale).reshape(1)])

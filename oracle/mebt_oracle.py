@@ -486,7 +486,7 @@ def sample(P, cfg, x, n_steps, temperature, top_k, top_p, context_temperature, n
 
 
 def bidirect_sample(P, cfg, batch_size, total_length, step_size, context_size, temperature, top_k, top_p,
-                    vid_n_steps, vid_c_temp, noise_fn, ctemp_schedule="linear", strategy="maskgit", bootstrap=0):
+                    vid_n_steps, vid_c_temp, noise_fn, ctemp_schedule="linear", strategy="maskgit", bootstrap=0, logits_fn=None):
     """sample_vqgan_transformer_videos.py:22-94 without the VQGAN decode: returns (code_map
     [B,T',H,W], score [B]).  The score gathers over the first window only (the reference's gather
     :89-92 only type-checks when no sliding-window continuation happened)."""
@@ -497,9 +497,9 @@ def bidirect_sample(P, cfg, batch_size, total_length, step_size, context_size, t
     ci = ti = boot = None
     if bootstrap > 0:                                                     # :41-42
         x, ci, ti, boot = sample(P, cfg, x, bootstrap, 1., None, None, vid_c_temp, noise_fn, strategy="bootstrap",
-                                 ctemp_schedule=ctemp_schedule, ci=ci, ti=ti, return_probs=True)
+                                 ctemp_schedule=ctemp_schedule, ci=ci, ti=ti, return_probs=True, logits_fn=logits_fn)
     x, ci, _, final = sample(P, cfg, x.reshape(shape), vid_n_steps, temperature, top_k, top_p, vid_c_temp, noise_fn,
-                             strategy=strategy, ctemp_schedule=ctemp_schedule, ci=ci, ti=ti, return_probs=True)   # :43-46
+                             strategy=strategy, ctemp_schedule=ctemp_schedule, ci=ci, ti=ti, return_probs=True, logits_fn=logits_fn)   # :43-46
     vq = x.reshape(shape)
     code_map, curr_t = [vq], step
     while curr_t < total_length * 0.25:                                   # :55-71
@@ -508,7 +508,7 @@ def bidirect_sample(P, cfg, batch_size, total_length, step_size, context_size, t
         ci = torch.arange(H * W * ctx).repeat(batch_size, 1)
         ti = torch.arange((step - ctx) * H * W).repeat(batch_size, 1) + H * W * ctx
         x = sample(P, cfg, new_x, vid_n_steps, temperature, top_k, top_p, vid_c_temp, noise_fn, strategy=strategy,
-                   ctemp_schedule=ctemp_schedule, ci=ci, ti=ti)[0]
+                   ctemp_schedule=ctemp_schedule, ci=ci, ti=ti, logits_fn=logits_fn)[0]
         vq = x.reshape(shape)
         code_map.append(vq[:, ctx:])
         curr_t += step - ctx

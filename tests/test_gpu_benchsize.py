@@ -141,6 +141,11 @@ def test_c2_bf16_train_step_vs_oracle(dropout):
             bad.append((k, "cos", round(cos, 6), "rel-L2", round(rl2, 5)))
     print(f"[c2 bf16 dropout={dropout}] loss hip {loss_hip:.6f} oracle {r['loss']:.6f}; worst gradient {worst[0]} rel-to-max {worst[1]:.3e}; "
           f"worst cosine {worst_cos[0]} {worst_cos[1]:.6f}; worst rel-L2 {worst_l2[0]} {worst_l2[1]:.3e}")
+    from tests.helpers import record_measured
+    record_measured(f"c2 train bf16 dropout={dropout}: worst gradient rel-to-max", worst[1], C2_BF16_GRAD, worst[0])
+    record_measured(f"c2 train bf16 dropout={dropout}: worst 1-cosine", 1 - worst_cos[1], 1 - C2_BF16_COS, worst_cos[0])
+    record_measured(f"c2 train bf16 dropout={dropout}: worst rel-L2", worst_l2[1], C2_BF16_RELL2, worst_l2[0])
+    record_measured(f"c2 train bf16 dropout={dropout}: loss rel", abs(loss_hip - r["loss"]) / abs(r["loss"]), C2_BF16_LOSS_REL)
     assert not bad, (len(bad), bad[:30])
 
     # ---- post-step parameters.  At step 1 AdamW moves every parameter by ~lr * sign(g): where the oracle's |g| is
@@ -251,6 +256,8 @@ def test_c2_bf16_logits_vs_oracle_b6():
         logits, z2, _, _ = m(x.to(DEV), None, t=0.5, indices=idx.to(DEV))
     err = (logits.cpu() - ref).abs().max().item()
     print(f"[c2 bf16 B=6] max |dlogits| {err:.3e} (|logits| max {ref.abs().max().item():.2f})")
+    from tests.helpers import record_measured
+    record_measured("c2 bf16 B=6 logits: max |d| / max |logits|", err / ref.abs().max().item(), BF16_LOGITS_REL)
     assert torch.equal(z2.cpu(), z_t) and err < BF16_LOGITS_REL * ref.abs().max().item(), err
 
 
@@ -285,6 +292,8 @@ def test_c4_revise_forward_vs_oracle(ucf):
         err = (got.cpu() - ref).abs().max().item()
         agree = (got.cpu().argmax(-1) == ref.argmax(-1)).float().mean().item()
         print(f"[c4 {dtype} NC=7936 NT=256] max |dlogits| {err:.3e}, arg-max agreement {agree:.4f}")
+        from tests.helpers import record_measured
+        record_measured(f"c4 revise forward {dtype} (7936, 256): max |dlogits|", err, tol, f"arg-max agreement {agree:.4f}")
         assert err < tol, (dtype, err)
         assert agree > (0.999 if dtype == "f32" else 0.95)       # bf16 measured 0.984
         del m
@@ -374,6 +383,97 @@ def test_c4_draft_and_revise_block8192_bit_exact(ucf):
     assert 0 < n_tie <= 3, n_tie        # got != ref must be explained by at least one flipped tie, and ties are rare
 
 
+def _grad_report(g_hip, grads_ref, grad_gate, cos_gate, rell2_gate):
+    """every gradient tensor against the oracle's: max error relative to the tensor's max, cosine, relative L2"""
+    worst, worst_cos, worst_l2, bad = ("", 0.0), ("", 1.0), ("", 0.0), []
+    for k, ref in grads_ref.items():
+        denom = grads_ref[k.replace("attn.key.bias", "attn.query.bias")].abs().max().item() + 1e-12
+        err = (g_hip[k] - ref).abs().max().item() / denom
+        worst = max(worst, (k, err), key=lambda v: v[1])
+        if not err < grad_gate:
+            bad.append((k, round(err, 5)))
+        if "attn.key.bias" in k:
+            continue                                  # a mathematically zero gradient has no direction
+        a, b = g_hip[k].double().reshape(-1), ref.double().reshape(-1)
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
+        rl2 = float((a - b).norm() / (b.norm() + 1e-300))
+        worst_cos = min(worst_cos, (k, cos), key=lambda v: v[1])
+        worst_l2 = max(worst_l2, (k, rl2), key=lambda v: v[1])
+        if not (cos >= cos_gate and rl2 <= rell2_gate):
+            bad.append((k, "cos", round(cos, 7), "rel-L2", round(rl2, 6)))
+    return worst, worst_cos, worst_l2, bad
+
+
+@pytest.mark.parametrize("dtype,window", [("f32", None), ("bf16", None), ("f32", (16, 9)), ("bf16", (16, 9))])
+def test_c4_train_step_vs_oracle(ucf, dtype, window):
+    """TRAINING at the 128-frame geometry (VERDICT r03 missing #3 / weak #8: the HIP backward had never run with 4096+ keys or a
+    weight-gradient reduction over 8192+ tokens).  UCF-128f preset (configs/ucf/mebt_128f.yaml:4-57: block 8192, grid [32,16,16],
+    budget 8192, t_prior gaussian100000_2), B = 2, one whole `TrainLoop.step` against `oracle.train_step`: loss, every gradient,
+    post-step parameters.  window = None: the full sequence (T = 32 drawn: NC = NT = 4096 at t = 0.5, i.e. latent_enc over 4096 keys,
+    lt2l over 4352 keys, latent_dec with 4096 queries, head over 8192 rows); window = (16, 9): the mask sampler's two numpy draws
+    (mask_sampler.py:88,90) forced to T = 16 latent frames starting at frame 9, so seq_len = 4096 < N = 8192 and the loss divisor
+    and the positional rows follow the window (transformer.py:243-259, mask_sampler.py:83-99).  fp32 engine: north-star 1e-3;
+    bf16 engine: the C2 bounds."""
+    cfg, sd = ucf
+    assert cfg.model.params.t_prior == "gaussian100000_2" and cfg.model.mask.params.budget == 8192
+    lr = cfg.exp.exact_lr
+    ocfg = oracle_cfg_of(cfg)
+    B, t = 2, 0.5
+    x, idx = batch(B, [32, 16, 16], 91)
+    m = presets.build_model(cfg, compute_dtype=dtype)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    loop = TrainLoop(m, fused_optimizer=False)
+    rec = {}
+    real_choice, real_randint = np.random.choice, np.random.randint
+    T_, start_ = window if window is not None else (32, 0)
+
+    def fake_choice(a, p=None, **kw):
+        rec["a"], rec["p"] = np.asarray(a).copy(), np.asarray(p).copy()
+        return T_
+
+    def fake_randint(lo, hi=None, **kw):
+        rec["randint"] = (lo, hi)
+        return start_
+    np.random.choice, np.random.randint = fake_choice, fake_randint
+    try:
+        stats = loop.step(x.to(DEV), idx.to(DEV), t=t).cpu()
+    finally:
+        np.random.choice, np.random.randint = real_choice, real_randint
+    assert list(rec["a"]) == list(range(1, 33)) and abs(rec["p"].sum() - 1) < 1e-9      # the prior over 1..32 latent frames
+    if window is not None:
+        assert tuple(rec["randint"]) == (0, 32 - T_ + 1)
+    seq_len = T_ * 256
+    nm = loop.native
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    g_hip = {k: v.detach().cpu().clone() for k, v in nm.views(shapes, grads=True).items()}
+    p_hip = {k: v.detach().cpu().clone() for k, v in nm.views(shapes).items()}
+    assert m.weight_decay == cfg.exp.weight_decay == 1e-4
+    st = orc.TrainState(sd, lr=lr, weight_decay=cfg.exp.weight_decay)
+    r = orc.train_step(st, ocfg, x, idx, t, window=(T_, start_) if window is not None else None)
+    assert r["n_targets"] == int(stats[3]) == B * seq_len // 2
+    loss_hip = float(stats[4])
+    f32 = dtype == "f32"
+    assert abs(loss_hip - r["loss"]) < (2e-5 if f32 else C2_BF16_LOSS_REL) * abs(r["loss"]), (loss_hip, r["loss"])
+    worst, worst_cos, worst_l2, bad = _grad_report(g_hip, r["grads"], C2_F32_GRAD if f32 else C2_BF16_GRAD, (1 - 1e-6) if f32 else C2_BF16_COS,
+                                                   1e-3 if f32 else C2_BF16_RELL2)
+    tag = f"c4 train {dtype} window={window}"
+    print(f"[{tag}] seq_len {seq_len}: loss hip {loss_hip:.6f} oracle {r['loss']:.6f}; worst gradient {worst[0]} rel-to-max {worst[1]:.3e}; "
+          f"worst cosine {worst_cos[0]} {worst_cos[1]:.8f}; worst rel-L2 {worst_l2[0]} {worst_l2[1]:.3e}")
+    from tests.helpers import record_measured
+    record_measured(f"{tag}: worst gradient rel-to-max", worst[1], C2_F32_GRAD if f32 else C2_BF16_GRAD, worst[0])
+    record_measured(f"{tag}: worst 1-cosine", 1 - worst_cos[1], 1e-6 if f32 else 1 - C2_BF16_COS, worst_cos[0])
+    record_measured(f"{tag}: worst rel-L2", worst_l2[1], 1e-3 if f32 else C2_BF16_RELL2, worst_l2[0])
+    assert not bad, (len(bad), bad[:20])
+    for k, ref in st.P.items():       # step 1 of AdamW moves a parameter by ~lr sign(g): tight where |g| is well above rounding
+        d = (p_hip[k] - ref.detach()).abs()
+        assert d.max().item() <= 2.2 * lr + 1e-7, (k, d.max().item())
+        g = r["grads"][k]
+        sure = g.abs() > (0.05 if f32 else 0.25) * r["grads"][k.replace("attn.key.bias", "attn.query.bias")].abs().max()
+        if sure.any():
+            assert d[sure].max().item() < (0.02 if f32 else 0.12) * lr, (k, d[sure].max().item())
+
+
 @pytest.mark.parametrize("B,t", [(6, 0.0), (6, 0.03), (6, 0.97), (5, 0.337), (3, 0.62), (1, 0.81), (7, 0.25)])
 def test_c2_ragged_shapes_bf16_engine_vs_fp32_engine(B, t):
     """The benchmarked shapes are the friendliest ones (B = 6, NC = NT = 512: every GEMM dimension a multiple of every tile).
@@ -417,7 +517,7 @@ def test_c2_ragged_shapes_bf16_engine_vs_fp32_engine(B, t):
     assert not bad, (len(bad), bad[:20])
 
 
-def _replay_steps_prove_ties(m, steps, stream, temperature, max_ties=3):
+def _replay_steps_prove_ties(m, steps, stream, temperature, max_ties=3, top_k=None):
     """`got != ref` after a sampling loop: replay every recorded step of the ORACLE on the HIP path from the oracle's own state —
     logits within 1e-3, and sampled ids different only where the oracle's two best keys p / q are within 5e-4 (an fp tie that
     1e-5 logit differences may flip, after which the two runs legitimately diverge)."""
@@ -427,15 +527,106 @@ def _replay_steps_prove_ties(m, steps, stream, temperature, max_ties=3):
         lg, _ = m.reconstruct_mask(s["partial"].to(DEV), s["c"].to(DEV), s["t"].to(DEV))
         assert (lg.cpu() - s["logits"]).abs().max().item() < 1e-3
         nz = stream(s["noise_k"], "exp", tuple(s["logits"].shape))
-        ids, _, _ = sample_from_logits_scored(lg, temperature, None, None, nz.to(DEV))
-        oid, _ = orc.sample_from_logits(s["logits"], temperature, None, None, nz)
+        T_, k_ = (1.0, None) if s.get("boot") else (temperature, top_k)       # the bootstrap phase samples at T = 1 without top-k (:41-42)
+        ids, _, _ = sample_from_logits_scored(lg, T_, k_, None, nz.to(DEV))
+        oid, oprobs = orc.sample_from_logits(s["logits"], T_, k_, None, nz)
         for b, j in (ids.cpu() != oid).nonzero().tolist():
-            p = torch.softmax((s["logits"][b, j] / (temperature + 1e-8)).double(), -1)
-            top2 = (p / nz[b, j].double()).topk(2).values
+            top2 = (oprobs[b, j].double() / nz[b, j].double()).topk(2).values     # the oracle's own keys p / q after temperature / top-k
             assert top2[0] / top2[1] < 1 + 5e-4, ("not a tie", b, j, float(top2[0] / top2[1]))
             n_tie += 1
     assert 0 < n_tie <= max_ties, n_tie        # a difference must be explained by at least one flipped tie, and ties are rare
     return n_tie
+
+
+def test_c4_bidirect_sample_bootstrap_topk_block8192(ucf):
+    """The shipped UCF-128f sampling flow at its real geometry (VERDICT r03 missing #4 / weak #9; reference
+    scripts/valid_dnr_config_ckpt_exp_ucf_128f.sh:10-15 -> sample_vqgan_transformer_videos.py:22-94): `bidirect_sample` of one
+    128-frame clip (block 8192) with `--bootstrap B --top_k 32`, then `vid_n_steps` MaskGIT steps at context temperature 2.0,
+    cosine mask schedule, fp32 engine, against `oracle.bidirect_sample` driven by the same noise: code map identical, or every
+    difference a proven fp tie of the oracle (step-by-step replay from the oracle's state), score within 1e-4.  The shipped
+    schedule (bootstrap 64 + 32 steps = 96 forwards of ~1.7 TFLOP on the host for the oracle) runs with MEBT_LONG_TESTS=1
+    (result committed under profiles/); the default run uses bootstrap 8 + 8 steps: the same kernels and shapes (NT from
+    8192 down, the [1, 8192, 16384] probability maps, top-k thresholds over 8192 rows)."""
+    from mebt_amd.sampling import bidirect_sample
+    cfg, sd = ucf
+    ocfg = oracle_cfg_of(cfg)
+    long_run = os.environ.get("MEBT_LONG_TESTS") == "1"
+    boot, n_steps = (64, 32) if long_run else (8, 8)
+    base = torch.empty(8192, 2048).exponential_(generator=torch.Generator().manual_seed(77001))
+
+    def stream(k, kind, shape):
+        g = torch.Generator().manual_seed(616100 + k)
+        if kind == "perm":
+            return torch.randperm(int(shape[0]), generator=g)
+        if kind == "randn":
+            return torch.randn(tuple(shape), generator=g)
+        if len(shape) == 3 and shape[-1] == 16384:       # [1, NT, V] Exp(1): rolled copies of one table instead of 134 M fresh draws per step
+            nt = shape[1]
+            rows = base.roll(shifts=37 * k, dims=0)[:nt]
+            return torch.cat([rows.roll(shifts=k * 131 + 17 * i, dims=1) for i in range(8)], dim=1).reshape(shape)
+        return torch.empty(tuple(shape), dtype=torch.float32).exponential_(generator=g)
+
+    m = presets.build_model(cfg, compute_dtype="f32")
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.mask_sampler.schedule = "cosine"                       # sample_vqgan_transformer_videos.py:189,219
+    ctr = {"k": 0}
+
+    def hook(kind, shape):
+        k = ctr["k"]
+        ctr["k"] += 1
+        return stream(k, kind, shape)
+
+    m.noise_hook = hook
+    m.mask_sampler.noise_hook = hook
+    import time
+    t0 = time.time()
+    log = bidirect_sample(m, 1, 128, 128, 128, temperature=1.0, top_k=32, top_p=None, vid_n_steps=n_steps, vid_c_temp=2.0,
+                          ctemp_schedule="linear", strategy="maskgit", bootstrap=boot)
+    torch.cuda.synchronize()
+    t_hip = time.time() - t0
+    got = log["code_maps"].cpu()
+    assert tuple(got.shape) == (1, 32, 16, 16)
+    octr = {"k": 0}
+    steps = []
+
+    def noise_fn(tag, shape):
+        k = octr["k"]
+        octr["k"] += 1
+        if tag == "sample":
+            steps[-1]["noise_k"] = k
+        if tag == "randn":
+            steps[-1]["boot"] = True
+        return stream(k, "randn" if tag == "randn" else "exp", tuple(shape))
+
+    def logits_fn(partial, c_, t_):
+        with torch.no_grad():
+            lg = orc.reconstruct_mask(sd, ocfg, partial, c_, t_)
+        steps.append({"partial": partial.clone(), "c": c_.clone(), "t": t_.clone(), "logits": lg})
+        return lg
+
+    import copy
+    ocos = copy.copy(ocfg)
+    ocos.schedule = "cosine"
+    t0 = time.time()
+    with torch.no_grad():
+        ref, score = orc.bidirect_sample(sd, ocos, 1, 128, 128, 128, 1.0, 32, None, n_steps, 2.0, noise_fn, ctemp_schedule="linear",
+                                         strategy="maskgit", bootstrap=boot, logits_fn=logits_fn)
+    t_orc = time.time() - t0
+    assert octr["k"] == ctr["k"], (octr["k"], ctr["k"])          # both sides consumed the same draws in the same order
+    assert sum(1 for s_ in steps if s_.get("boot")) == boot and len(steps) >= boot + n_steps - 1
+    assert steps[0]["c"].shape[1] == 0 and steps[0]["t"].shape[1] == 8192 and steps[boot]["c"].shape[1] == boot
+    same = bool(torch.equal(got, ref))
+    n_tie = 0
+    if same:
+        np.testing.assert_allclose(log["score"].cpu().numpy(), score.numpy(), rtol=1e-4)
+    else:
+        n_tie = _replay_steps_prove_ties(m, steps, stream, 1.0, max_ties=64, top_k=32)
+    msg = (f"[c4 bidirect_sample block 8192 bootstrap {boot} top_k 32 steps {n_steps}] {len(steps)} forwards; code map == oracle: {same} "
+           f"(proven fp ties in the replay: {n_tie}); HIP {t_hip:.1f} s, oracle {t_orc:.1f} s")
+    print(msg)
+    from tests.helpers import record_measured
+    record_measured(msg, n_tie, 64)
 
 
 def test_c5_pipeline_vs_the_two_oracles():

@@ -458,6 +458,41 @@ def test_load_reference_checkpoint_with_omegaconf_hparams(tmp_path, flavour):
     torch.save({"state_dict": {}, "hyper_parameters": {"x": Evil()}}, bad)
     with pytest.raises(pickle.UnpicklingError):
         mebt.load_transformer(bad)
+    # pickle protocol 4 resolves DOTTED names inside an allow-listed module — ('torch', 'os.system') must not
+    # reach os.system through torch's own `import os`; neither may a module of this package lend its imports
+    from mebt_amd.lightning_shim import TolerantUnpickler
+    import io
+
+    def stack_global(module, name, arg):        # PROTO 4 | module | name | STACK_GLOBAL | arg | TUPLE1 | REDUCE | STOP
+        def u(sv):
+            b = sv.encode()
+            return b"\x8c" + bytes([len(b)]) + b
+        return b"\x80\x04" + u(module) + u(name) + b"\x93" + u(arg) + b"\x85R."
+    marker = tmp_path / "pwned"
+    for module, name in (("torch", "os.system"), ("torch", "serialization.os.system"), ("mebt_amd.launch", "subprocess.getoutput"),
+                         ("numpy", "os.system"), ("functools", "partial"), ("builtins", "eval"), ("builtins", "getattr"),
+                         ("torch.storage", "_load_from_bytes"), ("os", "system"), ("pathlib", "os.system")):
+        with pytest.raises(pickle.UnpicklingError):
+            TolerantUnpickler(io.BytesIO(stack_global(module, name, f"touch {marker}"))).load()
+    assert not marker.exists()
+
+
+def test_train_launcher_gpus_argument_follows_lightning():
+    """`--gpus` as Lightning reads it (reference scripts/train_config_log_gpus.sh passes `--gpus 0,1,2,3,`): N, -1, lists, a single
+    id with a trailing comma, and composition with an already exported HIP_VISIBLE_DEVICES."""
+    from mebt_amd.train import parse_gpus
+    assert parse_gpus(None, visible="") == (1, None)
+    assert parse_gpus("8", visible="") == (8, None)
+    assert parse_gpus("1", visible="") == (1, None) and parse_gpus("0", visible="") == (1, None)
+    assert parse_gpus("-1", visible="", device_count=8) == (8, None)
+    assert parse_gpus("-1", visible="4,5") == (2, None)
+    assert parse_gpus("0,1,2,3,", visible="") == (4, ["0", "1", "2", "3"])
+    assert parse_gpus("3,", visible="") == (1, ["3"])                      # Lightning: device 3, not "3 devices"
+    assert parse_gpus("1,0", visible="4,6,7") == (2, ["6", "4"])            # indices into the visible set
+    with pytest.raises(ValueError):
+        parse_gpus("0,3", visible="4,6,7")
+    with pytest.raises(ValueError):
+        parse_gpus("4", visible="4,6,7")
 
 
 def test_bench_parent_starts_ranks_as_a_child_and_never_touches_the_gpu(tmp_path):
