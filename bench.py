@@ -233,77 +233,98 @@ def secondary_metrics(args, cfg, model, loop, x, idx, device, lib, level):
 
 
 def secondary_c4(args, device, lib):
-    """BASELINE.json configs[3]: UCF-101 128f geometry (block 8192) — the shipped inference schedules and one train step."""
+    """BASELINE.json configs[3]: UCF-101 128f geometry (block 8192), batch 4 as the shipped script runs it
+    (scripts/valid_dnr_config_ckpt_exp_ucf_128f.sh:12,34) — the inference schedules and one train step.  `--c4-legs` selects."""
     from mebt_amd import presets, _lib
     from mebt_amd.trainer import TrainLoop
+    from mebt_amd.sampling import bidirect_sample
     sync = torch.cuda.synchronize
     forward_flops_per_sample = presets.forward_flops_per_sample
+    legs = set(args.c4_legs.split(","))
     out = {}
-    # (7) C4: UCF-101 128f geometry (block 8192), the revise schedule of the shipped script: M = 2 x 32 revise forwards at
-    # (NC, NT) = (7936, 256), batch 4
     ucfg = presets.ucf_128f()
+    uo = ucfg.model.params
     torch.manual_seed(1)
     um = presets.build_model(ucfg, compute_dtype=args.dtype).to(device).eval()
-    xu = torch.randint(0, 16384, (4, 32, 16, 16), device=device)
-    uo = ucfg.model.params
-    with torch.no_grad():
-        f = lambda: um.draft_and_revise(xu, None, 8, 1.0, None, None, 32, 1.0, None, None, 2, True)
-        f()
-        dt = timed(f, 1, sync)
-    fl = 64 * 4 * forward_flops_per_sample(uo, 7936, 256)
-    out["c4_revise_64_forwards"] = {"batch": 4, "s": round(dt, 3), "forwards_per_s": round(64 / dt, 1), "tflops": round(fl / dt / 1e12, 1),
-                                    "note": "64 forwards at (NC, NT) = (7936, 256) + sampling + scatter, block 8192"}
-    # the 30-step MaskGIT-style sample at the same geometry (SURVEY.md §8d: the other C4 inference schedule), cosine mask
-    # schedule as the sampling script sets it: NT shrinks from 8192 to 0 over the steps
-    um.mask_sampler.schedule = "cosine"
-    x0u = torch.zeros(4, 32, 16, 16, dtype=torch.long, device=device)
-    with torch.no_grad():
-        f = lambda: um.sample(x0u, None, 1.0, None, None, 30, None, None, context_temperature=4.5, skips=False)
-        f()
-        dt = timed(f, 1, sync)
-    out["c4_sample_30_steps"] = {"batch": 4, "s": round(dt, 3), "sampler_steps_per_s": round(30 / dt, 1), "tokens_per_s": round(4 * 8192 / dt, 1)}
-    # the shipped UCF-128f draft producer (scripts/valid_dnr_config_ckpt_exp_ucf_128f.sh:10-15 -> sample_vqgan_transformer_videos.py:22-94):
-    # bidirect_sample with --bootstrap 64 --top_k 32, then 32 MaskGIT steps; FLOP model of SURVEY.md §8d (107.8 + 36.5 TFLOP/sample)
-    from mebt_amd.sampling import bidirect_sample
-    with torch.no_grad():
-        f = lambda: bidirect_sample(um, 4, 128, 128, 128, temperature=1.0, top_k=32, top_p=None, vid_n_steps=32, vid_c_temp=2.0, bootstrap=64)
-        f()
-        dt = timed(f, 1, sync)
-    fl = 4 * (107.8e12 + 36.5e12)
-    out["c4_bootstrap64_topk32"] = {"batch": 4, "s": round(dt, 3), "forwards": 96, "tflops": round(fl / dt / 1e12, 1),
-                                    "frac_of_bf16_mfma_peak": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "videos_per_s": round(4 / dt, 3),
-                                    "note": "bidirect_sample(bootstrap=64, top_k=32, vid_n_steps=32, vid_c_temp=2.0) at block 8192 incl. the [4, 8192, 16384] "
-                                            "probability maps of debug=True; FLOPs = SURVEY.md §8d's 107.8 + 36.5 TFLOP per sample"}
+
+    def gemm_share(fn):
+        """GEMM-family launches of one more call bracketed by HIP events: their FLOPs and summed duration"""
+        lib.mebt_profile_enable(1)
+        fn()
+        sync()
+        n, tms, fl = C.c_double(), C.c_double(), C.c_double()
+        _lib.check(lib.mebt_profile_read(0, C.byref(n), C.byref(tms), C.byref(fl)))
+        lib.mebt_profile_enable(0)
+        return {"gemm_launches": n.value, "gemm_tflop": round(fl.value / 1e12, 2), "gemm_ms_by_events": round(tms.value, 2),
+                "gemm_family_tflops": round(fl.value / max(tms.value, 1e-9) / 1e9, 1)}
+
+    if "revise" in legs:
+        # the revise schedule of the shipped script: M = 2 x 32 revise forwards at (NC, NT) = (7936, 256)
+        xu = torch.randint(0, 16384, (4, 32, 16, 16), device=device)
+        with torch.no_grad():
+            f = lambda: um.draft_and_revise(xu, None, 8, 1.0, None, None, 32, 1.0, None, None, 2, True)
+            f()
+            dt = timed(f, 1, sync)
+            fl = 64 * 4 * forward_flops_per_sample(uo, 7936, 256)
+            out["c4_revise_64_forwards"] = {"batch": 4, "s": round(dt, 3), "forwards_per_s": round(64 / dt, 1), "tflops": round(fl / dt / 1e12, 1),
+                                            "frac_of_bf16_mfma_peak": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                            "note": "64 forwards at (NC, NT) = (7936, 256) + sampling + scatter, block 8192", **gemm_share(f)}
+    if "sample" in legs:
+        # the 30-step MaskGIT-style sample at the same geometry (SURVEY.md §8d: the other C4 inference schedule), cosine mask
+        # schedule as the sampling script sets it: NT shrinks from 8192 to 0 over the steps
+        um.mask_sampler.schedule = "cosine"
+        x0u = torch.zeros(4, 32, 16, 16, dtype=torch.long, device=device)
+        with torch.no_grad():
+            f = lambda: um.sample(x0u, None, 1.0, None, None, 30, None, None, context_temperature=4.5, skips=False)
+            f()
+            dt = timed(f, 1, sync)
+        fl = 4 * 36.5e12
+        out["c4_sample_30_steps"] = {"batch": 4, "s": round(dt, 3), "sampler_steps_per_s": round(30 / dt, 1), "tokens_per_s": round(4 * 8192 / dt, 1),
+                                     "tflops": round(fl / dt / 1e12, 1), "note": "FLOPs = SURVEY.md §8d's 36.5 TFLOP per sample"}
+    if "bootstrap" in legs:
+        # the shipped UCF-128f draft producer (scripts/valid_dnr_config_ckpt_exp_ucf_128f.sh:10-15 -> sample_vqgan_transformer_videos.py:22-94):
+        # bidirect_sample with --bootstrap 64 --top_k 32, then 32 MaskGIT steps; FLOP model of SURVEY.md §8d (107.8 + 36.5 TFLOP/sample)
+        um.mask_sampler.schedule = "cosine"
+        with torch.no_grad():
+            f = lambda: bidirect_sample(um, 4, 128, 128, 128, temperature=1.0, top_k=32, top_p=None, vid_n_steps=32, vid_c_temp=2.0, bootstrap=64)
+            f()
+            dt = timed(f, 1, sync)
+            fl = 4 * (107.8e12 + 36.5e12)
+            out["c4_bootstrap64_topk32"] = {"batch": 4, "s": round(dt, 3), "forwards": 96, "tflops": round(fl / dt / 1e12, 1),
+                                            "frac_of_bf16_mfma_peak": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "videos_per_s": round(4 / dt, 3),
+                                            "note": "bidirect_sample(bootstrap=64, top_k=32, vid_n_steps=32, vid_c_temp=2.0) at block 8192 incl. the [4, 8192, 16384] "
+                                                    "probability maps of debug=True; FLOPs = SURVEY.md §8d's 107.8 + 36.5 TFLOP per sample", **gemm_share(f)}
     um.mask_sampler.schedule = ucfg.model.mask.params.schedule
     del um
     torch.cuda.empty_cache()
-    # TRAINING at block 8192 (configs/ucf/mebt_128f.yaml:4-57): B = 4, t = 0.5 on the full sequence -> NC = NT = 4096
-    torch.manual_seed(1)
-    tm = presets.build_model(ucfg, compute_dtype=args.dtype).to(device).train()
-    tm.t_prior = lambda lengths, step: __import__("numpy").eye(len(lengths))[-1]      # always the full 32 latent frames (the curriculum's end state)
-    tl = TrainLoop(tm)
-    xt, it = synthetic_batch(4, [32, 16, 16], 0, device)
-    for _ in range(3):
-        tl.step(xt, it, t=0.5)
-    dt = timed(lambda: tl.step(xt, it, t=0.5), 5, sync)
-    fl = 3 * 4 * forward_flops_per_sample(uo, 4096, 4096)
-    out["c4_train_step"] = {"batch": 4, "NC": 4096, "NT": 4096, "ms_per_step": round(dt * 1e3, 3), "masked_tokens_per_s": round(4 * 4096 / dt, 1),
-                            "tflops": round(fl / dt / 1e12, 1), "frac_of_bf16_mfma_peak": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
-                            "optimizer": "in-backward" if tl.fused_optimizer else "separate"}
-    del tm, tl
-    torch.cuda.empty_cache()
-
+    if "train" in legs:
+        # TRAINING at block 8192 (configs/ucf/mebt_128f.yaml:4-57): B = 4, t = 0.5 on the full sequence -> NC = NT = 4096
+        torch.manual_seed(1)
+        tm = presets.build_model(ucfg, compute_dtype=args.dtype).to(device).train()
+        tm.t_prior = lambda lengths, step: __import__("numpy").eye(len(lengths))[-1]      # always the full 32 latent frames (the curriculum's end state)
+        tl = TrainLoop(tm)
+        xt, it = synthetic_batch(4, [32, 16, 16], 0, device)
+        for _ in range(3):
+            tl.step(xt, it, t=0.5)
+        dt = timed(lambda: tl.step(xt, it, t=0.5), 5, sync)
+        fl = 3 * 4 * forward_flops_per_sample(uo, 4096, 4096)
+        out["c4_train_step"] = {"batch": 4, "NC": 4096, "NT": 4096, "ms_per_step": round(dt * 1e3, 3), "masked_tokens_per_s": round(4 * 4096 / dt, 1),
+                                "tflops": round(fl / dt / 1e12, 1), "frac_of_bf16_mfma_peak": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                "optimizer": "in-backward" if tl.fused_optimizer else "separate"}
+        del tm, tl
+        torch.cuda.empty_cache()
     return out
 
 
 def secondary_c5(args, device, lib):
-    """BASELINE.json configs[4]: Taichi 16f end to end."""
+    """BASELINE.json configs[4]: Taichi 16f end to end, at the batch the shipped script runs (`--batch_size 16`,
+    scripts/valid_dnr_config_ckpt_exp_taichi_16f.sh:12,34; rounds 1-3 timed batch 4: `--c5-batch 4` reproduces that figure)."""
     from mebt_amd import presets, _lib
     sync = torch.cuda.synchronize
     out = {}
     # (8) C5 (BASELINE.json configs[4]): Taichi 16f end to end — pixels -> 3D-VQGAN encode (fp16 MFMA, fp32 codebook search) ->
-    # MeBT sampling as the shipped script runs it (64-step MaskGIT draft, then M = 8 x 2 revise forwards at T = 0.3) ->
-    # 3D-VQGAN decode, batch 4, random-init weights
+    # MeBT sampling as the shipped script runs it (64-step MaskGIT draft through bidirect_sample incl. its debug=True probability map,
+    # then M = 8 x 2 revise forwards at T = 0.3) -> 3D-VQGAN decode, batch 16, random-init weights
     from mebt_amd.vqgan import VQGAN
     tcfg = presets.taichi_16f(vtokens=False)
     torch.manual_seed(2)
@@ -312,20 +333,24 @@ def secondary_c5(args, device, lib):
     tm.first_stage_model.compute_dtype = "f16"
     tm = tm.to(device).eval()
     tm.mask_sampler.schedule = "cosine"
-    vid = torch.rand(4, 3, 16, 128, 128, device=device) - 0.5
+    from mebt_amd.sampling import bidirect_sample
+    Bv = args.c5_batch
+    vid = torch.rand(Bv, 3, 16, 128, 128, device=device) - 0.5
     with torch.no_grad():
         stages = {}
         enc = lambda: tm.encode_to_z(vid)[1]
         toks = enc()
         stages["vqgan_encode_ms"] = round(timed(enc, 3, sync) * 1e3, 3)
-        x0 = torch.zeros(4, 4, 16, 16, dtype=torch.long, device=device)
-        draft = lambda: tm.sample(x0, None, 1.0, None, None, 64, None, None, context_temperature=2.0, skips=False)[0]
+        fs, tm.first_stage_model = tm.first_stage_model, None       # the draft's decode is timed as its own stage below
+        draft = lambda: bidirect_sample(tm, Bv, 16, 16, 16, temperature=1.0, top_k=None, top_p=None, vid_n_steps=64, vid_c_temp=2.0,
+                                        ctemp_schedule="linear", strategy="maskgit")["code_maps"]       # sample_vqgan_transformer_videos.py:22-94
         code = draft()
         stages["sample_64_steps_ms"] = round(timed(draft, 1, sync) * 1e3, 3)
-        rev = lambda: tm.draft_and_revise(code.view(4, 4, 16, 16), None, 8, 0.0, None, None, 2, 0.3, None, None, 8, True)
+        rev = lambda: tm.draft_and_revise(code.reshape(Bv, 4, 16, 16), None, 8, 0.0, None, None, 2, 0.3, None, None, 8, True)
         code2 = rev()
         stages["revise_8x2_ms"] = round(timed(rev, 1, sync) * 1e3, 3)
-        dec = lambda: tm.first_stage_model.decode(code2.view(4, 4, 16, 16))
+        tm.first_stage_model = fs
+        dec = lambda: tm.first_stage_model.decode(code2.view(Bv, 4, 16, 16))
         rec = dec()
         stages["vqgan_decode_ms"] = round(timed(dec, 3, sync) * 1e3, 3)
         # per-stage roofline (MFMA-bound stages): the sampler stages once more with the GEMM family bracketed by HIP events —
@@ -343,15 +368,15 @@ def secondary_c5(args, device, lib):
             stage_roof[name] = {"bound": "mfma", "achieved": round(fl.value / wall / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(fl.value / wall / 1e12 / PEAK_BF16_TFLOPS, 4), "gemm_launches": n.value,
                                 "gemm_gflop": round(fl.value / 1e9, 1), "gemm_ms_by_events": round(tms.value, 2)}
-        for name, gflop in (("vqgan_encode", 4 * 2 * 23.83), ("vqgan_decode", 4 * 2 * 347.17)):
+        for name, gflop in (("vqgan_encode", Bv * 2 * 23.83), ("vqgan_decode", Bv * 2 * 347.17)):
             tf = gflop / stages[name + "_ms"]                     # GFLOP / ms = TFLOP/s
             stage_roof[name] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(tf / PEAK_BF16_TFLOPS, 4), "conv_gflop": round(gflop, 1)}
-    assert tuple(rec.shape) == (4, 3, 16, 128, 128) and tuple(toks.shape) == (4, 1024)
+    assert tuple(rec.shape) == (Bv, 3, 16, 128, 128) and tuple(toks.shape) == (Bv, 1024)
     total = sum(stages.values())
-    stages.update({"batch": 4, "total_ms": round(total, 2), "videos_per_s": round(4 / (total * 1e-3), 2),
-                   "vqgan_encode_tflops": round(4 * 2 * 23.83e9 / (stages["vqgan_encode_ms"] * 1e-3) / 1e12, 1),
-                   "vqgan_decode_tflops": round(4 * 2 * 347.17e9 / (stages["vqgan_decode_ms"] * 1e-3) / 1e12, 1),
+    stages.update({"batch": Bv, "total_ms": round(total, 2), "videos_per_s": round(Bv / (total * 1e-3), 2),
+                   "vqgan_encode_tflops": round(Bv * 2 * 23.83e9 / (stages["vqgan_encode_ms"] * 1e-3) / 1e12, 1),
+                   "vqgan_decode_tflops": round(Bv * 2 * 347.17e9 / (stages["vqgan_decode_ms"] * 1e-3) / 1e12, 1),
                    "roofline_by_stage": stage_roof,
                    "note": "16 frames x 128 x 128 per video; VQGAN fp16 (conv3d implicit GEMM on v_mfma_f32_16x16x32_f16), transformer " + args.dtype})
     out["c5_taichi_end_to_end"] = stages
@@ -372,6 +397,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--secondary", default="full", choices=["none", "light", "full", "c4", "c5"])
     ap.add_argument("--preset", default="sky_16f", choices=["sky_16f", "tiny"])
+    ap.add_argument("--c5-batch", type=int, default=16, help="videos per batch of the config-5 leg (the shipped Taichi script: 16)")
+    ap.add_argument("--c4-legs", default="revise,sample,bootstrap,train", help="which config-4 legs run (profiling one at a time)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a torch.distributed environment: start the N ranks as a child process (before anything

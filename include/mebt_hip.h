@@ -214,6 +214,12 @@ int mebt_op_wgrad_grouped(int32_t n, const void* const* dY, const void* const* X
 int mebt_op_topk_threshold(const float* logits, int32_t top_k, float* kth, int64_t* ids_scratch, int32_t rows, int32_t V,
                            mebt_stream_t stream);
 /* x[b, ti[b,j]] = ids[b,j]  (the sparse_coo/to_dense/where scatter of transformer.py:413-439). */
+/* sample(debug=True) (transformer.py:395,426-436): the same draw for rows = B * NT target positions, each row's probabilities
+ * written straight to row ti[b, j] of the [B, N, V] probability map (the reference materialises [B, NT, V] and scatter_()s it).
+ * noise = NULL: Exp(1) drawn in the kernel from `seed`.  V = 16384, no top-p. */
+int mebt_op_sample_scatter(const float* logits, const float* noise, uint64_t seed, float temperature, int32_t top_k, int64_t* ids,
+                           float* score, float* probs_map, const int64_t* ti, int32_t B, int32_t N, int32_t NT, int32_t V,
+                           mebt_stream_t stream);
 int mebt_op_scatter_ids(int64_t* x, const int64_t* ti, const int64_t* ids, int32_t B, int32_t N, int32_t NT,
                         mebt_stream_t stream);
 /* MaskGen.generate_next_mask + gumbel_top_k (mask_sampler.py:178-246): order targets by

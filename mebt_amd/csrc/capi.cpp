@@ -147,6 +147,20 @@ extern "C" int mebt_op_sample_seeded(const float* logits, uint64_t seed, float t
     return launch_sample(p, S(stream));
 }
 
+// sample(debug=True) (transformer.py:395,426-436): the draw of rows = B * NT target positions, with each row's probabilities written
+// straight to its row ti[b, j] of the [B, N, V] probability map (the reference materialises [B, NT, V] and scatter_()s it).
+// noise = NULL: Exp(1) drawn in the kernel from `seed`.  V = 16384, no top-p.
+extern "C" int mebt_op_sample_scatter(const float* logits, const float* noise, uint64_t seed, float temperature, int32_t top_k, int64_t* ids,
+                                      float* score, float* probs_map, const int64_t* ti, int32_t B, int32_t N, int32_t NT, int32_t V,
+                                      mebt_stream_t stream) {
+    if (!logits || !ids || !probs_map || !ti) { mebt_set_error("sample_scatter: null pointer"); return MEBT_EINVAL; }
+    if (B <= 0 || NT <= 0 || N < NT) { mebt_set_error("sample_scatter: need B > 0 and 0 < NT <= N"); return MEBT_ESHAPE; }
+    SampleParams p;
+    p.logits = logits; p.noise = noise; p.noise_seed = seed; p.temperature = temperature; p.top_k = top_k; p.top_p = 0.f; p.ids = ids;
+    p.score = score; p.probs = probs_map; p.rows = B * NT; p.V = V; p.probs_ti = ti; p.probs_N = N; p.probs_NT = NT;
+    return launch_sample(p, S(stream));
+}
+
 // the k-th largest logit of every row (exact: temperature 1 leaves the values untouched): the threshold of `top_k_logits`
 extern "C" int mebt_op_topk_threshold(const float* logits, int32_t top_k, float* kth, int64_t* ids_scratch, int32_t rows, int32_t V, mebt_stream_t stream) {
     if (!logits || !kth || !ids_scratch) { mebt_set_error("topk_threshold: null pointer"); return MEBT_EINVAL; }

@@ -238,6 +238,10 @@ struct SampleParams {
     int rows, V;
     float* kth = nullptr;  // optional [rows]: the k-th largest value of logits / (temperature + 1e-8) of each row (top_k > 0), i.e. the
                            // threshold below which `top_k_logits` writes -inf (reference transformer.py:891-895)
+    // optional: rows = B * probs_NT and `probs` is the [B, probs_N, V] probability map of sample(debug=True) (transformer.py:395,
+    // 426-436): the probabilities of row (b, j) go to map row b * probs_N + probs_ti[b * probs_NT + j] (the reference's scatter_)
+    const int64_t* probs_ti = nullptr;
+    int probs_N = 0, probs_NT = 0;
 };
 int launch_sample(const SampleParams& p, hipStream_t stream);
 int launch_scatter_ids(int64_t* x, const int64_t* ti, const int64_t* ids, int B, int N, int NT, hipStream_t stream);

@@ -5,6 +5,7 @@
 // (the caller owns the RNG), which makes sampled ids bit-comparable with the oracle.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -187,6 +188,180 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same draw for V = 16384 without top-p (every shipped script), the row in REGISTERS: thread t owns elements t + 256 j
+// (j = 0 .. 63) — the ownership, accumulation order and expressions of sample_kernel above, so ids, scores and probabilities are
+// bit-identical to it — but one pass over the logits instead of six to ten passes over an LDS copy:
+//  * top-k threshold (the k-th largest value, ties kept, transformer.py:891-895) without a radix select over 16384 entries (its four
+//    LDS-histogram passes serialised on a handful of bins — logits share their exponent bits — and were most of the 1.9 ms this
+//    kernel averaged on [32768, 16384] inputs): the k-th largest of the 256 per-thread maxima is a lower bound L of the
+//    threshold (at least k elements are >= L); the elements >= L are collected in LDS (a few dozen on ordinary rows) and the
+//    exact k-th largest is picked among them by rank counting.  More than 1024 candidates (degenerate rows: many equal values)
+//    or k > 256: the block falls back to the radix select, reading registers.
+//  * exp / division / noise only where the filtered value is not -inf (wave-uniform skips: with top_k = 32 that is 32 of 16384).
+//  * the probability map of debug=True is written straight to its rows of the [B, N, V] map (16-byte stores through an LDS transpose).
+// ------------------------------------------------------------------------------------------------
+constexpr int FAST_E = 64;          // elements per thread
+constexpr int FAST_CAP = 1024;      // candidate list
+
+__global__ __launch_bounds__(256) void sample_fast_kernel(const SampleParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 64 KiB only when probabilities are written
+    __shared__ float sh[4];
+    __shared__ __attribute__((aligned(16))) float lmax[256];
+    __shared__ float cand[FAST_CAP];
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int sel_prefix, sel_k, ncand;
+    __shared__ float thr;
+    constexpr int V = SV_MAX;
+    const int tid = threadIdx.x, row = blockIdx.x;
+    const float* lg = p.logits + (size_t)row * V;
+    const float tdiv = p.temperature + 1e-8f;
+    float x[FAST_E];
+#pragma unroll
+    for (int j = 0; j < FAST_E; ++j) x[j] = lg[tid + 256 * j];
+    if (tdiv != 1.0f) {                                   // x / 1.0f == x: the division is skipped only where it is the identity
+#pragma unroll
+        for (int j = 0; j < FAST_E; ++j) x[j] = x[j] / tdiv;      // transformer.py:860
+    }
+    float lm = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < FAST_E; ++j) {
+        if (x[j] != x[j]) x[j] = -INFINITY;               // :866-868
+        lm = fmaxf(lm, x[j]);
+    }
+    if (p.top_k > 0 && p.top_k < V) {                     // :863-864, :891-895 — keep everything >= the k-th largest
+        bool radix = p.top_k > 256;
+        if (!radix) {
+            lmax[tid] = lm;
+            if (tid == 0) ncand = 0;
+            __syncthreads();
+            int greater = 0;                              // rank of this thread's maximum among the 256 (ties: lower thread first)
+            for (int s4 = 0; s4 < 64; ++s4) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(lmax + 4 * s4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) greater += (o[r] > lm || (o[r] == lm && 4 * s4 + r < tid)) ? 1 : 0;
+            }
+            if (greater == p.top_k - 1) thr = lm;         // exactly one thread: L
+            __syncthreads();
+            const float L = thr;
+#pragma unroll
+            for (int j = 0; j < FAST_E; ++j)
+                if (x[j] >= L) {
+                    const unsigned pos = atomicAdd(&ncand, 1u);
+                    if (pos < (unsigned)FAST_CAP) cand[pos] = x[j];
+                }
+            __syncthreads();
+            const int n = (int)ncand;
+            radix = n > FAST_CAP;                         // block-uniform
+            if (!radix) {
+                for (int i = tid; i < n; i += 256) {      // the k-th largest of the candidates: #greater < k <= #greater-or-equal
+                    const float c = cand[i];
+                    int gt = 0, ge = 0;
+                    for (int s = 0; s < n; ++s) { const float o = cand[s]; gt += o > c ? 1 : 0; ge += o >= c ? 1 : 0; }
+                    if (gt < p.top_k && p.top_k <= ge) thr = c;       // every thread that qualifies writes the same value
+                }
+                __syncthreads();
+            }
+        }
+        if (radix) {                                      // 4 x 8-bit radix select over the monotone keys, from registers
+            if (tid == 0) { sel_prefix = 0; sel_k = (unsigned)p.top_k; }
+            unsigned mask = 0;
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                hist[tid] = 0;
+                __syncthreads();
+                const unsigned pre = sel_prefix;
+#pragma unroll
+                for (int j = 0; j < FAST_E; ++j) {
+                    const uint32_t k = fkey(x[j]);
+                    if ((k & mask) == pre) atomicAdd(&hist[(k >> shift) & 255], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned need = sel_k, acc = 0;
+                    int b = 255;
+                    for (; b > 0; --b) { if (acc + hist[b] >= need) break; acc += hist[b]; }
+                    sel_prefix = pre | ((unsigned)b << shift);
+                    sel_k = need - acc;
+                }
+                mask |= 255u << shift;
+                __syncthreads();
+            }
+            if (tid == 0) { const uint32_t kth = sel_prefix; thr = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7FFFFFFFu) : ~kth); }
+            __syncthreads();
+        }
+        const float T = thr;
+        if (p.kth && tid == 0) p.kth[row] = T;
+        const uint32_t kT = fkey(T);
+#pragma unroll
+        for (int j = 0; j < FAST_E; ++j) if (fkey(x[j]) < kT) x[j] = -INFINITY;     // the comparison of sample_kernel (orders -0 below +0)
+    }
+    // softmax (:871): max, exp, sum, divide — the accumulation order of sample_kernel
+    const float mx = blk_max(lm, sh);                     // the filter never removes the row maximum
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < FAST_E; ++j) {
+        float e = 0.f;
+        if (__builtin_amdgcn_ballot_w64(x[j] > -INFINITY)) e = expf(x[j] - mx);    // expf(-inf - mx) = 0: skipped per wave where nothing survives
+        x[j] = e;
+        se += e;
+    }
+    se = blk_sum(se, sh);
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < FAST_E; ++j) {
+        if (__builtin_amdgcn_ballot_w64(x[j] != 0.f)) x[j] = x[j] / se;            // 0 / se = 0
+        tot += x[j];
+    }
+    if (p.probs) {                                        // rows of 64 KiB: transpose through LDS, 16-byte stores
+        float* sv = reinterpret_cast<float*>(smem);
+        size_t drow = (size_t)row;
+        if (p.probs_ti) {
+            const int b = row / p.probs_NT;
+            drow = (size_t)b * p.probs_N + (size_t)p.probs_ti[row];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < FAST_E; ++j) sv[tid + 256 * j] = x[j];
+        __syncthreads();
+        f32x4* dst = reinterpret_cast<f32x4*>(p.probs + drow * V);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[tid + 256 * i] = *reinterpret_cast<const f32x4*>(sv + 4 * (tid + 256 * i));
+    }
+    tot = blk_sum(tot, sh);
+    // gumbel_sort (:834-841): arg-max of (p / sum p) / q, zero-probability entries forced to 0
+    const float* nz = p.noise ? p.noise + (size_t)row * V : nullptr;
+    float best = -1.f, bp = 0.f;
+    int bi = V;
+#pragma unroll
+    for (int j = 0; j < FAST_E; ++j) {
+        const int e = tid + 256 * j;
+        const float pe = x[j];
+        float key = 0.f;
+        if (__builtin_amdgcn_ballot_w64(pe > 0.f)) {
+            if (pe > 0.f) {
+                const float q = nz ? nz[e] : exp1_counter(p.noise_seed, (uint64_t)row * V + e);
+                key = (pe / tot) / q;
+            }
+        }
+        if (key > best || (key == best && e < bi)) { best = key; bi = e; bp = pe; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64), op = __shfl_xor(bp, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; bp = op; }
+    }
+    __shared__ float wb[4], wp[4];
+    __shared__ int wi[4];
+    if ((tid & 63) == 0) { wb[tid >> 6] = best; wi[tid >> 6] = bi; wp[tid >> 6] = bp; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) if (wb[w] > best || (wb[w] == best && wi[w] < bi)) { best = wb[w]; bi = wi[w]; bp = wp[w]; }
+        p.ids[row] = bi;
+        if (p.score) p.score[row] = bp;
+    }
+}
+
 __global__ void scatter_ids_kernel(int64_t* x, const int64_t* ti, const int64_t* ids, int B, int N, int NT) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * NT) return;
@@ -195,19 +370,29 @@ __global__ void scatter_ids_kernel(int64_t* x, const int64_t* ti, const int64_t*
     if (pos >= 0 && pos < N) x[(size_t)b * N + pos] = ids[i];
 }
 
-// one workgroup per batch row: bitonic sort (descending) of (score/sum)/noise^ctemp over NT <= 8192
-__global__ __launch_bounds__(256) void next_mask_kernel(const NextMaskParams p, int n_pow2) {
+// one workgroup (1024 threads) per batch row: bitonic sort (descending) of (score/sum)/noise^ctemp over NT <= 16384 in LDS.
+// Every thread works on a compare-exchange PAIR per iteration (pair q of stride j: i = insert a 0 bit at position log2 j, l = i | j),
+// 16 waves hide the LDS latency of each other: 450 us -> tens of us per call at NT = 8192 (the 256-thread loop over elements,
+// half of them idle, was latency-bound on its dependent LDS round trips; profiles/r04_c4_kernel_stats.csv).
+constexpr int NM_THREADS = 1024;
+__global__ __launch_bounds__(NM_THREADS) void next_mask_kernel(const NextMaskParams p, int n_pow2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* key = reinterpret_cast<float*>(smem);
     int* idx = reinterpret_cast<int*>(smem + (size_t)n_pow2 * 4);
-    __shared__ float sh[4];
+    __shared__ float sh[NM_THREADS / 64];
     const int b = blockIdx.x, tid = threadIdx.x, NT = p.NT;
     const float* sc = p.score + (size_t)b * NT;
     const float* nz = p.noise + (size_t)b * NT;
+    // the row sum in the order of the 256-thread kernel this replaces (thread t of 256 adds elements t, t + 256, ...; wave sums;
+    // the four wave totals in order): the keys — and with them the order at near-ties — stay bit-identical
     float s = 0.f;
-    for (int j = tid; j < NT; j += 256) s += sc[j];
-    s = blk_sum(s, sh);
-    for (int j = tid; j < n_pow2; j += 256) {
+    if (tid < 256)
+        for (int j = tid; j < NT; j += 256) s += sc[j];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    __syncthreads();
+    s = sh[0] + sh[1] + sh[2] + sh[3];
+    for (int j = tid; j < n_pow2; j += NM_THREADS) {
         float k = -INFINITY;
         if (j < NT) {
             const float q = p.ctemp == 0.f ? 1.0f : powf(nz[j], p.ctemp);   // mask_sampler.py:183
@@ -216,19 +401,16 @@ __global__ __launch_bounds__(256) void next_mask_kernel(const NextMaskParams p, 
         key[j] = k; idx[j] = j < NT ? j : 0x7FFFFFFF;
     }
     __syncthreads();
+    const int half = n_pow2 >> 1;
     for (int k = 2; k <= n_pow2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n_pow2; i += 256) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const bool desc = (i & k) == 0;
-                    const float a = key[i], c = key[l];
-                    const bool before = (a > c) || (a == c && idx[i] < idx[l]);
-                    if (desc ? !before : before) {
-                        key[i] = c; key[l] = a;
-                        const int t = idx[i]; idx[i] = idx[l]; idx[l] = t;
-                    }
-                }
+            for (int q = tid; q < half; q += NM_THREADS) {
+                const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
+                const bool desc = (i & k) == 0;
+                const float a = key[i], c = key[l];
+                const int ia = idx[i], ic = idx[l];
+                const bool before = (a > c) || (a == c && ia < ic);
+                if (desc ? !before : before) { key[i] = c; key[l] = a; idx[i] = ic; idx[l] = ia; }
             }
             __syncthreads();
         }
@@ -236,9 +418,9 @@ __global__ __launch_bounds__(256) void next_mask_kernel(const NextMaskParams p, 
     const int64_t* ti = p.ti + (size_t)b * NT;
     int64_t* nc = p.new_ci + (size_t)b * (p.NC + p.n_new);
     int64_t* nt = p.new_ti + (size_t)b * (NT - p.n_new);
-    for (int j = tid; j < p.NC; j += 256) nc[j] = ci[j];                        // :228
-    for (int j = tid; j < p.n_new; j += 256) nc[p.NC + j] = ti[idx[j]];         // :232-233
-    for (int j = p.n_new + tid; j < NT; j += 256) nt[j - p.n_new] = ti[idx[j]]; // :231,:234
+    for (int j = tid; j < p.NC; j += NM_THREADS) nc[j] = ci[j];                        // :228
+    for (int j = tid; j < p.n_new; j += NM_THREADS) nc[p.NC + j] = ti[idx[j]];         // :232-233
+    for (int j = p.n_new + tid; j < NT; j += NM_THREADS) nt[j - p.n_new] = ti[idx[j]]; // :231,:234
 }
 
 }  // namespace
@@ -247,6 +429,15 @@ int launch_sample(const SampleParams& p, hipStream_t stream) {
     if (p.rows <= 0) return MEBT_OK;
     if (p.V > SV_MAX || p.V <= 0) { mebt_set_error("sample: vocabulary must be in [1, 16384]"); return MEBT_ESHAPE; }
     const bool tp = p.top_p > 0.f;
+    static const bool fast_on = [] { const char* e = getenv("MEBT_SAMPLE_FAST"); return !(e && e[0] == '0'); }();
+    if (p.probs_ti && (tp || p.V != SV_MAX || !fast_on)) { mebt_set_error("sample: the scattered probability map needs V = 16384 without top-p"); return MEBT_ESHAPE; }
+    if (!tp && p.V == SV_MAX && fast_on) {
+        const size_t fl = p.probs ? (size_t)SV_MAX * 4 : 0;
+        if (fl) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
+        hipLaunchKernelGGL(sample_fast_kernel, dim3(p.rows), dim3(256), fl, stream, p);
+        MEBT_HIP_CHECK(hipGetLastError());
+        return MEBT_OK;
+    }
     const size_t lds = tp ? (size_t)SV_MAX * 6 : (size_t)SV_MAX * 4;
     if (tp) {
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -274,7 +465,7 @@ int launch_next_mask(const NextMaskParams& p, hipStream_t stream) {
     while (n < p.NT) n <<= 1;
     const size_t lds = (size_t)n * 8;
     MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&next_mask_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(next_mask_kernel, dim3(p.B), dim3(256), lds, stream, p, n);
+    hipLaunchKernelGGL(next_mask_kernel, dim3(p.B), dim3(NM_THREADS), lds, stream, p, n);
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;
 }

@@ -556,14 +556,29 @@ class Net2NetTransformer(LightningModuleShim):
             return self.noise_hook(kind, tuple(shape)).to(device, torch.float32)
         return torch.empty(shape, device=device, dtype=torch.float32).exponential_()
 
-    def _sample_tokens(self, logits, temperature, top_k, top_p, want_probs=False):
-        """sample_from_logits (:843-889) + score gather (:409) in one kernel -> (ids, scores, probs?)"""
+    def _sample_tokens(self, logits, temperature, top_k, top_p, want_probs=False, probs_map=None, target_indices=None):
+        """sample_from_logits (:843-889) + score gather (:409) in one kernel -> (ids, scores, probs?).  `probs_map` [B, N, V] with
+        `target_indices` [B, NT]: the probabilities go straight to rows target_indices of the map (the `scatter_` of debug=True,
+        :426-436) instead of through a [B, NT, V] tensor; returns probs = None then."""
         B, NT, V = logits.shape
-        if self.noise_hook is None:      # production: Exp(1) generated inside the kernel, seeded from torch's default generator
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            return sample_from_logits_scored(logits, temperature, top_k, top_p, None, want_probs, seed=seed)
-        noise = self._noise("exp", (B, NT, V), logits.device)
-        return sample_from_logits_scored(logits, temperature, top_k, top_p, noise, want_probs)
+        noise = None if self.noise_hook is None else self._noise("exp", (B, NT, V), logits.device)
+        # production (no hook): Exp(1) generated inside the kernel, seeded from torch's default generator
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else None
+        if probs_map is not None and not top_p and V == 16384:
+            lg = logits.to(torch.float32).contiguous()
+            ids = torch.empty(B, NT, dtype=torch.long, device=lg.device)
+            score = torch.empty(B, NT, dtype=torch.float32, device=lg.device)
+            ti = target_indices.contiguous()
+            nz = None if noise is None else noise.to(torch.float32).contiguous()
+            _lib.check(_lib.load().mebt_op_sample_scatter(_lib.ptr(lg), _lib.ptr(nz), int(seed or 0), float(temperature), int(top_k or 0),
+                                                          _lib.ptr(ids), _lib.ptr(score), _lib.ptr(probs_map), _lib.ptr(ti), B, probs_map.shape[1],
+                                                          NT, V, _lib.cur_stream()))
+            return ids, score, None
+        ids, score, probs = sample_from_logits_scored(logits, temperature, top_k, top_p, noise, want_probs or probs_map is not None, seed=seed)
+        if probs_map is not None:
+            probs_map.scatter_(1, target_indices.unsqueeze(-1).expand(-1, -1, V), probs)
+            probs = None
+        return ids, score, probs
 
     @staticmethod
     def _scatter(partial, target_indices, ids):
@@ -609,10 +624,9 @@ class Net2NetTransformer(LightningModuleShim):
             if int((n_masked > target_indices.shape[-1]).sum()) == B:       # :401-402
                 continue
             logits, _ = self.reconstruct_mask(partial, context_indices, target_indices, debug)
-            ids, scores, probs = self._sample_tokens(logits, temperature, top_k, top_p, want_probs=debug)
             target_indices = target_indices.view(B, -1)
-            if debug:
-                partial_probs.scatter_(1, target_indices.unsqueeze(-1).expand(-1, -1, probs.shape[-1]), probs)
+            ids, scores, _ = self._sample_tokens(logits, temperature, top_k, top_p, probs_map=partial_probs if debug else None,
+                                                 target_indices=target_indices)
             partial = self._scatter(partial, target_indices, ids)
             ctemp = context_temperature * CTEMP_SCHEDULES[ctemp_schedule](t_next)   # :440
             if debug:

@@ -406,6 +406,87 @@ def test_sampler_full_vocab_row():
         np.testing.assert_allclose(probs.cpu().numpy(), probs_r.numpy(), rtol=3e-5, atol=1e-9)
 
 
+def test_sampler_register_kernel_edges_and_scattered_probability_map():
+    """The register-resident sampler (V = 16384, no top-p: csrc/sampler.hip sample_fast_kernel) on the rows that leave its fast
+    top-k path: k = 1, k = 256 (the last k served by the local-maxima bound), k = 300 and k = V - 1 (radix fallback), a row of
+    equal values and a row with two distinct values (more than 1024 candidates -> radix fallback), rows that are -inf except for a
+    few entries, NaNs, temperature != 1 — ids and probabilities against the oracle; then the debug=True form: probabilities
+    written straight to rows ti of a [B, N, V] map == materialise + scatter_ (transformer.py:426-436)."""
+    from oracle import mebt_oracle as orc
+    V = 16384
+    g = torch.Generator().manual_seed(21)
+    rows = [torch.randn(V, generator=g) * 2.0 for _ in range(4)]
+    rows.append(torch.zeros(V))                                              # all equal
+    r = torch.zeros(V); r[::3] = 1.0; rows.append(r)                         # two values, thousands of ties at the threshold
+    r = torch.full((V,), -float("inf")); r[[5, 900, 16383]] = torch.tensor([0.3, 1.2, -0.7]); rows.append(r)
+    r = torch.randn(V, generator=g); r[100:200] = float("nan"); rows.append(r)
+    r = torch.sort(torch.randn(V, generator=g), descending=True).values; rows.append(r)      # the whole top-k inside one thread's stride
+    r = torch.randn(V, generator=g); r[:256 * 40:256] = 7.0; rows.append(r)                   # 40 equal maxima owned by ONE thread
+    logits = torch.stack(rows)
+    R = logits.shape[0]
+    noise = torch.empty(R, V).exponential_(generator=g)
+    ld, nd = logits.to(DEV), noise.to(DEV)
+    for temp, k in ((1.0, 0), (1.0, 1), (1.0, 32), (0.7, 32), (1.0, 256), (1.0, 300), (1.3, 16383), (0.05, 5)):
+        ids_r, probs_r = orc.sample_from_logits(logits, temp, k or None, None, noise)
+        ids = torch.empty(R, dtype=torch.long, device=DEV)
+        score = torch.empty(R, device=DEV)
+        probs = torch.full((R, V), -7.0, device=DEV)
+        check(lib().mebt_op_sample(ptr(ld), ptr(nd), temp, k, 0.0, ptr(ids), ptr(score), ptr(probs), R, V, cur_stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(ids.cpu(), ids_r), (temp, k, ids.cpu().tolist(), ids_r.tolist())
+        assert ((probs.cpu() > 0) == (probs_r > 0)).all(), (temp, k)
+        np.testing.assert_allclose(probs.cpu().numpy(), probs_r.numpy(), rtol=3e-5, atol=1e-9)
+        np.testing.assert_allclose(score.cpu().numpy(), probs_r.gather(1, ids_r.view(R, 1)).squeeze(1).numpy(), rtol=3e-5, atol=1e-12)
+    # the scattered probability map
+    B, N, NT = 2, 9, 5
+    lg = torch.randn(B * NT, V, generator=g)
+    nz = torch.empty(B * NT, V).exponential_(generator=g)
+    ti = torch.stack([torch.randperm(N, generator=g)[:NT] for _ in range(B)])
+    ids_r, probs_r = orc.sample_from_logits(lg, 0.9, 32, None, nz)
+    ref_map = -torch.ones(B, N, V)
+    ref_map.scatter_(1, ti.unsqueeze(-1).expand(-1, -1, V), probs_r.view(B, NT, V))
+    pmap = -torch.ones(B, N, V, device=DEV)
+    ids = torch.empty(B * NT, dtype=torch.long, device=DEV)
+    score = torch.empty(B * NT, device=DEV)
+    lgd, nzd, tid = lg.to(DEV), nz.to(DEV), ti.to(DEV)
+    check(lib().mebt_op_sample_scatter(ptr(lgd), ptr(nzd), 0, 0.9, 32, ptr(ids), ptr(score), ptr(pmap), ptr(tid), B, N, NT, V, cur_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(ids.cpu(), ids_r)
+    assert ((pmap.cpu() == -1) == (ref_map == -1)).all()
+    np.testing.assert_allclose(pmap.cpu().numpy(), ref_map.numpy(), rtol=3e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("NT,NC,ctemp", [(8192, 0, 2.0), (8128, 64, 0.0), (5000, 3192, 1.3), (33, 7, 4.5)])
+def test_next_mask_kernel_long_rows(NT, NC, ctemp):
+    """generate_next_mask at the 128-frame geometry (up to 8192 targets per row; 1024-thread LDS bitonic sort) against the oracle's
+    argsort: the same keys in fp32, stable by index at exact ties."""
+    B = 3
+    g = torch.Generator().manual_seed(NT)
+    perm = torch.stack([torch.randperm(NC + NT, generator=g) for _ in range(B)])
+    ci, ti = perm[:, :NC].contiguous(), perm[:, NC:].contiguous()
+    score = torch.rand(B, NT, generator=g)
+    score[0, : NT // 2] = score[0, NT // 2: 2 * (NT // 2)]                   # exact ties: resolved by position
+    noise = torch.empty(B, NT).exponential_(generator=g)
+    n_new = max(1, NT // 3)
+    nc = torch.empty(B, NC + n_new, dtype=torch.long, device=DEV)
+    nt = torch.empty(B, NT - n_new, dtype=torch.long, device=DEV)
+    cid, tid, sd, nd = ci.to(DEV), ti.to(DEV), score.to(DEV), noise.to(DEV)
+    check(lib().mebt_op_next_mask(ptr(cid) if NC else None, ptr(tid), ptr(sd), ptr(nd), float(ctemp), n_new, B, NC, NT, ptr(nc), ptr(nt), cur_stream()))
+    torch.cuda.synchronize()
+    nc, nt = nc.cpu(), nt.cpu()
+    assert torch.equal(nc[:, :NC], ci)
+    for b in range(B):
+        order = torch.cat([nc[b, NC:], nt[b]])
+        assert sorted(order.tolist()) == sorted(ti[b].tolist())
+        pos = {int(v): j for j, v in enumerate(ti[b].tolist())}
+        js = torch.tensor([pos[int(v)] for v in order])
+        key = (score[b] / score[b].sum()).double() / (noise[b].double() ** ctemp if ctemp else torch.ones(NT, dtype=torch.float64))
+        ko = key[js]
+        assert bool((ko[1:] <= ko[:-1] * (1 + 1e-5)).all())                 # descending in the oracle's keys up to fp32 rounding of the key
+        same = ko[1:] == ko[:-1]
+        assert bool((js[1:][same] > js[:-1][same]).all())                   # exact ties keep their position order
+
+
 @pytest.mark.parametrize("top_k,top_p", [(0, 0.0), (64, 0.0), (0, 0.9), (256, 0.8)])
 def test_sampler_seeded_noise_matches_cpu_twin(top_k, top_p):
     """mebt_op_sample_seeded: the Exp(1) noise is generated inside the kernel (counter-based); with the CPU twin of the
