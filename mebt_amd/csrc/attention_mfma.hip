@@ -21,6 +21,7 @@
 // transposed reads used here.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -97,15 +98,23 @@ __device__ __forceinline__ bf16x8 frag_global(const bf16_t* base, int row, int r
     if (row >= rows) return z;
     return *reinterpret_cast<const bf16x8*>(base + (size_t)row * ld + 32 * ks + 8 * (lane >> 4));
 }
+// Across the 4 lane groups (same l & 15) without the LDS crossbar: v_permlane16_swap / v_permlane32_swap (gfx950) exchange 16- /
+// 32-lane rows between two registers in the vector ALU.  With both operands = v: after the 16-lane swap one register holds rows
+// {0, 0, 2, 2} and the other {1, 1, 3, 3}; after the 32-lane swap {lo, lo} and {hi, hi} — one add / max of the pair is the xor-16 /
+// xor-32 butterfly step.  __shfl_xor compiled to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): four exposed LDS round trips per 64-key tile
+// in the forward's softmax (profiles/r04_attention_forward.txt).
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float group_sum(float v) {   // across the 4 lane groups (same l&15)
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float group_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+    u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
@@ -127,22 +136,24 @@ constexpr int DMA_PER_WAVE = 2 * (CHUNK_BYTES / 1024) / WAVES; // 8 LDS-DMA inst
 // One operand of a chunk = 32 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces w, w+8, w+16, w+24.
 // A piece is written lane-linearly (lane l -> bytes 16 l), so the XOR swizzle of the tile image is applied
 // to the per-lane SOURCE address.  Rows beyond `rows` are zero-filled by the buffer bounds.
+// NW waves copy a chunk of 32 NW rows (NW / 2 tiles): four pieces per wave and operand whatever NW is.
+template <int NW = WAVES>
 struct ChunkDma {
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t goff[4];
     uint32_t step;
     __device__ __forceinline__ void init(const bf16_t* base, int rows, int ld, int wave, int lane) {
         rsrc = make_rsrc(base, rows > 0 ? ((size_t)(rows - 1) * ld + 64) * 2 : 0);
-        step = (uint32_t)CHUNK * ld * 2;
+        step = (uint32_t)(32 * NW) * ld * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = 8 * (wave + WAVES * i) + (lane >> 3), slot = lane & 7;
+            const int row = 8 * (wave + NW * i) + (lane >> 3), slot = lane & 7;
             goff[i] = ((uint32_t)row * ld + 8 * (slot ^ swz(row))) * 2;
         }
     }
     __device__ __forceinline__ void issue(char* dst, int chunk, int wave) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(rsrc, lds_addr_of(dst + (wave + WAVES * i) * 1024), goff[i] + (uint32_t)chunk * step);
+        for (int i = 0; i < 4; ++i) dma16(rsrc, lds_addr_of(dst + (wave + NW * i) * 1024), goff[i] + (uint32_t)chunk * step);
     }
 };
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -150,28 +161,34 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVES * 64) void attn_fwd_mfma(const AttnParams p) {
+// NW = 8: 128 query rows per workgroup, chunks of 256 keys; NW = 4: 64 query rows, chunks of 128 keys (32 KiB per ring stage).
+// The 4-wave form exists for the routings whose 128-row grid does not fill the chip (NQ = 256 latents: 2 x heads x batch
+// workgroups — 128 at config 4, 192 at config 2): the kernel is bound by vector issue (softmax), two waves of one workgroup share
+// a SIMD, so the same waves spread over twice the CUs run up to twice as fast; NST = ring depth (stages of K + V).
+template <int NW, int NST>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CT = NW / 2, CROWS = CT * TILE, CBYTES = CT * TILE_BYTES, SBYTES = 2 * CBYTES;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q = blockIdx.x * BLOCK_ROWS + wave * 16 + (lane & 15);
+    const int q = blockIdx.x * (NW * 16) + wave * 16 + (lane & 15);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (size_t)b * p.NQ * p.ldq + h * 64;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (size_t)b * p.NK * p.ldk + h * 64;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * p.NK * p.ldv + h * 64;
     bf16x8 qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = frag_global(Q, q, p.NQ, p.ldq, ks, lane);
-    ChunkDma lk, lv;
+    ChunkDma<NW> lk, lv;
     lk.init(K, p.NK, p.ldk, wave, lane);
     lv.init(V, p.NK, p.ldv, wave, lane);
-    const int nchunks = (p.NK + CHUNK - 1) / CHUNK;
-    lk.issue(smem, 0, wave);
-    lv.issue(smem + CHUNK_BYTES, 0, wave);
-    if (nchunks > 1) {
-        lk.issue(smem + STAGE_BYTES, 1, wave);
-        lv.issue(smem + STAGE_BYTES + CHUNK_BYTES, 1, wave);
-    }
+    const int nchunks = (p.NK + CROWS - 1) / CROWS;
+#pragma unroll
+    for (int a = 0; a < NST; ++a)
+        if (a < nchunks) {
+            lk.issue(smem + a * SBYTES, a, wave);
+            lv.issue(smem + a * SBYTES + CBYTES, a, wave);
+        }
     const float c = 0.125f * LOG2E;     // 1/sqrt(64) folded with log2(e)
     const int mtiles = mebt_attn_dmask_tiles(p.NK);
     FragOffsets fo;
@@ -182,74 +199,104 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_mfma(const AttnParams p) 
     for (int e = 0; e < 4; ++e) o[e] = f32x4{0, 0, 0, 0};
     float m = -INFINITY, l = 0.f;
 
+    int st = 0;
     for (int ch = 0; ch < nchunks; ++ch) {
-        char* stage = smem + (ch & 1) * STAGE_BYTES;
-        if (ch + 1 < nchunks) wait_vm<DMA_PER_WAVE>(); else wait_vm<0>();     // this wave's pieces of chunk ch landed
+        char* stage = smem + st * SBYTES;
+        // this wave's pieces of chunk ch have landed; the (up to NST - 1) younger chunks may stay in flight
+        const int younger = min(NST - 1, nchunks - 1 - ch);
+        if (younger <= 0) wait_vm<0>();
+        else if (younger == 1) wait_vm<DMA_PER_WAVE>();
+        else if (younger == 2) wait_vm<2 * DMA_PER_WAVE>();
+        else wait_vm<3 * DMA_PER_WAVE>();
         __builtin_amdgcn_s_barrier();                                          // ... and everybody else's
-        const int nt = min(CHUNK_TILES, (p.NK - ch * CHUNK + TILE - 1) / TILE);
-        for (int t = 0; t < nt; ++t) {
+        const int nt = min(CT, (p.NK - ch * CROWS + TILE - 1) / TILE);
+        // TWO 64-key tiles per pass: their 16 score MFMAs are independent, and the softmax pays ONE maximum / sum exchange across
+        // the lane groups, one rescale decision and one dependent chain per 128 keys instead of per 64 (the per-tile chain — reads,
+        // 8 MFMAs, max, exchange, 16 exp, exchange, reads, 8 MFMAs — ran strictly in sequence: ~2000 cycles per tile and wave for
+        // ~700 of work).  A missing second tile (odd count) is a tile of masked keys: the DMA zero-fills rows beyond NK.
+        for (int t = 0; t < nt; t += 2) {
             const char* sK = stage + t * TILE_BYTES;
-            const char* sV = stage + CHUNK_BYTES + t * TILE_BYTES;
-            // S^T[key][q] for the 64 keys of the tile
-            f32x4 s[4];
+            const char* sV = stage + CBYTES + t * TILE_BYTES;
+            // S^T[key][q] for the 128 keys of the two tiles
+            f32x4 s[2][4];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                s[kb] = f32x4{0, 0, 0, 0};
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) s[kb] = MFMA(fo.row_frag(sK, kb, ks), qf[ks], s[kb]);
-            }
-            const int k0 = ch * CHUNK + t * TILE;
+                for (int kb = 0; kb < 4; ++kb) {
+                    s[u][kb] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) s[u][kb] = MFMA(fo.row_frag(sK + u * TILE_BYTES, kb, ks), qf[ks], s[u][kb]);
+                }
+            const int k0 = ch * CROWS + t * TILE;
             float tmax = -INFINITY;
-            if (k0 + TILE > p.NK) {         // ragged last tile only: keys beyond NK are masked out
+            if (k0 + 2 * TILE > p.NK) {     // ragged end only: keys beyond NK are masked out
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (k0 + 64 * u + 16 * kb + 4 * g + r >= p.NK) s[u][kb][r] = -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (k0 + 16 * kb + 4 * g + r >= p.NK) s[kb][r] = -INFINITY;
-            }
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[kb][r]);
+                    for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[u][kb][r]);
             tmax = group_max(tmax) * c;                       // c > 0: max commutes with the scale
             const float mn = fmaxf(m, tmax);
-            const float alpha = fast_exp2(m - mn);
             float ps = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s[kb][r] = fast_exp2(fmaf(s[kb][r], c, -mn)); ps += s[kb][r]; }
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s[u][kb][r] = fast_exp2(fmaf(s[u][kb][r], c, -mn)); ps += s[u][kb][r]; }
             ps = group_sum(ps);
-            l = l * alpha + ps;
+            // the running maximum moves in the first tiles and then rarely: when no lane of the wave saw it move, alpha = exp2(0) = 1
+            // exactly and the rescale of l and of the 16 output accumulators is skipped (same values, 17 vector instructions less)
+            if (__builtin_amdgcn_ballot_w64(mn != m)) {
+                const float alpha = fast_exp2(m - mn);
+                l *= alpha;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] *= alpha;
+            }
+            l += ps;
             m = mn;
             if (p.drop.thresh) {   // attn_drop on the probabilities (gpt.py:135); the row sum above stays undropped
-                const uint64_t dbase = (((uint64_t)b * p.H + h) * p.NQ + q) * p.NK + k0;
-                uint32_t bits = 0;
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    const f32x4 keep = drop_keep4(p.drop, dbase + 16 * kb + 4 * g);
-                    s[kb] *= keep;
+                for (int u = 0; u < 2; ++u) {
+                    if (t + u >= nt) break;
+                    const uint64_t dbase = (((uint64_t)b * p.H + h) * p.NQ + q) * p.NK + k0 + 64 * u;
+                    uint32_t bits = 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) bits |= (keep[r] != 0.f ? 1u : 0u) << (4 * kb + r);
+                    for (int kb = 0; kb < 4; ++kb) {
+                        const f32x4 keep = drop_keep4(p.drop, dbase + 16 * kb + 4 * g);
+                        s[u][kb] *= keep;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bits |= (keep[r] != 0.f ? 1u : 0u) << (4 * kb + r);
+                    }
+                    if (p.dmask && q < p.NQ)      // the keep bits of this lane's 16 elements: read back by the backward kernels
+                        p.dmask[((((size_t)b * p.H + h) * p.NQ + q) * mtiles + ((k0 >> 6) + u)) * 4 + g] = (uint16_t)bits;
                 }
-                if (p.dmask && q < p.NQ)      // the keep bits of this lane's 16 elements: read back by the backward kernels
-                    p.dmask[((((size_t)b * p.H + h) * p.NQ + q) * mtiles + (k0 >> 6)) * 4 + g] = (uint16_t)bits;
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] *= alpha;
             // O^T[e][q] += V^T[e][key] P^T[key][q]
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 pf = pack_acc(s[2 * kk], s[2 * kk + 1]);
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = MFMA(fo.col_frag(sV, e, kk), pf, o[e]);
-            }
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 pf = pack_acc(s[u][2 * kk], s[u][2 * kk + 1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = MFMA(fo.col_frag(sV + u * TILE_BYTES, e, kk), pf, o[e]);
+                }
         }
-        if (ch + 2 < nchunks) {
+        if (ch + NST < nchunks) {
             __builtin_amdgcn_s_barrier();                     // every wave is done reading this stage
-            lk.issue(stage, ch + 2, wave);
-            lv.issue(stage + CHUNK_BYTES, ch + 2, wave);
+            lk.issue(stage, ch + NST, wave);
+            lv.issue(stage + CBYTES, ch + NST, wave);
         }
+        if (++st == NST) st = 0;
     }
     if (q < p.NQ) {
         const float inv = 1.0f / l;
@@ -275,7 +322,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_mfma(const AttnParams 
     const bf16_t* Oo = reinterpret_cast<const bf16_t*>(p.o) + (size_t)b * p.NQ * p.ldo + h * 64;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (size_t)b * p.NK * p.ldk + h * 64;
     const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * p.NK * p.ldv + h * 64;
-    ChunkDma lk, lv;
+    ChunkDma<> lk, lv;
     lk.init(K, p.NK, p.ldk, wave, lane);
     lv.init(V, p.NK, p.ldv, wave, lane);
     const int nchunks = (p.NK + CHUNK - 1) / CHUNK;
@@ -396,7 +443,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_mfma(const AttnParams
     const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * p.NK * p.ldv + h * 64;
     const float* L = p.lse + ((size_t)b * p.H + h) * p.NQ;
     const float* Dl = p.delta + ((size_t)b * p.H + h) * p.NQ;
-    ChunkDma lq, lg;
+    ChunkDma<> lq, lg;
     lq.init(Q, p.NQ, p.ldq, wave, lane);
     lg.init(G, p.NQ, p.lddo, wave, lane);
     // lse / delta of a chunk: 256 floats = one 1-KiB piece each, copied by waves 0 and 1 (zero beyond NQ)
@@ -507,7 +554,10 @@ static int check_layout(const AttnParams& p) {
     if ((p.ldq | p.ldk | p.ldv | p.ldo) % 8) { mebt_set_error("mfma attention: row strides must be multiples of 8 elements"); return MEBT_ESHAPE; }
     static bool inited = false;
     if (!inited) {
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS));
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * CHUNK_BYTES));
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CHUNK_BYTES));
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CHUNK_BYTES));
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * CHUNK_BYTES));
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS));
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS));
         inited = true;
@@ -521,8 +571,23 @@ int launch_attn_fwd_mfma(const AttnParams& p_in, hipStream_t stream) {
     AttnParams p = p_in;
     drop_mark_small(p.drop, (uint64_t)p.B * p.H * p.NQ * p.NK);
     if (int rc = check_layout(p)) return rc;
-    const dim3 grid((p.NQ + BLOCK_ROWS - 1) / BLOCK_ROWS, p.H, p.B);
-    hipLaunchKernelGGL(attn_fwd_mfma, grid, dim3(WAVES * 64), lds_bytes(p.NK), stream, p);
+    // 128-row workgroups (8 waves) unless their grid leaves CUs idle; then 64-row workgroups (4 waves, twice the workgroups).
+    // MEBT_ATTN_FWD_WAVES = 4 | 8 forces one form (A/B runs).
+    static const int force = [] { const char* e = getenv("MEBT_ATTN_FWD_WAVES"); return e ? atoi(e) : 0; }();
+    // measured (tools/attn_bench.py, profiles/r04_attention_forward.txt): with 192 workgroups of 128 rows (config 2, batch 6) the 8-wave
+    // form wins on every routing (10.7 vs 15.0 us at 512 keys); with 128 (batch 4) the 4-wave form does: 93 vs 112 us at 7936 keys
+    const long grid8 = (long)((p.NQ + 127) / 128) * p.H * p.B;
+    const bool four = force ? force == 4 : grid8 <= 128;
+    if (four) {
+        const dim3 grid((p.NQ + 63) / 64, p.H, p.B);
+        // short key sets: two stages of 128 keys (64 KiB: two workgroups per CU); long ones: four stages, one workgroup per CU
+        if (p.NK <= 1024) hipLaunchKernelGGL((attn_fwd_mfma<4, 2>), grid, dim3(256), 2 * CHUNK_BYTES, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_mfma<4, 4>), grid, dim3(256), 4 * CHUNK_BYTES, stream, p);
+    } else {
+        const dim3 grid((p.NQ + BLOCK_ROWS - 1) / BLOCK_ROWS, p.H, p.B);
+        if (p.NK <= CHUNK) hipLaunchKernelGGL((attn_fwd_mfma<8, 1>), grid, dim3(WAVES * 64), 2 * CHUNK_BYTES, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_mfma<8, 2>), grid, dim3(WAVES * 64), 2 * 2 * CHUNK_BYTES, stream, p);
+    }
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;
 }

@@ -54,15 +54,19 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
     const int tid = threadIdx.x, V = p.V, row = blockIdx.x;
     const float* lg = p.logits + (size_t)row * V;
     const float inv_t = 1.0f / (p.temperature + 1e-8f);
+    int n_nan = 0;
     for (int e = tid; e < V; e += 256) {
         float v = lg[e] / (p.temperature + 1e-8f);      // transformer.py:860 (division, not multiply by reciprocal)
         (void)inv_t;
-        if (v != v) v = -INFINITY;                       // :866-868
+        if (v != v) { v = -INFINITY; ++n_nan; }          // :866-868
         sv[e] = v;
     }
+    // torch.topk ranks NaN above every number and the reference filters before it replaces NaNs (see sample_fast_kernel)
+    int top_k = p.top_k;
+    if (__syncthreads_or(n_nan) && top_k > 0 && top_k < V) top_k -= (int)blk_sum((float)n_nan, sh);
     __syncthreads();
-    if (p.top_k > 0 && p.top_k < V) {                    // :863-864, :891-895 — keep everything >= k-th largest
-        if (tid == 0) { sel_prefix = 0; sel_k = (unsigned)p.top_k; }
+    if (top_k > 0 && top_k < V) {                        // :863-864, :891-895 — keep everything >= k-th largest
+        if (tid == 0) { sel_prefix = 0; sel_k = (unsigned)top_k; }
         unsigned mask = 0;
         for (int shift = 24; shift >= 0; shift -= 8) {
             hist[tid] = 0;
@@ -224,13 +228,18 @@ __global__ __launch_bounds__(256) void sample_fast_kernel(const SampleParams p) 
         for (int j = 0; j < FAST_E; ++j) x[j] = x[j] / tdiv;      // transformer.py:860
     }
     float lm = -INFINITY;
+    int n_nan = 0;
 #pragma unroll
     for (int j = 0; j < FAST_E; ++j) {
-        if (x[j] != x[j]) x[j] = -INFINITY;               // :866-868
+        if (x[j] != x[j]) { x[j] = -INFINITY; ++n_nan; }  // :866-868 (applied AFTER the top-k filter in the reference: see top_k below)
         lm = fmaxf(lm, x[j]);
     }
-    if (p.top_k > 0 && p.top_k < V) {                     // :863-864, :891-895 — keep everything >= the k-th largest
-        bool radix = p.top_k > 256;
+    // torch.topk ranks NaN above every number (:891-895 runs before the NaN -> -inf replacement :866-868): a row with n NaNs keeps
+    // everything >= its (k - n)-th largest NUMBER, and nothing is filtered when n >= k (the k-th value is NaN, `out < NaN` is false)
+    int top_k = p.top_k;
+    if (top_k > 0 && top_k < V && __syncthreads_or(n_nan)) top_k -= (int)blk_sum((float)n_nan, sh);
+    if (top_k > 0 && top_k < V) {                         // :863-864, :891-895 — keep everything >= the k-th largest
+        bool radix = top_k > 256;
         if (!radix) {
             lmax[tid] = lm;
             if (tid == 0) ncand = 0;
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(256) void sample_fast_kernel(const SampleParams p) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) greater += (o[r] > lm || (o[r] == lm && 4 * s4 + r < tid)) ? 1 : 0;
             }
-            if (greater == p.top_k - 1) thr = lm;         // exactly one thread: L
+            if (greater == top_k - 1) thr = lm;         // exactly one thread: L
             __syncthreads();
             const float L = thr;
 #pragma unroll
@@ -258,13 +267,13 @@ __global__ __launch_bounds__(256) void sample_fast_kernel(const SampleParams p) 
                     const float c = cand[i];
                     int gt = 0, ge = 0;
                     for (int s = 0; s < n; ++s) { const float o = cand[s]; gt += o > c ? 1 : 0; ge += o >= c ? 1 : 0; }
-                    if (gt < p.top_k && p.top_k <= ge) thr = c;       // every thread that qualifies writes the same value
+                    if (gt < top_k && top_k <= ge) thr = c;       // every thread that qualifies writes the same value
                 }
                 __syncthreads();
             }
         }
         if (radix) {                                      // 4 x 8-bit radix select over the monotone keys, from registers
-            if (tid == 0) { sel_prefix = 0; sel_k = (unsigned)p.top_k; }
+            if (tid == 0) { sel_prefix = 0; sel_k = (unsigned)top_k; }
             unsigned mask = 0;
             for (int shift = 24; shift >= 0; shift -= 8) {
                 hist[tid] = 0;

@@ -434,7 +434,8 @@ def test_sampler_register_kernel_edges_and_scattered_probability_map():
         check(lib().mebt_op_sample(ptr(ld), ptr(nd), temp, k, 0.0, ptr(ids), ptr(score), ptr(probs), R, V, cur_stream()))
         torch.cuda.synchronize()
         assert torch.equal(ids.cpu(), ids_r), (temp, k, ids.cpu().tolist(), ids_r.tolist())
-        assert ((probs.cpu() > 0) == (probs_r > 0)).all(), (temp, k)
+        # the kept sets agree; fp32 denormals (exp of a spread beyond 87 at temperature 0.05) are flushed to zero on the GPU, kept by the CPU
+        assert ((probs.cpu() > 0) == (probs_r > 0))[probs_r > 1e-30].all() and not (probs.cpu() > 0)[probs_r == 0].any(), (temp, k)
         np.testing.assert_allclose(probs.cpu().numpy(), probs_r.numpy(), rtol=3e-5, atol=1e-9)
         np.testing.assert_allclose(score.cpu().numpy(), probs_r.gather(1, ids_r.view(R, 1)).squeeze(1).numpy(), rtol=3e-5, atol=1e-12)
     # the scattered probability map

@@ -5,9 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mebt_amd import _lib
 from mebt_amd._lib import check, ptr, cur_stream
 lib = _lib.load()
-B, H, HD = 6, 16, 64
+H, HD = 16, 64
 C = H * HD
-for name, NQ, NK in (("enc", 256, 512), ("self", 256, 256), ("dec", 512, 256), ("lt2l", 256, 768)):
+# Sky-16f train step (B = 6); UCF-128f revise forward and the first sampler step (B = 4); Taichi-16f sampling (B = 16)
+SHAPES = [(6, "c2 enc", 256, 512), (6, "c2 self", 256, 256), (6, "c2 dec", 512, 256), (6, "c2 lt2l", 256, 768),
+          (4, "c4 enc revise", 256, 7936), (4, "c4 lt2l revise", 256, 512), (4, "c4 dec sample0", 8192, 256), (4, "c4 lt2l sample0", 256, 8448),
+          (4, "c4 train enc", 256, 4096), (4, "c4 train dec", 4096, 256), (16, "c5 enc", 256, 512), (16, "c5 self", 256, 256)]
+for B, name, NQ, NK in SHAPES:
     q = torch.randn(B, NQ, C, device="cuda").bfloat16()
     kv = torch.randn(B, NK, 2 * C, device="cuda").bfloat16()
     do = torch.randn(B, NQ, C, device="cuda").bfloat16()
@@ -23,4 +27,4 @@ for name, NQ, NK in (("enc", 256, 512), ("self", 256, 256), ("dec", 512, 256), (
         for _ in range(20): fn()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 20
-        print(f"{name:5s} {lab:12s} NQ={NQ} NK={NK}: {us:7.1f} us  {fl / us / 1e6:7.1f} TF/s")
+        print(f"{name:16s} B={B:2d} {lab:12s} NQ={NQ} NK={NK}: {us:7.1f} us  {fl / us / 1e6:7.1f} TF/s")
