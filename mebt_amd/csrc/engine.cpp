@@ -174,26 +174,6 @@ static int gemm_pair(const mebt_model* m, const GemmParams& p0_in, const GemmPar
     return rc;
 }
 
-// several independent products in one launch (kernels.h: GemmMulti): the backward's dgrad + weight-gradient pairs
-static int gemm_multi(const mebt_model* m, GemmMulti& g, hipStream_t st) {
-    ProfRec r;
-    const bool prof = g_prof_on;
-    if (prof) {
-        r.a = get_event(); r.b = get_event(); r.flops = 0; r.bytes = 0;
-        for (int i = 0; i < g.n; ++i) {
-            const GemmParams& q = g.p[i];
-            if (q.M <= 0 || q.N <= 0 || q.K <= 0) continue;
-            r.flops += 2.0 * q.M * q.N * q.K;
-            const double out = q.epilogue == EPI_ADAMW ? 26.0 : (q.c_f32 ? 4.0 : 2.0) * (q.C ? 1 : 0) + (q.aux ? 2.0 : 0);
-            r.bytes += ((double)q.M * q.K + (double)q.N * q.K) * 2.0 + (double)q.M * q.N * out;
-        }
-        (void)hipEventRecord(r.a, st);
-    }
-    const int rc = launch_gemm_multi(g, m->ctx.tune.flush ? &m->ctx.tune : nullptr, st);
-    if (prof) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
-    return rc;
-}
-
 extern "C" int mebt_profile_enable(int32_t on) {
     g_prof_on = on != 0;
     for (auto& r : g_prof) { g_ev_pool.push_back(r.a); g_ev_pool.push_back(r.b); }
@@ -764,29 +744,6 @@ static int dgrad(const mebt_model* m, const void* dY, int ld_dy, int64_t w_off, 
     return gemm(m, p, st);
 }
 
-// the same two products as GemmParams, for the merged dgrad + weight-gradient launches (gemm_multi)
-static GemmParams dgrad_params(const mebt_model* m, const void* dY, int ld_dy, int64_t w_off, void* dX, int tokens, int n_out, int k_in, int epilogue,
-                               const void* aux, int ld_aux, int64_t pf_off = -1, int64_t pf_elems = 0) {
-    GemmParams p = gp(dY, m->Wop(w_off), dX, tokens, k_in, n_out, ld_dy, k_in, k_in, 1, 0);
-    p.epilogue = epilogue; p.aux = aux; p.ld_aux = ld_aux;
-    set_pf(m, p, pf_off, pf_elems);
-    return p;
-}
-// dW[n_out, k_in] = dY^T X in the mode the model is in: AdamW in the epilogue (optimizer-in-backward), bf16 wire gradients
-// (data parallel), or stored fp32; `bias`: += column sums of dY
-static GemmParams wgrad_params(const mebt_model* m, const void* dY, int ld_dy, const void* X, int ld_x, int64_t w_off, int n_out, int k_in, int tokens,
-                               float* bias) {
-    GemmParams p = gp(dY, X, m->gW + w_off, n_out, k_in, tokens, ld_dy, ld_x, k_in, 0, 0);
-    p.c_f32 = 1; p.rowsum_a = bias;
-    if (m->wire()) { p.C = (char*)m->gWb + (size_t)w_off * 2; p.c_f32 = 0; }
-    if (m->fused_on) {
-        p.epilogue = EPI_ADAMW; p.opt = m->fused_h;
-        p.opt_p = m->W + w_off; p.opt_m = m->fused_mW + w_off; p.opt_v = m->fused_vW + w_off;
-        p.opt_lp = m->Wlp ? (void*)((char*)m->Wlp + (size_t)w_off * 2) : nullptr;
-    }
-    return p;
-}
-
 // shared tail of the head backward: dlogits (already in x.dlogits) -> dW_head, d ln_f, g_T
 static int head_backward_common(mebt_model* m, hipStream_t st) {
     FwdCtx& x = m->ctx;
@@ -991,28 +948,11 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     const void* dmlp = sc.dout_m;
     static const bool bias_in_wgrad = [] { const char* e = getenv("MEBT_BIAS_IN_WGRAD"); return !(e && e[0] == '0'); }();
     const bool bg = dt == MEBT_BF16 && bias_in_wgrad;           // bias gradients inside the grouped weight-gradient launch
-    // MEBT_BWD_MERGE=1: every dgrad product of the block is launched TOGETHER with the weight-gradient product that reads the same
-    // dY (gemm_multi: critical-path tiles first, the long-K weight-gradient tiles — AdamW in their epilogue — fill the slots the
-    // dgrad tiles' ramp and tail leave idle, dY is fetched once), instead of one grouped weight-gradient launch at the block's end
-    static const bool merge_on = [] { const char* e = getenv("MEBT_BWD_MERGE"); return e && e[0] == '1'; }();
-    const bool mg = merge_on && bg && !side && !m->grad_acc && Mq > 0 && Mk > 0 && pf_level() < 2;
     const int64_t dd = (int64_t)d * d;
-    if (mg) {
-        GemmMulti g2;
-        g2.n = 2;
-        g2.p[0] = dgrad_params(m, dmlp, d, o.w2, sc.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, o.w1, 4 * dd);
-        g2.p[1] = wgrad_params(m, dmlp, d, a.u, 4 * d, o.w2, d, 4 * d, Mq, m->gP + o.b2);
-        RC(gemm_multi(m, g2, st));
-        g2.n = 2;
-        g2.p[0] = dgrad_params(m, sc.d4, 4 * d, o.w1, sc.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, o.wp, dd);
-        g2.p[1] = wgrad_params(m, sc.d4, 4 * d, a.hn, d, o.w1, 4 * d, d, Mq, m->gP + o.b1);
-        RC(gemm_multi(m, g2, st));
-    } else {
     lv.wgrad(dmlp, d, a.u, 4 * d, m->gW + o.w2, d, 4 * d, Mq, m->gP + o.b2, bg);
     RC(dgrad(m, dmlp, d, o.w2, sc.d4, Mq, d, 4 * d, EPI_GELU_BWD, a.pre, 4 * d, st, o.w1, 4 * dd));   // d(pre) = (dmlp W2) * gelu'(pre)
     lv.wgrad(sc.d4, 4 * d, a.hn, d, m->gW + o.w1, 4 * d, d, Mq, m->gP + o.b1, bg);
     RC(dgrad(m, sc.d4, 4 * d, o.w1, sc.dh, Mq, 4 * d, d, EPI_NONE, nullptr, 0, st, o.wp, dd, &a, 0));
-    }
     // dx = dout + LN2'(dh); the same kernel reduces dgamma/dbeta and writes the dropout-masked copy the
     // projection branch reads (x = qn + dropout(att Wp^T + bp))
     const void* dproj = sc.dx;
@@ -1028,16 +968,8 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         if (side) RC(fork_side(m, st));
         RC(launch_ln_bwd(p, dt, st, sd));
     }
-    if (mg) {
-        GemmMulti g2;
-        g2.n = 2;
-        g2.p[0] = dgrad_params(m, dproj, d, o.wp, x.datt, Mq, d, d, EPI_NONE, nullptr, 0, o.wq, 3 * dd);
-        g2.p[1] = wgrad_params(m, dproj, d, a.att, d, o.wp, d, d, Mq, m->gP + o.bp);
-        RC(gemm_multi(m, g2, st));
-    } else {
     lv.wgrad(dproj, d, a.att, d, m->gW + o.wp, d, d, Mq, m->gP + o.bp, bg);
     RC(dgrad(m, dproj, d, o.wp, x.datt, Mq, d, d, EPI_NONE, nullptr, 0, st, o.wq, 3 * dd));
-    }
     // attention backward
     AttnParams ap;
     memset(&ap, 0, sizeof(ap));
@@ -1065,19 +997,11 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         p.rows = rows; p.d = d; p.seg = seg; p.seg_stride = seg_stride; p.seg_off = seg_off;
     };
     if (mode == MEBT_MODE_LATENT_SELF || ismg) {
-        if (mg) {
-            GemmMulti g2;
-            g2.n = 2;
-            g2.p[0] = dgrad_params(m, sc.dqkv_q, 3 * d, o.wq, sc.dqn, Mq, 3 * d, d, EPI_RESID, sc.dx, d, i > 0 ? m->lo[i - 1].w2 : -1, 4 * dd);
-            g2.p[1] = wgrad_params(m, sc.dqkv_q, 3 * d, a.qn, d, o.wq, 3 * d, d, Mq, m->gP + o.bq);
-            RC(gemm_multi(m, g2, st));
-        } else {
         lv.wgrad(sc.dqkv_q, 3 * d, a.qn, d, m->gW + o.wq, 3 * d, d, Mq, m->gP + o.bq, bg);
         RC(dgrad(m, sc.dqkv_q, 3 * d, o.wq, sc.dqn, Mq, 3 * d, d, EPI_RESID, sc.dx, d, st, i > 0 ? m->lo[i - 1].w2 : -1, 4 * dd,
                  i > 0 ? &x.L[i - 1] : nullptr, 1));   // + dx (residual on qn)
         if (side) RC(fork_side(m, st));
         RC(flush_leaves(m, lv, sd));
-        }
         if (ismg) {      // LN1 rows [0,NC) of each sample came from the contexts stream, the rest from the targets stream
             const int NC = x.NC;
             ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_C, 1, 0, B * NC, NC, NC + NT, 0);
@@ -1087,18 +1011,6 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
             ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0);
         }
     } else {
-        if (mg) {
-            GemmMulti g4;
-            g4.n = 4;            // the longer dgrad first, then the query side, then the two weight gradients (longest reduction first)
-            g4.p[0] = dgrad_params(m, sc.dqkv_k, 2 * d, o.wk, sc.dkn, Mk, 2 * d, d, EPI_NONE, nullptr, 0, i > 0 ? m->lo[i - 1].w2 : -1, 4 * dd);
-            g4.p[1] = dgrad_params(m, sc.dqkv_q, d, o.wq, sc.dqn, Mq, d, d, EPI_RESID, sc.dx, d);
-            const bool k_long = Mk >= Mq;
-            const GemmParams wk = wgrad_params(m, sc.dqkv_k, 2 * d, a.kn, d, o.wk, 2 * d, d, Mk, m->gP + o.bk);
-            const GemmParams wq = wgrad_params(m, sc.dqkv_q, d, a.qn, d, o.wq, d, d, Mq, m->gP + o.bq);
-            g4.p[2] = k_long ? wk : wq;
-            g4.p[3] = k_long ? wq : wk;
-            RC(gemm_multi(m, g4, st));
-        } else {
         lv.wgrad(sc.dqkv_q, d, a.qn, d, m->gW + o.wq, d, d, Mq, m->gP + o.bq, bg);
         lv.wgrad(sc.dqkv_k, 2 * d, a.kn, d, m->gW + o.wk, 2 * d, d, Mk, m->gP + o.bk, bg);
         {
@@ -1114,7 +1026,6 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         }
         if (side) RC(fork_side(m, st));
         RC(flush_leaves(m, lv, sd));
-        }
         if (mode == MEBT_MODE_LATENT_ENC) {
             ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0);
             if (Mk > 0) {   // contexts feed every latent_enc block: accumulate in fp32

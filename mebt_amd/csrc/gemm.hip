@@ -31,8 +31,7 @@ int mebt_gemm_attrs_kk(); int mebt_gemm_attrs_kr(); int mebt_gemm_attrs_rr(); in
 void mebt_gemm_pair_kk(GemmPair&, int, int, int, hipStream_t);
 void mebt_gemm_pair_kr(GemmPair&, int, int, int, hipStream_t);
 void mebt_gemm_grouped(GroupedWgrad&, int, int, int, hipStream_t);
-void mebt_gemm_multi_cfg(GemmMulti&, int, int, int, hipStream_t);
-int mebt_gemm_multi_attrs();
+
 
 static void launch_bf16_ks2(const GemmParams& p, int tbm, int tbn, int ring, hipStream_t stream) {
     if (p.a_kc && p.b_kc) mebt_gemm_ks2_kk(p, tbm, tbn, ring, stream);
@@ -591,73 +590,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
     return MEBT_OK;
 }
 
-// Mixed-layout multi-product launch (kernels.h: GemmMulti).  Tile / ring depth are tuned per signature like everything else; a
-// weight-gradient item with the optimizer in its epilogue is not idempotent, so its candidates run with a zero learning rate, zero
-// decay and beta1 = beta2 = 1 (p, m, v rewritten unchanged) and without the bias row sums (atomic adds), as for the grouped launch.
-int launch_gemm_multi(GemmMulti& g, const GemmScratch* scratch, hipStream_t stream) {
-    int n = 0;
-    for (int i = 0; i < g.n; ++i) {
-        const GemmParams& q = g.p[i];
-        if (q.M <= 0 || q.N <= 0) continue;
-        if (q.K <= 0 || (!q.a_kc && q.b_kc) || q.beta || q.split_k > 1 || (q.N % 8) || ((q.a_kc || q.b_kc) && q.K % BK) || (!q.a_kc && (q.M % 8))) {
-            mebt_set_error("gemm_multi: unsupported item (K > 0, layouts KCxKC / KCxRC / RCxRC, no accumulation, no split-K)");
-            return MEBT_ESHAPE;
-        }
-        if (i != n) g.p[n] = g.p[i];
-        drop_mark_small(g.p[n].drop, (uint64_t)g.p[n].M * g.p[n].ldc);
-        ++n;
-    }
-    g.n = n;
-    if (!n) return MEBT_OK;
-    int tbm = 128, tbn = 64, ring = 2;
-    {
-        std::lock_guard<std::mutex> lk(g_tune_mutex);
-        tune_init();
-        TuneKey key{0x60000000 | n};
-        for (int i = 0; i < n; ++i) {
-            const GemmParams& q = g.p[i];
-            key.push_back(q.a_kc | (q.b_kc << 1) | (q.epilogue << 2) | (q.c_f32 << 5) | ((q.bias != nullptr) << 6) | ((q.drop.thresh != 0) << 7) | ((q.rowsum_a != nullptr) << 8));
-            key.push_back(q.a_kc ? tune_bucket(q.M) : q.M);
-            key.push_back(q.N);
-            key.push_back(q.a_kc ? q.K : tune_bucket(q.K));
-        }
-        auto it = g_tuned.find(key);
-        if (it == g_tuned.end() && g_autotune && tune_scratch_of(scratch)) {
-            TuneRun tr;
-            if (int rc = tr.begin(tune_scratch_of(scratch))) return rc;
-            GemmMulti tc = g;
-            for (int i = 0; i < n; ++i) {
-                GemmParams& q = tc.p[i];
-                q.rowsum_a = nullptr;
-                if (q.epilogue == EPI_ADAMW) { q.opt.lr = 0.f; q.opt.weight_decay = 0.f; q.opt.beta1 = 1.f; q.opt.beta2 = 1.f; }
-            }
-            static const int tiles[6][2] = {{128, 128}, {128, 64}, {96, 128}, {96, 64}, {64, 128}, {64, 64}};
-            float best = 1e30f;
-            for (int t = 0; t < 6; ++t)
-                for (int st = 2; st <= 4; ++st) {
-                    if (st == 4 && 4 * (tiles[t][0] + tiles[t][1]) * BK * 2 > 128 * 1024) continue;
-                    float ms = 0.f;
-                    if (int rc = time_cold([&] { mebt_gemm_multi_cfg(tc, tiles[t][0], tiles[t][1], st, stream); }, stream, tr, ms)) return rc;
-                    if (g_tune_log >= 2) fprintf(stderr, "    cand multi %dx%d ring %d: %.1f us\n", tiles[t][0], tiles[t][1], st, ms * 1e3f);
-                    if (ms < best) { best = ms; tbm = tiles[t][0]; tbn = tiles[t][1]; ring = st; }
-                }
-            if (g_tune_log) {
-                fprintf(stderr, "[mebt gemm autotune] multi");
-                for (int i = 0; i < n; ++i) fprintf(stderr, " %s %dx%dx%d", g.p[i].a_kc ? (g.p[i].b_kc ? "fwd" : "dgrad") : "wgrad", g.p[i].M, g.p[i].N, g.p[i].K);
-                fprintf(stderr, " -> %dx%d ring %d (%.1f us cold)\n", tbm, tbn, ring, best * 1e3f);
-            }
-            it = g_tuned.emplace(key, (tbm << 20) | (tbn << 8) | ring).first;
-            tune_remember(key, it->second);
-        }
-        if (it != g_tuned.end()) { tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; ring = it->second & 255; }
-    }
-    mebt_gemm_multi_cfg(g, tbm, tbn, ring, stream);
-    MEBT_HIP_CHECK(hipGetLastError());
-    return MEBT_OK;
-}
-
 int gemm_init_attributes() {
-    if (int rc = mebt_gemm_multi_attrs()) return rc;
     if (int rc = mebt_gemm_attrs_kk()) return rc;
     if (int rc = mebt_gemm_attrs_kr()) return rc;
     if (int rc = mebt_gemm_attrs_rr()) return rc;

@@ -88,19 +88,6 @@ struct GroupedWgrad {
     const GemmScratch* scratch = nullptr;   // host side only, see GemmParams
 };
 int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream);   // fills tile_start / ntx
-// Up to 6 independent bf16 products of ANY of the layouts forward (KC x KC), dgrad (KC x RC) and wgrad (RC x RC) in ONE launch,
-// each with its own epilogue (incl. the weight gradients' AdamW / bf16-wire / bias-row-sum forms).  The backward of a block
-// launches every dgrad product together with the weight-gradient product that reads the same dY (VERDICT r03 #1a): the
-// critical-path tiles are dispatched first, the long-K weight-gradient tiles fill the slots their ramp and tail leave idle, and
-// dY is fetched once.  Items are processed in the order given (item 0's tiles first); item 0 carries the launch's weight prefetch.
-#define MEBT_MAX_MULTI 6
-struct GemmMulti {
-    int n;
-    int tile_start[MEBT_MAX_MULTI + 1];
-    int ntx[MEBT_MAX_MULTI];
-    GemmParams p[MEBT_MAX_MULTI];
-};
-int launch_gemm_multi(GemmMulti& g, const GemmScratch* scratch, hipStream_t stream);
 struct GroupedColsum {
     int n;
     int blk_start[MEBT_MAX_GROUP + 1];
