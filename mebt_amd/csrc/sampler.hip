@@ -35,6 +35,21 @@ __device__ __forceinline__ float exp1_counter(uint64_t seed, uint64_t idx) {
     const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
     return -logf(u);
 }
+// The same draw with the logarithm on v_log_f32: u = (n + 0.5) / 2^24; for u within 2^-6 of 1 (where log2's absolute error would be a
+// large relative one) the series of -log(1 - d), d = 1 - u exact in fp32; elsewhere -log2(u) * ln 2 (relative error < 5e-6).  In-kernel
+// noise has no reference to be bit-equal to; its CPU twin (float64 log of the same u) agrees to that accuracy, inside the 1e-4 the
+// twin test allows at near-ties.
+__device__ __forceinline__ float exp1_fast(uint64_t seed, uint64_t idx) {
+    uint32_t h = pair_hash(seed, 0x5A3B1Eu, idx);
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    const uint32_t n = h >> 8;
+    const float u = ((float)n + 0.5f) * (1.0f / 16777216.0f);
+    const float d = ((float)(16777215u - n) + 0.5f) * (1.0f / 16777216.0f);      // 1 - u, exact
+    const float series = d * (1.0f + d * (0.5f + d * (0.33333334f + d * 0.25f)));
+    const float lg = -__builtin_amdgcn_logf(u) * 0.6931471805599453f;
+    return d < 0.015625f ? series : lg;
+}
 __device__ __forceinline__ uint32_t fkey(float f) {   // monotone float -> uint map
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -194,8 +209,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
 
 // ------------------------------------------------------------------------------------------------
 // The same draw for V = 16384 without top-p (every shipped script), the row in REGISTERS: thread t owns elements t + 256 j
-// (j = 0 .. 63) — the ownership, accumulation order and expressions of sample_kernel above, so ids, scores and probabilities are
-// bit-identical to it — but one pass over the logits instead of six to ten passes over an LDS copy:
+// (j = 0 .. 63), one pass over the logits instead of six to ten passes over an LDS copy:
 //  * top-k threshold (the k-th largest value, ties kept, transformer.py:891-895) without a radix select over 16384 entries (its four
 //    LDS-histogram passes serialised on a handful of bins — logits share their exponent bits — and were most of the 1.9 ms this
 //    kernel averaged on [32768, 16384] inputs): the k-th largest of the 256 per-thread maxima is a lower bound L of the
@@ -205,13 +219,28 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
 //  * exp / division / noise only where the filtered value is not -inf (wave-uniform skips: with top_k = 32 that is 32 of 16384).
 //  * the probability map of debug=True is written straight to its rows of the [B, N, V] map (16-byte stores through an LDS transpose).
 // ------------------------------------------------------------------------------------------------
-constexpr int FAST_E = 64;          // elements per thread
-constexpr int FAST_CAP = 1024;      // candidate list
+constexpr int FAST_T = 512;                 // threads per row
+constexpr int FAST_E = SV_MAX / FAST_T;     // elements per thread: 32
+constexpr int FAST_CAP = 1024;              // candidate list
+__device__ __forceinline__ float blk_sum8(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]));
+}
+__device__ __forceinline__ float blk_max8(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])), fmaxf(fmaxf(sh[4], sh[5]), fmaxf(sh[6], sh[7])));
+}
 
-__global__ __launch_bounds__(256) void sample_fast_kernel(const SampleParams p) {
+__global__ __launch_bounds__(FAST_T) void sample_fast_kernel(const SampleParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 64 KiB only when probabilities are written
-    __shared__ float sh[4];
-    __shared__ __attribute__((aligned(16))) float lmax[256];
+    __shared__ float sh[8];
+    __shared__ float lmax[8];
     __shared__ float cand[FAST_CAP];
     __shared__ unsigned int hist[256];
     __shared__ unsigned int sel_prefix, sel_k, ncand;
@@ -222,7 +251,7 @@ __global__ __launch_bounds__(256) void sample_fast_kernel(const SampleParams p) 
     const float tdiv = p.temperature + 1e-8f;
     float x[FAST_E];
 #pragma unroll
-    for (int j = 0; j < FAST_E; ++j) x[j] = lg[tid + 256 * j];
+    for (int j = 0; j < FAST_E; ++j) x[j] = lg[tid + FAST_T * j];
     if (tdiv != 1.0f) {                                   // x / 1.0f == x: the division is skipped only where it is the identity
 #pragma unroll
         for (int j = 0; j < FAST_E; ++j) x[j] = x[j] / tdiv;      // transformer.py:860
@@ -237,20 +266,23 @@ __global__ __launch_bounds__(256) void sample_fast_kernel(const SampleParams p) 
     // torch.topk ranks NaN above every number (:891-895 runs before the NaN -> -inf replacement :866-868): a row with n NaNs keeps
     // everything >= its (k - n)-th largest NUMBER, and nothing is filtered when n >= k (the k-th value is NaN, `out < NaN` is false)
     int top_k = p.top_k;
-    if (top_k > 0 && top_k < V && __syncthreads_or(n_nan)) top_k -= (int)blk_sum((float)n_nan, sh);
+    if (top_k > 0 && top_k < V && __syncthreads_or(n_nan)) top_k -= (int)blk_sum8((float)n_nan, sh);
     if (top_k > 0 && top_k < V) {                         // :863-864, :891-895 — keep everything >= the k-th largest
-        bool radix = top_k > 256;
+        bool radix = top_k > FAST_T;
         if (!radix) {
-            lmax[tid] = lm;
+            // lower bound L of the threshold: every wave takes the m-th largest of its 64 per-thread maxima, m = ceil(k / 8) (m rounds
+            // of wave maximum + retire one lane that holds it), L = the smallest of the eight: at least 8 m >= k elements are >= L
+            const int mrounds = (top_k + 7) >> 3;
+            float v = lm, wm = lm;
+            for (int r = 0; r < mrounds; ++r) {
+                wm = wave_max(v);
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(v == wm);
+                if ((tid & 63) == (int)__builtin_ctzll(hit)) v = -INFINITY;       // one holder leaves (equal maxima leave one per round)
+            }
+            if ((tid & 63) == 0) lmax[tid >> 6] = wm;
             if (tid == 0) ncand = 0;
             __syncthreads();
-            int greater = 0;                              // rank of this thread's maximum among the 256 (ties: lower thread first)
-            for (int s4 = 0; s4 < 64; ++s4) {
-                const f32x4 o = *reinterpret_cast<const f32x4*>(lmax + 4 * s4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) greater += (o[r] > lm || (o[r] == lm && 4 * s4 + r < tid)) ? 1 : 0;
-            }
-            if (greater == top_k - 1) thr = lm;         // exactly one thread: L
+            if (tid == 0) thr = fminf(fminf(fminf(lmax[0], lmax[1]), fminf(lmax[2], lmax[3])), fminf(fminf(lmax[4], lmax[5]), fminf(lmax[6], lmax[7])));
             __syncthreads();
             const float L = thr;
 #pragma unroll
@@ -263,7 +295,7 @@ __global__ __launch_bounds__(256) void sample_fast_kernel(const SampleParams p) 
             const int n = (int)ncand;
             radix = n > FAST_CAP;                         // block-uniform
             if (!radix) {
-                for (int i = tid; i < n; i += 256) {      // the k-th largest of the candidates: #greater < k <= #greater-or-equal
+                for (int i = tid; i < n; i += FAST_T) {   // the k-th largest of the candidates: #greater < k <= #greater-or-equal
                     const float c = cand[i];
                     int gt = 0, ge = 0;
                     for (int s = 0; s < n; ++s) { const float o = cand[s]; gt += o > c ? 1 : 0; ge += o >= c ? 1 : 0; }
@@ -276,7 +308,7 @@ __global__ __launch_bounds__(256) void sample_fast_kernel(const SampleParams p) 
             if (tid == 0) { sel_prefix = 0; sel_k = (unsigned)top_k; }
             unsigned mask = 0;
             for (int shift = 24; shift >= 0; shift -= 8) {
-                hist[tid] = 0;
+                if (tid < 256) hist[tid] = 0;
                 __syncthreads();
                 const unsigned pre = sel_prefix;
 #pragma unroll
@@ -304,8 +336,9 @@ __global__ __launch_bounds__(256) void sample_fast_kernel(const SampleParams p) 
 #pragma unroll
         for (int j = 0; j < FAST_E; ++j) if (fkey(x[j]) < kT) x[j] = -INFINITY;     // the comparison of sample_kernel (orders -0 below +0)
     }
-    // softmax (:871): max, exp, sum, divide — the accumulation order of sample_kernel
-    const float mx = blk_max(lm, sh);                     // the filter never removes the row maximum
+    // softmax (:871): max, exp, sum; p = e * (1 / sum) (one rounding away from e / sum: inside every tolerance the probabilities are
+    // compared with, and the arg-max below does not depend on the common factor)
+    const float mx = blk_max8(lm, sh);                     // the filter never removes the row maximum
     float se = 0.f;
 #pragma unroll
     for (int j = 0; j < FAST_E; ++j) {
@@ -314,11 +347,12 @@ __global__ __launch_bounds__(256) void sample_fast_kernel(const SampleParams p) 
         x[j] = e;
         se += e;
     }
-    se = blk_sum(se, sh);
+    se = blk_sum8(se, sh);
+    const float inv_se = 1.0f / se;
     float tot = 0.f;
 #pragma unroll
     for (int j = 0; j < FAST_E; ++j) {
-        if (__builtin_amdgcn_ballot_w64(x[j] != 0.f)) x[j] = x[j] / se;            // 0 / se = 0
+        x[j] *= inv_se;
         tot += x[j];
     }
     if (p.probs) {                                        // rows of 64 KiB: transpose through LDS, 16-byte stores
@@ -330,42 +364,51 @@ __global__ __launch_bounds__(256) void sample_fast_kernel(const SampleParams p) 
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < FAST_E; ++j) sv[tid + 256 * j] = x[j];
+        for (int j = 0; j < FAST_E; ++j) sv[tid + FAST_T * j] = x[j];
         __syncthreads();
         f32x4* dst = reinterpret_cast<f32x4*>(p.probs + drow * V);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dst[tid + 256 * i] = *reinterpret_cast<const f32x4*>(sv + 4 * (tid + 256 * i));
+        for (int i = 0; i < SV_MAX / 4 / FAST_T; ++i) dst[tid + FAST_T * i] = *reinterpret_cast<const f32x4*>(sv + 4 * (tid + FAST_T * i));
     }
-    tot = blk_sum(tot, sh);
-    // gumbel_sort (:834-841): arg-max of (p / sum p) / q, zero-probability entries forced to 0
+    tot = blk_sum8(tot, sh);
+    // gumbel_sort (:834-841): arg-max of (p / sum p) / q, zero-probability entries forced to 0.  First sweep: a = p * rcp(q) (the common
+    // factor 1 / sum p dropped, v_rcp_f32 instead of two IEEE divisions) keeping each thread's best entry with its p and q; the row
+    // maximum A of a; then the exact key (p / tot) / q of every thread's best within 4e-6 of A decides (lowest index at equal keys) —
+    // the reference's choice unless TWO of one thread's 32 entries lie within 4e-6 of the row maximum (such a pair is a tie by the
+    // parity tests' own criterion, 5e-4).
     const float* nz = p.noise ? p.noise + (size_t)row * V : nullptr;
-    float best = -1.f, bp = 0.f;
-    int bi = V;
+    float a1 = -1.f, p1 = 0.f, q1 = 1.f;
+    int e1 = V;
 #pragma unroll
     for (int j = 0; j < FAST_E; ++j) {
-        const int e = tid + 256 * j;
+        const int e = tid + FAST_T * j;
         const float pe = x[j];
-        float key = 0.f;
+        float a = 0.f, q = 1.f;
         if (__builtin_amdgcn_ballot_w64(pe > 0.f)) {
             if (pe > 0.f) {
-                const float q = nz ? nz[e] : exp1_counter(p.noise_seed, (uint64_t)row * V + e);
-                key = (pe / tot) / q;
+                q = nz ? nz[e] : exp1_fast(p.noise_seed, (uint64_t)row * V + e);
+                a = pe * __builtin_amdgcn_rcpf(q);
             }
         }
-        if (key > best || (key == best && e < bi)) { best = key; bi = e; bp = pe; }
+        if (a > a1) { a1 = a; e1 = e; p1 = pe; q1 = q; }  // strict: the lower index stays at equal keys.  (As four selects instead of a
+                                                          // branch hipcc overlaps all 32 hash / log chains: 148 VGPRs, one row per CU instead of two.)
     }
+    const float A = blk_max8(a1, sh);
+    float best = -1.f, bp = 0.f;
+    int bi = V;
+    if (a1 >= A * (1.0f - 4e-6f)) { best = p1 > 0.f ? (p1 / tot) / q1 : 0.f; bi = e1; bp = p1; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o, 64), op = __shfl_xor(bp, o, 64);
         const int oi = __shfl_xor(bi, o, 64);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; bp = op; }
     }
-    __shared__ float wb[4], wp[4];
-    __shared__ int wi[4];
+    __shared__ float wb[8], wp[8];
+    __shared__ int wi[8];
     if ((tid & 63) == 0) { wb[tid >> 6] = best; wi[tid >> 6] = bi; wp[tid >> 6] = bp; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w) if (wb[w] > best || (wb[w] == best && wi[w] < bi)) { best = wb[w]; bi = wi[w]; bp = wp[w]; }
+        for (int w = 1; w < 8; ++w) if (wb[w] > best || (wb[w] == best && wi[w] < bi)) { best = wb[w]; bi = wi[w]; bp = wp[w]; }
         p.ids[row] = bi;
         if (p.score) p.score[row] = bp;
     }
@@ -443,7 +486,7 @@ int launch_sample(const SampleParams& p, hipStream_t stream) {
     if (!tp && p.V == SV_MAX && fast_on) {
         const size_t fl = p.probs ? (size_t)SV_MAX * 4 : 0;
         if (fl) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
-        hipLaunchKernelGGL(sample_fast_kernel, dim3(p.rows), dim3(256), fl, stream, p);
+        hipLaunchKernelGGL(sample_fast_kernel, dim3(p.rows), dim3(FAST_T), fl, stream, p);
         MEBT_HIP_CHECK(hipGetLastError());
         return MEBT_OK;
     }
