@@ -234,6 +234,7 @@ int mebt_op_cast_bf16(const float* src, void* dst, int64_t n, mebt_stream_t stre
 /* 0: never time GEMM candidates (measured heuristic or cached choices only: no host synchronisation anywhere);
  * 1: tune unseen signatures at their first launch (default; environment MEBT_GEMM_AUTOTUNE). */
 void mebt_gemm_autotune(int32_t mode);
+int32_t mebt_gemm_autotune_enabled(void);      /* the current mode */
 /* The tuned-configuration table as text (one `n k_0 .. k_{n-1} value` entry per line + a version entry): export returns the bytes
  * needed incl. the terminating 0 and writes them when `cap` suffices; import merges a text (overwrite = 1: its entries replace the
  * ones this process holds; 2: the table is dropped first, i.e. replaced; 0: they only fill gaps) and returns the number of entries taken (0 for a text written by a build

@@ -83,6 +83,7 @@ PROTOTYPES = {
     "mebt_debug_gemm_scratch": (None, [c_vp, c_i64]),
     "mebt_debug_gemm_stamps": (None, [c_vp]),
     "mebt_gemm_autotune": (None, [c_i32]),
+    "mebt_gemm_autotune_enabled": (c_i32, []),
     "mebt_gemm_tune_export": (c_i64, [C.c_char_p, c_i64]),
     "mebt_gemm_tune_import": (c_i32, [C.c_char_p, c_i32]),
     "mebt_profile_enable": (c_i32, [c_i32]),

@@ -253,7 +253,7 @@ extern "C" int32_t mebt_gemm_tune_import(const char* text, int32_t overwrite) {
 }
 // 0: never tune (heuristic / cached choices only; every entry point is then free of host synchronisation and
 // capture-safe), 1: tune unseen signatures at their first launch.  Default: MEBT_GEMM_AUTOTUNE (1).
-int mebt_gemm_autotune_enabled() { std::lock_guard<std::mutex> lk(g_tune_mutex); tune_init(); return g_autotune; }
+extern "C" int32_t mebt_gemm_autotune_enabled(void) { std::lock_guard<std::mutex> lk(g_tune_mutex); tune_init(); return g_autotune; }
 extern "C" void mebt_gemm_autotune(int32_t mode) { std::lock_guard<std::mutex> lk(g_tune_mutex); tune_init(); g_autotune = mode ? 1 : 0; }
 
 static void heuristic_config(const GemmParams& p, int& tbm, int& tbn, int& staging) {

@@ -95,7 +95,7 @@ struct GroupedColsum {
 };
 int launch_colsum_grouped(GroupedColsum& c, int dtype, hipStream_t stream);
 int gemm_init_attributes();
-int mebt_gemm_autotune_enabled();      // is in-situ tuning on (MEBT_GEMM_AUTOTUNE / mebt_gemm_autotune)?
+extern "C" int32_t mebt_gemm_autotune_enabled(void);      // is in-situ tuning on (MEBT_GEMM_AUTOTUNE / mebt_gemm_autotune)?  (public: include/mebt_hip.h)
 void mebt_gemm_force_split(int s);
 
 // ---- embedding gather (reference transformer.py:255-277) and its scatter-add backward -----------

@@ -360,10 +360,12 @@ class GradReducer:
             native.sync_lowp(force=True)
 
     def sync_tune_table(self, src=0):
-        """Every rank adopts rank `src`'s table of tuned GEMM configurations (a collective; TrainLoop calls it after the first
-        step, which is where the in-situ tuner runs).  Ranks that tune on their own can settle on different tiles for the same
-        product — a rank with a slower pick is then the straggler of every later step.  Returns the
-        table text every rank now holds."""
+        """Every rank adopts rank `src`'s table of tuned GEMM configurations (a collective).  Ranks that tune on their own can
+        settle on different tiles for the same product — a rank with a slower pick is then the straggler of every later step
+         — so in a data-parallel job ONLY rank `src` tunes in situ (`lead_tuning()` switches the others'
+        tuner off) and the others replace their table with its table here.  TrainLoop calls this after optimizer steps 1, 2, 4,
+        8, ... and then every 256: unseen signatures (a new bucket of `t`) keep appearing for a while; between two calls a
+        follower launches its heuristic configuration for them (same results, possibly another speed).  Returns the table text."""
         from . import _lib
         if not self.active:
             return _lib.tune_table_text()
@@ -372,6 +374,16 @@ class GradReducer:
         if self.rank != src:
             _lib.tune_table_merge(box[0], replace=True)
         return box[0]
+
+    def lead_tuning(self, src=0):
+        """only rank `src` times GEMM candidates in situ; the other ranks take its choices (sync_tune_table)"""
+        from . import _lib
+        if self.active and self.rank != src:
+            _lib.load().mebt_gemm_autotune(0)
+
+    @staticmethod
+    def tune_sync_due(step):
+        return step > 0 and ((step & (step - 1)) == 0 or step % 256 == 0)
 
     def consolidate(self, native, optimizer_state=False):
         """Make the fp32 masters (and, on request, the AdamW moments) complete on every rank: after sharded steps each rank

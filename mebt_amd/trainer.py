@@ -37,6 +37,10 @@ class TrainLoop:
         # The engine's bf16 wire-gradient binding must match the step() branch that will run: with it bound the Linear weight
         # gradients exist ONLY in gWb (bf16), which only reduce_update() reads.  Set it either way — a TrainLoop built on a
         # model whose previous loop had bound it (bench.py's fallback) must not inherit the binding.
+        # data parallel: one tuner (rank 0), every rank launches its choices (parallel.GradReducer.sync_tune_table)
+        self.sync_tune = bool(self.reducer.active and os.environ.get("MEBT_DP_SYNC_TUNE", "1") != "0")
+        if self.sync_tune:
+            self.reducer.lead_tuning()
         self.sharded = bool(self.reducer.active and self.reducer.mode == "sharded")
         wire = (self.sharded and self.reducer.wire == "bf16" and self.accum == 1 and model.compute_dtype == "bf16"
                 and os.environ.get("MEBT_DP_WIRE_GRADS", "1") != "0")
@@ -133,8 +137,8 @@ class TrainLoop:
             main.wait_stream(opt)                                   # the next forward reads the updated weights
         if self.accum > 1:
             nm.set_grad_accumulate(False)
-        if self.step_count == 1 and red.active and os.environ.get("MEBT_DP_SYNC_TUNE", "1") != "0":
-            red.sync_tune_table()       # the first backward tuned the GEMM tiles in situ on every rank: rank 0's choices win
+        if self.sync_tune and red.tune_sync_due(self.step_count):
+            red.sync_tune_table()       # rank 0 is the only rank that tunes GEMM tiles in situ: the others adopt its table
         m.trainer.global_step += 1
         m.global_step += 1
         return torch.cat([stats, (stats[0] * scale).reshape(1)])

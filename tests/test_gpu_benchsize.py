@@ -409,7 +409,7 @@ def _grad_report(g_hip, grads_ref, grad_gate, cos_gate, rell2_gate):
     return worst, worst_cos, worst_l2, bad
 
 
-@pytest.mark.parametrize("dtype,window", [("f32", None), ("bf16", None), ("f32", (16, 9)), ("bf16", (16, 9))])
+@pytest.mark.parametrize("dtype,window", [("f32", None), ("bf16", None), ("bf16", (16, 9)), ("f32", (16, 9))][:3 if os.environ.get("MEBT_LONG_TESTS") != "1" else 4])
 def test_c4_train_step_vs_oracle(ucf, dtype, window):
     """TRAINING at the 128-frame geometry (VERDICT r03 missing #3 / weak #8: the HIP backward had never run with 4096+ keys or a
     weight-gradient reduction over 8192+ tokens).  UCF-128f preset (configs/ucf/mebt_128f.yaml:4-57: block 8192, grid [32,16,16],
@@ -550,13 +550,13 @@ def test_c4_bidirect_sample_bootstrap_topk_block8192(ucf):
     cosine mask schedule, fp32 engine, against `oracle.bidirect_sample` driven by the same noise: code map identical, or every
     difference a proven fp tie of the oracle (step-by-step replay from the oracle's state), score within 1e-4.  The shipped
     schedule (bootstrap 64 + 32 steps = 96 forwards of ~1.7 TFLOP on the host for the oracle) runs with MEBT_LONG_TESTS=1
-    (result committed under profiles/); the default run uses bootstrap 8 + 8 steps: the same kernels and shapes (NT from
+    (result committed under profiles/); the default run uses bootstrap 4 + 4 steps: the same kernels and shapes (NT from
     8192 down, the [1, 8192, 16384] probability maps, top-k thresholds over 8192 rows)."""
     from mebt_amd.sampling import bidirect_sample
     cfg, sd = ucf
     ocfg = oracle_cfg_of(cfg)
     long_run = os.environ.get("MEBT_LONG_TESTS") == "1"
-    boot, n_steps = (64, 32) if long_run else (8, 8)
+    boot, n_steps = (64, 32) if long_run else (4, 4)
     base = torch.empty(8192, 2048).exponential_(generator=torch.Generator().manual_seed(77001))
 
     def stream(k, kind, shape):

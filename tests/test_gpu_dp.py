@@ -60,14 +60,19 @@ def _worker(rank, world, port, dtype, mode, wire, defer, ret, overlap=True, chec
             if mode == "sharded" and check_buckets:      # deferred: one event per bucket handed to the engine (head, blocks [3,2], [1], [0], non-Linear), none otherwise
                 assert red.defer == defer and len(getattr(loop.native, "_fw_events", [])) == (5 if defer else 0)
                 assert len(red._sharded_ranges) == (5 if world == 2 else 3)      # world 3: head and non-Linear bucket replicated
-        # every rank launches the same kernels from the second step on: the ranks tuned their GEMM tiles in situ side by side in
-        # step 1 (sharing this GPU, so their timings certainly differed) and then adopted rank 0's table (VERDICT r03 #6a)
+        # one tuner per job (VERDICT r03 #6a): only rank 0 times GEMM candidates in situ, the other ranks adopted its table after
+        # steps 1 and 2 (TrainLoop) and never tuned themselves; after one more sync every rank holds rank 0's table
         from mebt_amd import _lib
+        mine = _lib.tune_table_text()
+        red.sync_tune_table()
         tabs = [None] * world
-        dist.all_gather_object(tabs, _lib.tune_table_text())
-        assert all(t == tabs[0] for t in tabs), "tune tables differ between ranks"
+        dist.all_gather_object(tabs, (_lib.tune_table_text(), mine, bool(_lib.load().mebt_gemm_autotune_enabled())))
+        assert all(t[0] == tabs[0][0] for t in tabs), "tune tables differ between ranks after the sync"
+        assert tabs[0][2] and not any(t[2] for t in tabs[1:]), "only rank 0 may tune in situ"
+        lead = set(tabs[0][0].splitlines())
+        assert all(set(t[1].splitlines()) <= lead for t in tabs[1:]), "a follower held an entry rank 0 never chose"
         if dtype == "bf16":
-            assert tabs[0].count("\n") > 3, tabs[0]           # version line + the signatures the tiny config tuned
+            assert tabs[0][0].count("\n") > 3, tabs[0][0]     # version line + the signatures the tiny config tuned
         loss = red.mean_scalars(st[4:5].clone()).cpu()
         stale = red.master_stale
         if stale:

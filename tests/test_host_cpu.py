@@ -162,6 +162,18 @@ def _dp_worker(rank, world, port, ret):
                     off += k
         r = orc.train_step(st, cfg, xs, ids, 0.4, grad_hook=hook)
         t = red.mean_scalars(torch.tensor([r["loss"]], dtype=torch.float64))
+        # one GEMM tuner per job (VERDICT r03 #6a): followers switch their in-situ tuner off and adopt rank 0's table at the sync points
+        from mebt_amd import _lib
+        lib = _lib.load()
+        assert lib.mebt_gemm_autotune_enabled() == 1
+        red.lead_tuning()
+        assert lib.mebt_gemm_autotune_enabled() == (1 if rank == 0 else 0)
+        version = _lib.tune_table_text().splitlines()[0]           # "1 -1 <MEBT_TUNE_VERSION>": texts of another version are ignored
+        assert _lib.tune_table_merge(f"{version}\n4 3 {1536 + 128 * rank} 1024 1024 {100673538 + rank}\n", replace=True) == 1
+        assert _lib.tune_table_merge("4 3 1536 1024 1024 5\n", overwrite=True) == 0      # unversioned text: another build's codes
+        text = red.sync_tune_table()
+        assert text == _lib.tune_table_text() and "4 3 1536 1024 1024 100673538" in text and "1664" not in text
+        assert [red.tune_sync_due(k) for k in (0, 1, 2, 3, 4, 5, 8, 255, 256, 257, 512)] == [False, True, True, False, True, False, True, False, True, False, True]
         if rank == 0:
             ret.put(({k: v.detach().numpy().copy() for k, v in st.P.items()}, float(t)))   # numpy: pickled by value
         dist.barrier()
