@@ -33,6 +33,24 @@ def test_library_exports_every_declared_symbol():
     assert bound.mebt_abi_version() == 2
 
 
+def test_shipped_tune_table_matches_this_build():
+    """mebt_amd/tune/gfx950.txt (tools/make_tune_table.sh) is merged at load time so that a fresh process — every data-parallel
+    rank, every bench run — does not stall on in-situ GEMM tuning.  A table written by a build with other
+    variant codes is ignored as a whole (MEBT_TUNE_VERSION): this test fails when the version was bumped without regenerating it."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from mebt_amd import _lib; t = _lib.tune_table_text(); s = open(_lib.SHIPPED_TUNE).read(); "
+            "print(len(t.splitlines()), len(s.splitlines()), t.splitlines()[0] == s.splitlines()[0])")
+    env = {k: v for k, v in os.environ.items() if k not in ("MEBT_GEMM_TUNE_CACHE", "MEBT_GEMM_TUNE_SHIPPED")}
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    loaded, shipped, same_version = out.stdout.split()
+    assert same_version == "True" and int(loaded) == int(shipped) > 500, out.stdout
+    env["MEBT_GEMM_TUNE_SHIPPED"] = "0"                     # fresh-tuning runs start from an empty table
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.split()[0] == "1", out.stdout
+
+
 def test_product_fails_loudly_without_gpu():
     """no CPU fallback: a forward on a CPU-resident model must raise, not silently compute"""
     from tests.helpers import build_product
