@@ -72,6 +72,7 @@ PROTOTYPES = {
     "mebt_op_conv3d": (c_i32, [c_i32, c_vp, c_i32, c_vp]),
     "mebt_op_groupnorm_silu": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "mebt_op_codebook_argmin": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "mebt_op_codebook_argmin_filtered": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "mebt_op_embedding_rows": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "mebt_op_cast_f16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "mebt_debug_dropout_mask": (c_i32, [C.c_uint64, C.c_uint32, c_f32, c_i64, c_vp, c_vp]),

@@ -377,41 +377,49 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_mfma(const AttnParams 
         if (ch + 1 < nchunks) { if (wave < 4) wait_vm<DMA_PER_WAVE + 1>(); else wait_vm<DMA_PER_WAVE>(); } else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         const int nt = min(CHUNK_TILES, (p.NK - ch * CHUNK + TILE - 1) / TILE);
-        for (int t = 0; t < nt; ++t) {
-            const char* sK = stage + t * TILE_BYTES;
-            const char* sV = stage + CHUNK_BYTES + t * TILE_BYTES;
-            const int k0 = ch * CHUNK + t * TILE;
-            const uint32_t bits = use_bits ? *reinterpret_cast<const uint16_t*>(stage + MASK_OFF + mlds + t * 8) : 0u;
-            f32x4 ds[4];
+        // TWO key tiles per pass, unconditionally (a chunk always holds four tile images; rows beyond NK are zero-filled and their
+        // probabilities forced to 0): 16 independent score / dP chains and 32 exponentials in flight instead of a strictly
+        // sequential reads -> MFMA -> exp -> pack -> MFMA chain per tile (as in the forward)
+        for (int t = 0; t < nt; t += 2) {
+            f32x4 ds[2][4];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+            for (int u = 0; u < 2; ++u) {
+                const char* sK = stage + (t + u) * TILE_BYTES;
+                const char* sV = stage + CHUNK_BYTES + (t + u) * TILE_BYTES;
+                const int k0 = ch * CHUNK + (t + u) * TILE;
+                const uint32_t bits = use_bits ? *reinterpret_cast<const uint16_t*>(stage + MASK_OFF + mlds + (t + u) * 8) : 0u;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    s = MFMA(fo.row_frag(sK, kb, ks), qf[ks], s);      // S^T[key][q]
-                    dp = MFMA(fo.row_frag(sV, kb, ks), gf[ks], dp);    // dP^T[key][q] = V dO^T
-                }
-                f32x4 keep = {1.f, 1.f, 1.f, 1.f};
-                if (use_bits) {
+                for (int kb = 0; kb < 4; ++kb) {
+                    f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) keep[r] = ((bits >> (4 * kb + r)) & 1u) ? p.drop.inv_keep : 0.f;
-                } else if (p.drop.thresh) {
-                    keep = drop_keep4(p.drop, drow + (uint64_t)(k0 + 16 * kb + 4 * g));
-                }
+                    for (int ks = 0; ks < 2; ++ks) {
+                        sc = MFMA(fo.row_frag(sK, kb, ks), qf[ks], sc);     // S^T[key][q]
+                        dp = MFMA(fo.row_frag(sV, kb, ks), gf[ks], dp);    // dP^T[key][q] = V dO^T
+                    }
+                    f32x4 keep = {1.f, 1.f, 1.f, 1.f};
+                    if (use_bits) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + 16 * kb + 4 * g + r;
-                    const float pr = key < p.NK ? fast_exp2(fmaf(s[r], c, -lse2)) : 0.f;
-                    ds[kb][r] = pr * (dp[r] * keep[r] - delta) * 0.125f;
+                        for (int r = 0; r < 4; ++r) keep[r] = ((bits >> (4 * kb + r)) & 1u) ? p.drop.inv_keep : 0.f;
+                    } else if (p.drop.thresh) {
+                        keep = drop_keep4(p.drop, drow + (uint64_t)(k0 + 16 * kb + 4 * g));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + 16 * kb + 4 * g + r;
+                        const float pr = key < p.NK ? fast_exp2(fmaf(sc[r], c, -lse2)) : 0.f;
+                        ds[u][kb][r] = pr * (dp[r] * keep[r] - delta) * 0.125f;
+                    }
                 }
             }
             // dQ^T[e][q] += K^T[e][key] dS^T[key][q]
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 df = pack_acc(ds[2 * kk], ds[2 * kk + 1]);
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dq[e] = MFMA(fo.col_frag(sK, e, kk), df, dq[e]);
-            }
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 df = pack_acc(ds[u][2 * kk], ds[u][2 * kk + 1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dq[e] = MFMA(fo.col_frag(stage + (t + u) * TILE_BYTES, e, kk), df, dq[e]);
+                }
         }
         if (ch + 2 < nchunks) {
             __builtin_amdgcn_s_barrier();
@@ -492,44 +500,50 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_mfma(const AttnParams
         const char* cm = stage + MASK_OFF + (wave >> 2) * 8 + ((lane >> 2) & 3) * 2;
         const int mbit = 4 * (wave & 3) + (lane & 3);
         const int nt = min(CHUNK_TILES, (p.NQ - ch * CHUNK + TILE - 1) / TILE);
-        for (int t = 0; t < nt; ++t) {
-            const char* sQ = stage + t * TILE_BYTES;
-            const char* sG = stage + CHUNK_BYTES + t * TILE_BYTES;
-            const int q0 = ch * CHUNK + t * TILE;
-            f32x4 pr[4], ds[4];
+        // two query tiles per pass, unconditionally (see the dQ kernel; padded query rows are zero rows of Q and dO: they add nothing)
+        for (int t = 0; t < nt; t += 2) {
+            f32x4 pr[2][4], ds[2][4];
 #pragma unroll
-            for (int qb = 0; qb < 4; ++qb) {
-                f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+            for (int u = 0; u < 2; ++u) {
+                const char* sQ = stage + (t + u) * TILE_BYTES;
+                const char* sG = stage + CHUNK_BYTES + (t + u) * TILE_BYTES;
+                const int q0 = ch * CHUNK + (t + u) * TILE;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    s = MFMA(fo.row_frag(sQ, qb, ks), kf[ks], s);      // S[q][key]
-                    dp = MFMA(fo.row_frag(sG, qb, ks), vf[ks], dp);    // dP[q][key] = dO V^T
-                }
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(cl + t * TILE + 16 * qb + 4 * g);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(cd + t * TILE + 16 * qb + 4 * g);
+                for (int qb = 0; qb < 4; ++qb) {
+                    f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qi = q0 + 16 * qb + 4 * g + r;
-                    // padded query rows (qi >= NQ): Q and dO rows are zero-filled, so whatever p is they add nothing
-                    const float pv = fast_exp2(fmaf(s[r], c, -l4[r] * LOG2E));
-                    float keep = 1.0f;
-                    if (use_bits) keep = ((*reinterpret_cast<const uint16_t*>(cm + (t * TILE + 16 * qb + 4 * g + r) * 16) >> mbit) & 1u) ? p.drop.inv_keep : 0.f;
-                    else if (p.drop.thresh) keep = drop_keep(p.drop, dcol + (uint64_t)(uint32_t)qi * (uint32_t)p.NK);
-                    ds[qb][r] = pv * (dp[r] * keep - d4[r]) * 0.125f;
-                    pr[qb][r] = pv * keep;
+                    for (int ks = 0; ks < 2; ++ks) {
+                        sc = MFMA(fo.row_frag(sQ, qb, ks), kf[ks], sc);     // S[q][key]
+                        dp = MFMA(fo.row_frag(sG, qb, ks), vf[ks], dp);    // dP[q][key] = dO V^T
+                    }
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(cl + (t + u) * TILE + 16 * qb + 4 * g);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(cd + (t + u) * TILE + 16 * qb + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qi = q0 + 16 * qb + 4 * g + r;
+                        // padded query rows (qi >= NQ): Q and dO rows are zero-filled, so whatever p is they add nothing
+                        const float pv = fast_exp2(fmaf(sc[r], c, -l4[r] * LOG2E));
+                        float keep = 1.0f;
+                        if (use_bits) keep = ((*reinterpret_cast<const uint16_t*>(cm + ((t + u) * TILE + 16 * qb + 4 * g + r) * 16) >> mbit) & 1u) ? p.drop.inv_keep : 0.f;
+                        else if (p.drop.thresh) keep = drop_keep(p.drop, dcol + (uint64_t)(uint32_t)qi * (uint32_t)p.NK);
+                        ds[u][qb][r] = pv * (dp[r] * keep - d4[r]) * 0.125f;
+                        pr[u][qb][r] = pv * keep;
+                    }
                 }
             }
             // dV^T[e][key] += dO^T[e][q] P[q][key];   dK^T[e][key] += Q^T[e][q] dS[q][key]
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 pf = pack_acc(pr[2 * kk], pr[2 * kk + 1]);
-                const bf16x8 df = pack_acc(ds[2 * kk], ds[2 * kk + 1]);
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    dv[e] = MFMA(fo.col_frag(sG, e, kk), pf, dv[e]);
-                    dk[e] = MFMA(fo.col_frag(sQ, e, kk), df, dk[e]);
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 pf = pack_acc(pr[u][2 * kk], pr[u][2 * kk + 1]);
+                    const bf16x8 df = pack_acc(ds[u][2 * kk], ds[u][2 * kk + 1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dv[e] = MFMA(fo.col_frag(stage + CHUNK_BYTES + (t + u) * TILE_BYTES, e, kk), pf, dv[e]);
+                        dk[e] = MFMA(fo.col_frag(stage + (t + u) * TILE_BYTES, e, kk), df, dk[e]);
+                    }
                 }
-            }
         }
         if (ch + 2 < nchunks) {
             __builtin_amdgcn_s_barrier();

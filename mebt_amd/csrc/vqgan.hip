@@ -176,6 +176,165 @@ __global__ __launch_bounds__(256) void conv3d_voxel_kernel(const mebt_conv3d_des
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same thin layers on the matrix cores (fp16 mode).  conv3d_voxel_kernel ran them on the vector ALUs: 1.0 ms for the 3 -> 32
+// first layer and 1.9 ms for the 64 -> 3 last layer at batch 16 (12 % of encode + decode; profiles/r04_vqgan16_kernel_table.txt).
+// Both use v_mfma_f32_16x16x32_f16 with the operands swapped (D^T = W A^T: a lane owns 4 consecutive output channels of one voxel).
+//
+// conv3d_first_mfma_kernel (fp32 [B, C, T, H, W] video in, CIN = 3): K = taps x CIN (81) padded to a multiple of 32.  There is no
+// contiguous k-run to copy — k = 3 tap + channel — so every lane gathers the 8 values of its A fragment (voxel lane & 15, k group
+// lane >> 4) from the video with clamped coordinates (replicate padding) and rounds them to fp16; the weight fragments
+// (Cout / 16 x K / 32, at most 8) stay in registers for the whole kernel.  A wave walks 16-voxel row blocks with a grid stride.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int NKS, int NCF>
+__global__ __launch_bounds__(256) void conv3d_first_mfma_kernel(const mebt_conv3d_desc p) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    const int K = p.ntaps * CIN;
+    const f16_t* w = reinterpret_cast<const f16_t*>(p.w);
+    f16x8 wf[NKS][NCF];
+    uint32_t tk[NKS][8];           // this lane's k -> (dt + 8, dh + 8, dw + 8, channel | valid << 7), voxel-independent
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * ks + 8 * g + j;
+            const int tap = k / CIN, ci = k - tap * CIN;
+            tk[ks][j] = k < K ? ((uint32_t)(p.tap[tap][0] + 8) | ((uint32_t)(p.tap[tap][1] + 8) << 8) | ((uint32_t)(p.tap[tap][2] + 8) << 16) | ((uint32_t)(ci | 128) << 24)) : 0u;
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf) wf[ks][cf][j] = k < K ? w[(size_t)(16 * cf + r) * K + k] : (f16_t)0.f;
+        }
+    }
+    const long Mcls = (long)p.B * p.cT * p.cH * p.cW;
+    const long nblk = (Mcls + 15) / 16;
+    const uint32_t plane = (uint32_t)(p.Ti * p.Hi * p.Wi);       // the launcher vouches for < 2^31 input elements: 32-bit index arithmetic
+    const float* x = reinterpret_cast<const float*>(p.in);
+    for (long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblk; blk += (long)gridDim.x * 4) {
+        long m = blk * 16 + r;
+        const bool live = m < Mcls;
+        if (!live) m = Mcls - 1;
+        const Vox v = decode_vox(p, m);
+        const float* xb = x + (uint32_t)v.b * CIN * plane;
+        const int t0 = v.t * p.sm[0] - 8, h0 = v.h * p.sm[1] - 8, w0 = v.w * p.sm[2] - 8;
+        f32x4 acc[NCF];
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf) acc[cf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            f16x8 af;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t c = tk[ks][j];
+                const int ti = clampi(t0 + (int)(c & 255u), p.Ti - 1);
+                const int hi = clampi(h0 + (int)((c >> 8) & 255u), p.Hi - 1);
+                const int wi = clampi(w0 + (int)((c >> 16) & 255u), p.Wi - 1);
+                const float val = xb[((c >> 24) & 127u) * plane + (uint32_t)((ti * p.Hi + hi) * p.Wi + wi)];  // k >= K: element (0, clamped origin), times a zero weight
+                af[j] = (f16_t)val;
+            }
+#pragma unroll
+            for (int cf = 0; cf < NCF; ++cf) acc[cf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][cf], af, acc[cf], 0, 0, 0);
+        }
+        if (!live) continue;
+        const size_t ov = out_voxel(p, v);
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf) {
+            const int n = 16 * cf + 4 * g;
+            f32x4 o = acc[cf];
+            if (p.bias) o += *reinterpret_cast<const f32x4*>(p.bias + n);
+            st4<f16_t>(reinterpret_cast<f16_t*>(p.out) + ov * p.Cout + n, o);
+        }
+    }
+}
+
+// conv3d_last_mfma_kernel (channels-last fp16 in, Cin % 32 == 0, Cout <= 16 padded to one 16-column fragment; any output mode):
+// K = taps x Cin (1728) in 32-channel steps of one tap, so an A fragment is ONE 16-byte load per lane (voxel lane & 15, channels
+// c0 + 8 (lane >> 4) .. + 7 of the tap's input voxel).  The weights sit in LDS already arranged as fragments ([k-step][lane] x 16 B:
+// conflict-free, one ds_read_b128 per k-step); a wave multiplies FOUR 16-voxel row blocks per k-step against each fragment.
+template <int KC2>
+__global__ __launch_bounds__(256) void conv3d_last_mfma_kernel(const mebt_conv3d_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_l[];
+    f16x8* wl = reinterpret_cast<f16x8*>(smem_l);            // [nks][64]
+    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    const int kc = p.Cin / 32, nks = p.ntaps * kc, K = p.ntaps * p.Cin;
+    const f16_t* w = reinterpret_cast<const f16_t*>(p.w);
+    for (int i = threadIdx.x; i < nks * 64; i += 256) {
+        const int ks = i >> 6, l = i & 63, n = l & 15, k0 = 32 * ks + 8 * (l >> 4);
+        f16x8 f = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (n < p.Cout) f = *reinterpret_cast<const f16x8*>(w + (size_t)n * K + k0);
+        wl[i] = f;
+    }
+    __syncthreads();
+    constexpr int RF = 4;
+    const long Mcls = (long)p.B * p.cT * p.cH * p.cW;
+    const long nblk = (Mcls + 16 * RF - 1) / (16 * RF);
+    const f16_t* in = reinterpret_cast<const f16_t*>(p.in);
+    for (long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblk; blk += (long)gridDim.x * 4) {
+        Vox v[RF];
+        bool live[RF];
+#pragma unroll
+        for (int i = 0; i < RF; ++i) {
+            long m = (blk * RF + i) * 16 + r;
+            live[i] = m < Mcls;
+            if (!live[i]) m = Mcls - 1;
+            v[i] = decode_vox(p, m);
+        }
+        f32x4 acc[RF];
+#pragma unroll
+        for (int i = 0; i < RF; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the loads of tap j + 1 are issued before the MFMAs of tap j (two register sets): one exposed L1 / L2 round trip per
+        // 64 voxels instead of one per k-step.  KC2 = Cin / 32 k-steps per tap (2 for the 64-channel last layer).
+        f16x8 af[2][KC2][RF];
+        auto load_tap = [&](int j, int buf) {
+#pragma unroll
+            for (int i = 0; i < RF; ++i) {
+                const int ti = clampi(v[i].t * p.sm[0] + p.tap[j][0], p.Ti - 1);
+                const int hi = clampi(v[i].h * p.sm[1] + p.tap[j][1], p.Hi - 1);
+                const int wi = clampi(v[i].w * p.sm[2] + p.tap[j][2], p.Wi - 1);
+                const uint32_t vox = (uint32_t)(((v[i].b * p.Ti + ti) * p.Hi + hi) * p.Wi + wi);      // < 2^31 input elements (launcher)
+                const f16_t* src = in + vox * (uint32_t)p.Cin + 8 * g;
+#pragma unroll
+                for (int c = 0; c < KC2; ++c)
+                    if (c < kc) af[buf][c][i] = *reinterpret_cast<const f16x8*>(src + 32 * c);
+            }
+        };
+        load_tap(0, 0);
+        for (int j = 0; j < p.ntaps; j += 2) {
+            if (j + 1 < p.ntaps) load_tap(j + 1, 1);
+#pragma unroll
+            for (int c = 0; c < KC2; ++c)
+                if (c < kc) {
+                    const f16x8 wf = wl[(j * kc + c) * 64 + lane];
+#pragma unroll
+                    for (int i = 0; i < RF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, af[0][c][i], acc[i], 0, 0, 0);
+                }
+            if (j + 1 >= p.ntaps) break;
+            if (j + 2 < p.ntaps) load_tap(j + 2, 0);
+#pragma unroll
+            for (int c = 0; c < KC2; ++c)
+                if (c < kc) {
+                    const f16x8 wf = wl[((j + 1) * kc + c) * 64 + lane];
+#pragma unroll
+                    for (int i = 0; i < RF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, af[1][c][i], acc[i], 0, 0, 0);
+                }
+        }
+        const size_t oplane = (size_t)p.To * p.Ho * p.Wo;
+#pragma unroll
+        for (int i = 0; i < RF; ++i) {
+            if (!live[i]) continue;
+            const size_t ov = out_voxel(p, v[i]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 4 * g + q;
+                if (c >= p.Cout) continue;
+                float a = acc[i][q] + (p.bias ? p.bias[c] : 0.f);
+                if (p.resid) a += (float)reinterpret_cast<const f16_t*>(p.resid)[ov * p.Cout + c];
+                if (p.out_mode == 0) reinterpret_cast<f16_t*>(p.out)[ov * p.Cout + c] = (f16_t)a;
+                else if (p.out_mode == 1) reinterpret_cast<float*>(p.out)[ov * p.Cout + c] = a;
+                else reinterpret_cast<float*>(p.out)[((ov / oplane) * p.Cout + c) * oplane + ov % oplane] = a;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MFMA implicit GEMM, fp16: C[m, n] = sum_{tap, ci} in[vox(m, tap), ci] * w[n][tap][ci]
 // ------------------------------------------------------------------------------------------------
 constexpr int CBM = 128, CBN = 64, CBK = 32, CLD = 40;      // LDS rows of 32 halfs padded to 40 (80 B): conflict-free b128 reads
@@ -520,6 +679,91 @@ __global__ __launch_bounds__(256) void codebook_argmin_kernel(const float* score
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Filtered search (large M x n_codes): the [M, n_codes] score matrix costs 137 GFLOP at config 5 / batch 16 — 1.16 ms on the exact
+// fp32 MFMA GEMM (77 % of its peak), a third of the whole encode.  The bf16 GEMM family computes APPROXIMATE scores 5x faster; this
+// kernel turns them into the same ids the exact search gives:
+//   d~_j = (|z|^2 - 2 s~_j) + |e_j|^2,  |d~_j - d_j| <= mu := 2^-7 |z| max_j |e_j| (1 + 2^-6)   (bf16 round-to-nearest: |x - x~| <= 2^-9 |x|
+//   per vector, Cauchy-Schwarz on both factors, doubled by the -2; the fp32 accumulation of the MFMA is inside the 2^-6 slack),
+// so the true arg-min is among C = { j : d~_j <= min d~ + 2 mu }.  For every j in C the distance is re-evaluated in exact fp32 (a
+// sequential FMA chain over k, the order of the exact GEMM) and the first minimum in index order wins, as in codebook_argmin_kernel.
+// |C| is a handful on real codebooks; more than 1024 candidates (degenerate codebook) -> every code is re-evaluated.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vec_max_sqrt_kernel(const float* v, float* out, int n) {      // out[0] = sqrt(max v)
+    __shared__ float sh[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, v[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = sqrtf(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])));
+}
+constexpr int CB_CAP = 1024;
+__global__ __launch_bounds__(256) void codebook_filter_kernel(const float* score /*[M, n_codes] ~ z E^T (bf16 operands)*/, const float* z, const float* e,
+                                                              const float* esq, const float* emax, int64_t* ids, int n_codes, int d) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    float* zl = reinterpret_cast<float*>(smem_c);                  // [d]
+    int* cand = reinterpret_cast<int*>(zl + d);                    // [CB_CAP]
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ float szz, smin;
+    __shared__ unsigned int ncand;
+    const int m = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < d; k += 256) zl[k] = z[(size_t)m * d + k];
+    if (threadIdx.x == 0) ncand = 0;
+    __syncthreads();
+    if (wv == 0) {           // |z|^2 in the summation order of codebook_argmin_kernel
+        float s = 0.f;
+        for (int k = lane; k < d; k += 64) { const float v = zl[k]; s += v * v; }
+        s = wave_sum(s);
+        if (lane == 0) szz = s;
+    }
+    __syncthreads();
+    const float zz = szz;
+    const float* srow = score + (size_t)m * n_codes;
+    float best = INFINITY;
+    for (int j = threadIdx.x; j < n_codes; j += 256) best = fminf(best, (zz - 2.0f * srow[j]) + esq[j]);
+    best = -wave_max(-best);
+    if (lane == 0) sv[wv] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) smin = fminf(fminf(sv[0], sv[1]), fminf(sv[2], sv[3]));
+    __syncthreads();
+    const float mu = 0.0078125f * 1.015625f * sqrtf(zz) * emax[0];
+    const float thr = smin + 2.0f * mu + 1e-30f;
+    for (int j = threadIdx.x; j < n_codes; j += 256)
+        if ((zz - 2.0f * srow[j]) + esq[j] <= thr) {
+            const unsigned pos = atomicAdd(&ncand, 1u);
+            if (pos < (unsigned)CB_CAP) cand[pos] = j;
+        }
+    __syncthreads();
+    const bool all = ncand > (unsigned)CB_CAP;               // block-uniform
+    const int n = all ? n_codes : (int)ncand;
+    float bd = INFINITY;
+    int bi = 0x7FFFFFFF;
+    for (int c = threadIdx.x; c < n; c += 256) {
+        const int j = all ? c : cand[c];
+        const float* ej = e + (size_t)j * d;
+        float s = 0.f;
+        for (int k = 0; k < d; ++k) s = fmaf(zl[k], ej[k], s);          // exact fp32, k ascending (the exact GEMM's chain)
+        const float dist = (zz - 2.0f * s) + esq[j];
+        if (dist < bd || (dist == bd && j < bi)) { bd = dist; bi = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(bd, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob < bd || (ob == bd && oi < bi)) { bd = ob; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { sv[wv] = bd; si[wv] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k)
+            if (sv[k] < bd || (sv[k] == bd && si[k] < bi)) { bd = sv[k]; bi = si[k]; }
+        ids[m] = bi;
+    }
+}
+
 // decode: out[m, :] = E[ids[m], :]  (F.embedding, vqgan.py:91), channels-last
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_rows_kernel(const int64_t* ids, const float* e, T* out, long rows, int d, int n_codes) {
@@ -556,6 +800,8 @@ extern "C" int mebt_op_conv3d(int32_t dtype, const mebt_conv3d_desc* d, int32_t 
     const int maxc = p.Cout <= 4 ? 4 : (p.Cout <= 32 && p.in_mode == 1 ? 32 : 0);
     const size_t vlds = (size_t)p.ntaps * p.Cin * maxc * 4;
     static const int conv_dma = [] { const char* e = getenv("MEBT_CONV_DMA"); return (e && e[0] == '0') ? 0 : 1; }();   // 0: the first (register-staged) kernel
+    const bool small_in = (size_t)p.B * p.Ti * p.Hi * p.Wi * p.Cin < (1ull << 31);      // the thin MFMA kernels index the input with 32 bits
+    static const int thin_mfma = [] { const char* e = getenv("MEBT_CONV_THIN_MFMA"); return (e && e[0] == '0') ? 0 : 1; }();   // 0: the 3-channel boundary layers on the vector ALUs (conv3d_voxel_kernel)
     if (mfma && conv_dma && p.Cin % 64 == 0 && p.Cout % 64 == 0 && (size_t)p.B * p.Ti * p.Hi * p.Wi * p.Cin * 2 < (1ull << 32)) {
         // tile: 128 x 128 (two workgroups per CU at ring depth 2) where Cout allows, else 256 x 64; MEBT_CONV_TILE=bm,bn,ring (experiments)
         static int force[3] = {0, 0, 0};
@@ -583,6 +829,25 @@ extern "C" int mebt_op_conv3d(int32_t dtype, const mebt_conv3d_desc* d, int32_t 
     } else if (mfma) {
         const dim3 grid((unsigned)((mcls + CBM - 1) / CBM), p.Cout / CBN);
         hipLaunchKernelGGL(conv3d_mfma_f16_kernel, grid, dim3(256), 0, S(stream), p);
+    } else if (allow_mfma && thin_mfma && small_in && is_f16(dtype) && p.in_mode == 1 && p.Cin == 3 && p.out_mode == 0 && !p.resid && p.Cout == 32 && p.ntaps * 3 > 64 &&
+               p.ntaps * 3 <= 96) {          // the TATS first layer: 3 -> 32 channels, 27 taps (K = 81 in three k-steps, two column fragments)
+        const long nblk = (mcls + 15) / 16;
+        const unsigned wgs = (unsigned)((nblk + 3) / 4 < 2048 ? (nblk + 3) / 4 : 2048);
+        hipLaunchKernelGGL((conv3d_first_mfma_kernel<3, 3, 2>), dim3(wgs), dim3(256), 0, S(stream), p);
+    } else if (allow_mfma && thin_mfma && small_in && is_f16(dtype) && p.in_mode == 0 && (p.Cin == 32 || p.Cin == 64 || p.Cin == 128) && p.Cout <= 16 && (size_t)p.ntaps * (p.Cin / 32) * 1024 <= 96 * 1024) {
+        const size_t lds = (size_t)p.ntaps * (p.Cin / 32) * 1024;
+        static bool attr = false;
+        if (!attr) {
+            MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_last_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_last_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_last_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr = true;
+        }
+        const long nblk = (mcls + 63) / 64;
+        const unsigned wgs = (unsigned)((nblk + 3) / 4 < 1024 ? (nblk + 3) / 4 : 1024);
+        if (p.Cin == 32) hipLaunchKernelGGL(conv3d_last_mfma_kernel<1>, dim3(wgs), dim3(256), lds, S(stream), p);
+        else if (p.Cin == 64) hipLaunchKernelGGL(conv3d_last_mfma_kernel<2>, dim3(wgs), dim3(256), lds, S(stream), p);
+        else hipLaunchKernelGGL(conv3d_last_mfma_kernel<4>, dim3(wgs), dim3(256), lds, S(stream), p);
     } else if (allow_mfma && maxc && chan_ok && vlds <= 64 * 1024) {
         const dim3 grid((unsigned)((mcls + 255) / 256));
 #define VOX(T_, C_) hipLaunchKernelGGL((conv3d_voxel_kernel<T_, C_>), grid, dim3(256), vlds, S(stream), p)
@@ -637,6 +902,31 @@ extern "C" int mebt_op_codebook_argmin(const float* z, const float* embeddings, 
     if (int rc = launch_gemm(g, MEBT_F32, S(stream))) return rc;
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n_codes + 3) / 4), dim3(256), 0, S(stream), embeddings, esq, n_codes, d);
     hipLaunchKernelGGL(codebook_argmin_kernel, dim3(M), dim3(256), 0, S(stream), score, z, esq, ids, n_codes, d);
+    MEBT_HIP_CHECK(hipGetLastError());
+    return MEBT_OK;
+}
+
+// The same ids through the filtered search (see codebook_filter_kernel): approximate scores on the bf16 MFMA GEMM, exact fp32
+// re-evaluation of the candidates that can be the arg-min.  lowp: scratch of (M + n_codes) * d bf16 values (the rounded copies of
+// z and of the embeddings; the library allocates nothing); esq: scratch [n_codes + 1].  d a multiple of 64.
+extern "C" int mebt_op_codebook_argmin_filtered(const float* z, const float* embeddings, float* score, float* esq, void* lowp, int64_t* ids,
+                                                int32_t M, int32_t n_codes, int32_t d, mebt_stream_t stream) {
+    if (!z || !embeddings || !score || !esq || !lowp || !ids) { mebt_set_error("codebook: null pointer"); return MEBT_EINVAL; }
+    if (M <= 0) return MEBT_OK;
+    if (d % 64 || n_codes % 8 || d > 4096) { mebt_set_error("codebook (filtered): embedding_dim must be a multiple of 64 (<= 4096) and n_codes of 8"); return MEBT_ESHAPE; }
+    if (int rc = gemm_init_attributes()) return rc;
+    char* zb = reinterpret_cast<char*>(lowp);
+    char* eb = zb + (size_t)M * d * 2;
+    if (int rc = launch_cast_f32_to_bf16(z, zb, (size_t)M * d, S(stream))) return rc;
+    if (int rc = launch_cast_f32_to_bf16(embeddings, eb, (size_t)n_codes * d, S(stream))) return rc;
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.A = zb; g.B = eb; g.C = score; g.M = M; g.N = n_codes; g.K = d; g.lda = d; g.ldb = d; g.ldc = n_codes;
+    g.a_kc = 1; g.b_kc = 1; g.c_f32 = 1; g.split_k = 1;
+    if (int rc = launch_gemm(g, MEBT_BF16, S(stream))) return rc;
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n_codes + 3) / 4), dim3(256), 0, S(stream), embeddings, esq, n_codes, d);
+    hipLaunchKernelGGL(vec_max_sqrt_kernel, dim3(1), dim3(256), 0, S(stream), esq, esq + n_codes, n_codes);
+    hipLaunchKernelGGL(codebook_filter_kernel, dim3(M), dim3(256), (size_t)d * 4 + CB_CAP * 4, S(stream), score, z, embeddings, esq, esq + n_codes, ids, n_codes, d);
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;
 }

@@ -14,6 +14,8 @@ channels-last on the GPU; `compute_dtype` = "f16" (MFMA, BASELINE config 5) or "
 import ctypes as C
 import math
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -330,10 +332,18 @@ class VQGAN(nn.Module):
         M = B * int(np.prod(dims))
         emb = self._prepared["emb"]
         score = torch.empty(M, self.n_codes, device=x.device, dtype=torch.float32)
-        esq = torch.empty(self.n_codes, device=x.device, dtype=torch.float32)
+        esq = torch.empty(self.n_codes + 1, device=x.device, dtype=torch.float32)
         ids = torch.empty(M, device=x.device, dtype=torch.long)
-        check(_lib.load().mebt_op_codebook_argmin(ptr(z), ptr(emb), ptr(score), ptr(esq), ptr(ids), M, self.n_codes, self.embedding_dim,
-                                                  cur_stream()))
+        # large searches (config 5 at batch 16: 16384 x 16384 x 256): approximate scores on the bf16 MFMA GEMM + exact fp32 re-evaluation
+        # of every code that can still be the arg-min (csrc/vqgan.hip codebook_filter_kernel); small ones: the exact fp32 GEMM directly
+        if (self.use_mfma and self.embedding_dim % 64 == 0 and self.n_codes % 8 == 0 and M * self.n_codes >= (1 << 24)
+                and os.environ.get("MEBT_CODEBOOK_FILTER", "1") != "0"):
+            lowp = torch.empty((M + self.n_codes) * self.embedding_dim, device=x.device, dtype=torch.bfloat16)
+            check(_lib.load().mebt_op_codebook_argmin_filtered(ptr(z), ptr(emb), ptr(score), ptr(esq), ptr(lowp), ptr(ids), M, self.n_codes,
+                                                               self.embedding_dim, cur_stream()))
+        else:
+            check(_lib.load().mebt_op_codebook_argmin(ptr(z), ptr(emb), ptr(score), ptr(esq), ptr(ids), M, self.n_codes, self.embedding_dim,
+                                                      cur_stream()))
         self._last_z = z
         ids = ids.view(B, *dims)
         if include_embeddings:

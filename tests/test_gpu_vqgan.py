@@ -126,6 +126,52 @@ def test_codebook_argmin_operator():
     assert int(ids[0]) == 5
 
 
+@pytest.mark.parametrize("case", ["random", "near_ties", "clustered", "degenerate"])
+def test_codebook_filtered_search_equals_the_exact_search(case):
+    """mebt_op_codebook_argmin_filtered (approximate scores on the bf16 MFMA GEMM, exact fp32 re-evaluation of every code inside the
+    rounding bound) returns the SAME ids as the exact-fp32 search on the config-5 codebook geometry (16384 codes x 256): random
+    data; codes planted within 1e-6 .. 1e-3 of a query's nearest code (bf16 cannot tell them apart: the re-evaluation must); a
+    clustered codebook (hundreds of candidates per row); a degenerate one (every code equal: more candidates than the list holds,
+    every code is re-evaluated, the first index wins).  Reference semantics: codebook.py:52-58."""
+    from mebt_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    M, n_codes, d = 1536, 16384, 256
+    z, e = torch.randn(M, d, generator=g), torch.randn(n_codes, d, generator=g)
+    if case == "near_ties":
+        for i, eps in enumerate((1e-6, 1e-5, 1e-4, 1e-3, 0.0)):
+            e[100 + i] = z[i] + 0.05 * torch.randn(d, generator=g)               # the nearest code of query i
+            e[9000 + i] = e[100 + i] + eps * torch.randn(d, generator=g)         # ... and a near-duplicate of it further down the list
+    elif case == "clustered":
+        centre = torch.randn(1, d, generator=g)
+        e = centre + 0.01 * torch.randn(n_codes, d, generator=g)
+        z = centre + 0.3 * torch.randn(M, d, generator=g)
+    elif case == "degenerate":
+        e = e[:1].repeat(n_codes, 1).contiguous()
+    zd, ed = z.to(DEV), e.to(DEV)
+    score = torch.empty(M, n_codes, device=DEV)
+    esq = torch.empty(n_codes + 1, device=DEV)
+    ids_x, ids_f = torch.empty(M, dtype=torch.long, device=DEV), torch.empty(M, dtype=torch.long, device=DEV)
+    lowp = torch.empty((M + n_codes) * d, dtype=torch.bfloat16, device=DEV)
+    lib = _lib.load()
+    _lib.check(lib.mebt_op_codebook_argmin(_lib.ptr(zd), _lib.ptr(ed), _lib.ptr(score), _lib.ptr(esq), _lib.ptr(ids_x), M, n_codes, d, _lib.cur_stream()))
+    _lib.check(lib.mebt_op_codebook_argmin_filtered(_lib.ptr(zd), _lib.ptr(ed), _lib.ptr(score), _lib.ptr(esq), _lib.ptr(lowp), _lib.ptr(ids_f), M, n_codes, d,
+                                                    _lib.cur_stream()))
+    torch.cuda.synchronize()
+    a, b = ids_x.cpu(), ids_f.cpu()
+    if case == "degenerate":
+        assert int(b.max()) == 0 and int(a.max()) == 0
+        return
+    mism = (a != b).nonzero().flatten().tolist()
+    # the two paths sum z . e in the same k order; a difference could only be an exact-fp32 tie broken differently
+    dist = ((z ** 2).sum(1, keepdim=True) - 2 * z.double() @ e.double().t() + (e.double() ** 2).sum(1)[None]).float()
+    for r in mism:
+        assert abs(float(dist[r, a[r]] - dist[r, b[r]])) < 1e-4 * float(dist[r].abs().max()), (case, r, int(a[r]), int(b[r]))
+    assert len(mism) <= 2, (case, len(mism))
+    if case == "near_ties":
+        assert [int(v) for v in b[:5]] == [int(v) for v in a[:5]] and all(int(v) in (100 + i, 9000 + i) for i, v in enumerate(b[:5]))
+
+
+
 @pytest.mark.parametrize("name", ["vq_micro", "vq_c5"])
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 def test_vqgan_encode_decode_vs_reference_golden(name, dtype):

@@ -10,7 +10,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 torch.manual_seed(0)
 m = VQGAN(presets.vqgan_args()).cuda().eval()
 vid = torch.rand(B, 3, 16, 128, 128, device="cuda") - 0.5
-for dtype in ("f16", "f32"):
+for dtype in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("f16", "f32")):
     m.compute_dtype = dtype
     ids = m.encode(vid)
     rec = m.decode(ids)
