@@ -243,6 +243,9 @@ int32_t mebt_gemm_autotune_enabled(void);      /* the current mode */
  * (mebt_amd/tune/gfx950.txt) merged with overwrite = 0 at load time, so a fresh process does not stall on in-situ tuning. */
 int64_t mebt_gemm_tune_export(char* buf, int64_t cap);
 int32_t mebt_gemm_tune_import(const char* text, int32_t overwrite);
+/* diagnostics: the fastest few candidates (value, isolated microseconds) of every signature this process tuned, one line each
+ * (`n k.. : v us v us ...`); tools/step_tune.py tries them inside the train step.  Same size protocol as mebt_gemm_tune_export. */
+int64_t mebt_gemm_tune_alternatives(char* buf, int64_t cap);
 
 /* ---- 3D-VQGAN first stage (reference mebt/vqgan.py:82-93,255-424, modules/codebook.py:52-62) ------------
  * Activations are channels-last [B, T, H, W, C] of `dtype` (MEBT_DTYPE_F16: MFMA fast mode, MEBT_DTYPE_F32: parity mode); the

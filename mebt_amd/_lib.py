@@ -87,6 +87,7 @@ PROTOTYPES = {
     "mebt_gemm_autotune_enabled": (c_i32, []),
     "mebt_gemm_tune_export": (c_i64, [C.c_char_p, c_i64]),
     "mebt_gemm_tune_import": (c_i32, [C.c_char_p, c_i32]),
+    "mebt_gemm_tune_alternatives": (c_i64, [C.c_char_p, c_i64]),
     "mebt_profile_enable": (c_i32, [c_i32]),
     "mebt_profile_read": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

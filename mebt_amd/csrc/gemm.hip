@@ -151,6 +151,14 @@ static int launch_bf16_splitk(const GemmParams& p, int tbm, int tbn, int ring, i
 typedef std::vector<int> TuneKey;
 static int tune_bucket(int v) { return v <= 128 ? v : ((v + 127) / 128) * 128; }
 static std::map<TuneKey, int> g_tuned;      // -> (tbm << 20) | (tbn << 8) | staging
+// the fastest few candidates of every signature tuned in this process, with their isolated (cold) times: what tools/step_tune.py
+// tries one by one IN the train step (a candidate that is second in isolation can be first between its real neighbours)
+static std::map<TuneKey, std::vector<std::pair<int, float>>> g_alts;
+static void alts_keep(const TuneKey& key, std::vector<std::pair<int, float>> v) {
+    std::sort(v.begin(), v.end(), [](const std::pair<int, float>& a, const std::pair<int, float>& b) { return a.second < b.second; });
+    if (v.size() > 4) v.resize(4);
+    g_alts[key] = v;
+}
 static std::mutex g_tune_mutex;
 static int g_autotune = -1, g_tune_log = 0;
 static const char* g_tune_cache = nullptr;                       // MEBT_GEMM_TUNE_CACHE: text file of tuned choices
@@ -241,6 +249,23 @@ extern "C" int64_t mebt_gemm_tune_export(char* buf, int64_t cap) {
     if (buf && cap >= need) memcpy(buf, text.c_str(), (size_t)need);
     return need;
 }
+// The runner-up candidates of the signatures THIS process tuned: one line per signature, `n k_0 .. k_{n-1} : v us v us ...` (fastest
+// first, at most four; v as in the table).  Diagnostics for tools/step_tune.py; same size protocol as mebt_gemm_tune_export.
+extern "C" int64_t mebt_gemm_tune_alternatives(char* buf, int64_t cap) {
+    std::lock_guard<std::mutex> lk(g_tune_mutex);
+    std::string text;
+    char tmp[64];
+    for (auto& e : g_alts) {
+        text += std::to_string(e.first.size());
+        for (int x : e.first) { text += ' '; text += std::to_string(x); }
+        text += " :";
+        for (auto& a : e.second) { snprintf(tmp, sizeof tmp, " %d %.2f", a.first, a.second * 1e3f); text += tmp; }
+        text += '\n';
+    }
+    const int64_t need = (int64_t)text.size() + 1;
+    if (buf && cap >= need) memcpy(buf, text.c_str(), (size_t)need);
+    return need;
+}
 // Merge a text table: overwrite = 1 replaces entries this process already holds, 2 drops the whole table first (a data-parallel
 // rank adopting rank 0's table: identical tables afterwards), 0 keeps them (a shipped default table never overrides what was
 // tuned here or loaded from MEBT_GEMM_TUNE_CACHE).  Returns the number of entries taken
@@ -307,7 +332,7 @@ static int time_cold(F&& launch, hipStream_t stream, const TuneRun& tr, float& b
     return MEBT_OK;
 }
 
-static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, int& tbn, int& staging) {
+static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, int& tbn, int& staging, std::vector<std::pair<int, float>>* alts = nullptr) {
     TuneRun tr;
     if (int rc = tr.begin(scratch_of(p.scratch))) return rc;
     static const int tiles[7][2] = {{192, 128}, {128, 128}, {96, 128}, {128, 64}, {64, 128}, {96, 64}, {64, 64}};
@@ -397,6 +422,8 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
             if (k.ms < best) { best = k.ms; tbm = k.bm; tbn = k.bn; staging = k.staging; }
         }
     }
+    if (alts)
+        for (int c = 0; c < finalists; ++c) alts->emplace_back((cands[c].bm << 20) | (cands[c].bn << 8) | cands[c].staging, cands[c].ms);
     if (g_tune_log)
         fprintf(stderr, "[mebt gemm autotune] M=%d N=%d K=%d a_kc=%d b_kc=%d epi=%d c_f32=%d -> %dx%d ring %d%s (%.1f us cold)\n", p.M, p.N, p.K,
                 p.a_kc, p.b_kc, p.epilogue, p.c_f32, tbm, tbn, (tbm == 256 && staging == 9) ? 2 : (staging >= 8 && staging < 16) ? staging - 8 : (staging & 15),
@@ -445,7 +472,9 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
             auto it = g_tuned.find(key);
             if (it == g_tuned.end() && g_autotune && idempotent && tune_scratch_of(p.scratch)) {
                 heuristic_config(p, tbm, tbn, staging);
-                if (int rc = autotune_config(p, stream, tbm, tbn, staging)) return rc;
+                std::vector<std::pair<int, float>> alts;
+                if (int rc = autotune_config(p, stream, tbm, tbn, staging, &alts)) return rc;
+                alts_keep(key, alts);
                 it = g_tuned.emplace(key, (tbm << 20) | (tbn << 8) | staging).first;
                 tune_remember(key, it->second);
             }
@@ -507,11 +536,13 @@ int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipS
             lk.unlock();            // the separate-launch baseline below goes through launch_gemm, which takes the lock itself
             static const int tiles[7][2] = {{192, 128}, {128, 128}, {96, 128}, {128, 64}, {64, 128}, {96, 64}, {64, 64}};
             float best = 1e30f;
+            std::vector<std::pair<int, float>> alts;
             for (int t = 0; t < 7; ++t)
                 for (int st = 2; st <= 4; ++st) {
                     if (st * (tiles[t][0] + tiles[t][1]) * BK * 2 > 128 * 1024) continue;
                     float ms = 0.f;
                     if (int rc = time_cold([&] { launch_pair_config(g, tiles[t][0], tiles[t][1], st, stream); }, stream, tr, ms)) return rc;
+                    alts.emplace_back((tiles[t][0] << 20) | (tiles[t][1] << 8) | st, ms);
                     if (ms < best) { best = ms; tbm = tiles[t][0]; tbn = tiles[t][1]; staging = st; }
                 }
             // ... against the two products launched one after the other with their own tuned configurations
@@ -522,6 +553,8 @@ int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipS
                 fprintf(stderr, "[mebt gemm autotune] pair %dx%dx%d + %dx%dx%d b_kc=%d -> %dx%d ring %d (%.1f us cold; separate launches %.1f us)\n",
                         p0.M, p0.N, p0.K, p1.M, p1.N, p1.K, p0.b_kc, tbm, tbn, staging, best * 1e3f, sep * 1e3f);
             lk.lock();
+            alts.emplace_back(0, sep);                 // value 0 = the two products launched separately
+            alts_keep(key, alts);
             it = g_tuned.emplace(key, sep <= best ? 0 : ((tbm << 20) | (tbn << 8) | staging)).first;
             tune_remember(key, it->second);
         }
@@ -568,10 +601,12 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
             GroupedWgrad tc = c;
             for (int i = 0; i < n; ++i) tc.g[i].bias = nullptr;      // the bias row sums are atomic adds: not in the repeated candidate runs
             if (tc.fused) { tc.opt.lr = 0.f; tc.opt.weight_decay = 0.f; tc.opt.beta1 = 1.f; tc.opt.beta2 = 1.f; }
+            std::vector<std::pair<int, float>> alts;
             for (int t = 0; t < 4; ++t)
                 for (int st = 2; st <= 4; ++st) {
                     float ms = 0.f;
                     if (int rc = time_cold([&] { launch_grouped_config(tc, tiles[t][0], tiles[t][1], st, stream); }, stream, tr, ms)) return rc;
+                    alts.emplace_back((tiles[t][0] << 20) | (tiles[t][1] << 8) | st, ms);
                     if (g_tune_log >= 2) fprintf(stderr, "    cand grouped %dx%d ring %d%s%s: %.1f us\n", tiles[t][0], tiles[t][1], st, tc.fused ? " +adamw" : "", tc.Cb ? " bf16-out" : "", ms * 1e3f);
                     if (ms < best) { best = ms; tbm = tiles[t][0]; tbn = tiles[t][1]; stages = st; }
                 }
@@ -580,6 +615,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
                 for (int i = 0; i < n; ++i) fprintf(stderr, " %dx%dx%d", c.g[i].M, c.g[i].N, c.g[i].K);
                 fprintf(stderr, " -> %dx%d ring %d (%.1f us cold)\n", tbm, tbn, stages, best * 1e3f);
             }
+            alts_keep(key, alts);
             it = g_tuned.emplace(key, (tbm << 20) | (tbn << 8) | stages).first;
             tune_remember(key, it->second);
         }
