@@ -165,12 +165,19 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // The 4-wave form exists for the routings whose 128-row grid does not fill the chip (NQ = 256 latents: 2 x heads x batch
 // workgroups — 128 at config 4, 192 at config 2): the kernel is bound by vector issue (softmax), two waves of one workgroup share
 // a SIMD, so the same waves spread over twice the CUs run up to twice as fast; NST = ring depth (stages of K + V).
-template <int NW, int NST>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// SPLIT = 2 (long key sets on a grid that still leaves SIMD slots idle: config 4's 7936 keys for 256 latent queries at batch 4): TWO
+// groups of NW waves work on the SAME 16 NW query rows, group s on the key chunks s, s + 2, s + 4, ... with a ring of its own, and the
+// groups' (m, l, O) are merged through LDS at the end — twice the waves per query row without a second kernel or partial results
+// in HBM.  The groups run in lock step (the workgroup barrier is shared): a group without a chunk in an iteration only keeps the
+// barrier count.
+template <int NW, int NST, int SPLIT = 1>
+__global__ __launch_bounds__(NW * SPLIT * 64) void attn_fwd_mfma(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
     constexpr int CT = NW / 2, CROWS = CT * TILE, CBYTES = CT * TILE_BYTES, SBYTES = 2 * CBYTES;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = SPLIT == 1 ? 0 : wave_all / NW, wave = SPLIT == 1 ? wave_all : wave_all % NW;
+    char* smem = smem_all + half * (NST * SBYTES);
     const int b = blockIdx.z, h = blockIdx.y;
     const int q = blockIdx.x * (NW * 16) + wave * 16 + (lane & 15);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (size_t)b * p.NQ * p.ldq + h * 64;
@@ -182,12 +189,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const AttnParams p) {
     ChunkDma<NW> lk, lv;
     lk.init(K, p.NK, p.ldk, wave, lane);
     lv.init(V, p.NK, p.ldv, wave, lane);
-    const int nchunks = (p.NK + CROWS - 1) / CROWS;
+    const int nchunks_all = (p.NK + CROWS - 1) / CROWS;
+    const int nchunks = SPLIT == 1 ? nchunks_all : (nchunks_all - half + SPLIT - 1) / SPLIT;      // this group's chunks: half, half + SPLIT, ...
+    const int niter = (nchunks_all + SPLIT - 1) / SPLIT;                                            // barrier rounds of the workgroup
 #pragma unroll
     for (int a = 0; a < NST; ++a)
         if (a < nchunks) {
-            lk.issue(smem + a * SBYTES, a, wave);
-            lv.issue(smem + a * SBYTES + CBYTES, a, wave);
+            lk.issue(smem + a * SBYTES, a * SPLIT + half, wave);
+            lv.issue(smem + a * SBYTES + CBYTES, a * SPLIT + half, wave);
         }
     const float c = 0.125f * LOG2E;     // 1/sqrt(64) folded with log2(e)
     const int mtiles = mebt_attn_dmask_tiles(p.NK);
@@ -200,16 +209,18 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const AttnParams p) {
     float m = -INFINITY, l = 0.f;
 
     int st = 0;
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int it = 0; it < niter; ++it) {
+        const int ci = it;                       // index among this group's chunks
+        const int ch = it * SPLIT + half;        // chunk of the key set
         char* stage = smem + st * SBYTES;
         // this wave's pieces of chunk ch have landed; the (up to NST - 1) younger chunks may stay in flight
-        const int younger = min(NST - 1, nchunks - 1 - ch);
+        const int younger = min(NST - 1, nchunks - 1 - ci);
         if (younger <= 0) wait_vm<0>();
         else if (younger == 1) wait_vm<DMA_PER_WAVE>();
         else if (younger == 2) wait_vm<2 * DMA_PER_WAVE>();
         else wait_vm<3 * DMA_PER_WAVE>();
         __builtin_amdgcn_s_barrier();                                          // ... and everybody else's
-        const int nt = min(CT, (p.NK - ch * CROWS + TILE - 1) / TILE);
+        const int nt = ci < nchunks ? min(CT, (p.NK - ch * CROWS + TILE - 1) / TILE) : 0;
         // TWO 64-key tiles per pass: their 16 score MFMAs are independent, and the softmax pays ONE maximum / sum exchange across
         // the lane groups, one rescale decision and one dependent chain per 128 keys instead of per 64 (the per-tile chain — reads,
         // 8 MFMAs, max, exchange, 16 exp, exchange, reads, 8 MFMAs — ran strictly in sequence: ~2000 cycles per tile and wave for
@@ -291,12 +302,36 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma(const AttnParams p) {
                     for (int e = 0; e < 4; ++e) o[e] = MFMA(fo.col_frag(sV + u * TILE_BYTES, e, kk), pf, o[e]);
                 }
         }
-        if (ch + NST < nchunks) {
+        if (SPLIT == 1 ? ci + NST < nchunks : it + NST < niter) {      // SPLIT: both groups keep the same barrier count
             __builtin_amdgcn_s_barrier();                     // every wave is done reading this stage
-            lk.issue(stage, ch + NST, wave);
-            lv.issue(stage + CBYTES, ch + NST, wave);
+            if (ci + NST < nchunks) {
+                lk.issue(stage, (ci + NST) * SPLIT + half, wave);
+                lv.issue(stage + CBYTES, (ci + NST) * SPLIT + half, wave);
+            }
         }
         if (++st == NST) st = 0;
+    }
+    if (SPLIT > 1) {                             // merge the groups: group 1 parks (m, l, O) in LDS, group 0 combines
+        __syncthreads();                         // both rings are idle
+        float* mg = reinterpret_cast<float*>(smem_all) + (size_t)(wave * 64 + lane) * 18;
+        if (half == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mg[4 * e + r] = o[e][r];
+            mg[16] = m; mg[17] = l;
+        }
+        __syncthreads();
+        if (half == 1) return;
+        const float m1 = mg[16], l1 = mg[17];
+        const float mn = fmaxf(m, m1);
+        const float a0 = m == mn ? 1.f : fast_exp2(m - mn), a1 = m1 == mn ? 1.f : fast_exp2(m1 - mn);    // -inf == -inf cannot occur: NK > 0
+        l = l * a0 + l1 * a1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[e][r] = o[e][r] * a0 + mg[4 * e + r] * a1;
+        m = mn;
     }
     if (q < p.NQ) {
         const float inv = 1.0f / l;
@@ -572,6 +607,7 @@ static int check_layout(const AttnParams& p) {
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CHUNK_BYTES));
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CHUNK_BYTES));
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * CHUNK_BYTES));
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * CHUNK_BYTES));
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS));
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS));
         inited = true;
@@ -595,7 +631,10 @@ int launch_attn_fwd_mfma(const AttnParams& p_in, hipStream_t stream) {
     if (four) {
         const dim3 grid((p.NQ + 63) / 64, p.H, p.B);
         // short key sets: two stages of 128 keys (64 KiB: two workgroups per CU); long ones: four stages, one workgroup per CU
+        static const int split_on = [] { const char* e = getenv("MEBT_ATTN_FWD_SPLIT"); return e ? atoi(e) : 1; }();
         if (p.NK <= 1024) hipLaunchKernelGGL((attn_fwd_mfma<4, 2>), grid, dim3(256), 2 * CHUNK_BYTES, stream, p);
+        else if (split_on && (long)grid.x * p.H * p.B <= 256)      // one workgroup per CU at most: a second group of waves per query block
+            hipLaunchKernelGGL((attn_fwd_mfma<4, 2, 2>), grid, dim3(512), 4 * CHUNK_BYTES, stream, p);
         else hipLaunchKernelGGL((attn_fwd_mfma<4, 4>), grid, dim3(256), 4 * CHUNK_BYTES, stream, p);
     } else {
         const dim3 grid((p.NQ + BLOCK_ROWS - 1) / BLOCK_ROWS, p.H, p.B);
