@@ -524,20 +524,35 @@ def test_c2_ragged_shapes_bf16_engine_vs_fp32_engine(B, t):
 
 def _replay_steps_prove_ties(m, steps, stream, temperature, max_ties=3, top_k=None):
     """`got != ref` after a sampling loop: replay every recorded step of the ORACLE on the HIP path from the oracle's own state —
-    logits within 1e-3, and sampled ids different only where the oracle's two best keys p / q are within 5e-4 (an fp tie that
-    1e-5 logit differences may flip, after which the two runs legitimately diverge)."""
+    logits within 1e-3, and sampled ids different only where the oracle's own numbers say a logit difference of the measured
+    size may flip the draw, after which the two runs legitimately diverge:
+      * the oracle's two best keys p / q are within 5e-4 (an fp tie), or
+      * with top-k: the oracle's k-th and (k+1)-th logits of that row are closer than twice this step's measured
+        max |logits_hip - logits_oracle|, so the two paths keep different 32-sets and one of the two draws is the element
+        the other dropped (torch.topk boundary, modules/gpt.py:233-238)."""
     from mebt_amd.transformer import sample_from_logits_scored
     n_tie = 0
     for s in steps:
         lg, _ = m.reconstruct_mask(s["partial"].to(DEV), s["c"].to(DEV), s["t"].to(DEV))
-        assert (lg.cpu() - s["logits"]).abs().max().item() < 1e-3
+        d_lg = (lg.cpu() - s["logits"]).abs().max().item()
+        assert d_lg < 1e-3
         nz = stream(s["noise_k"], "exp", tuple(s["logits"].shape))
         T_, k_ = (1.0, None) if s.get("boot") else (temperature, top_k)       # the bootstrap phase samples at T = 1 without top-k (:41-42)
         ids, _, _ = sample_from_logits_scored(lg, T_, k_, None, nz.to(DEV))
         oid, oprobs = orc.sample_from_logits(s["logits"], T_, k_, None, nz)
-        for b, j in (ids.cpu() != oid).nonzero().tolist():
+        ids = ids.cpu()
+        for b, j in (ids != oid).nonzero().tolist():
             top2 = (oprobs[b, j].double() / nz[b, j].double()).topk(2).values     # the oracle's own keys p / q after temperature / top-k
-            assert top2[0] / top2[1] < 1 + 5e-4, ("not a tie", b, j, float(top2[0] / top2[1]))
+            if top2[0] / top2[1] < 1 + 5e-4:
+                n_tie += 1
+                continue
+            assert k_, ("not a tie", b, j, float(top2[0] / top2[1]))
+            kth = s["logits"][b, j].topk(k_ + 1).values
+            gap = float(kth[k_ - 1] - kth[k_])
+            edge = {int(i) for i in (s["logits"][b, j] >= kth[k_] - 2 * d_lg).nonzero().flatten().tolist()
+                    if float(s["logits"][b, j, i]) <= float(kth[k_ - 1]) + 2 * d_lg}       # elements either path may put on the other side of the cut
+            assert gap <= 2 * d_lg and (int(ids[b, j]) in edge or int(oid[b, j]) in edge), \
+                ("neither a key tie nor a top-k boundary", b, j, float(top2[0] / top2[1]), gap, d_lg)
             n_tie += 1
     assert 0 < n_tie <= max_ties, n_tie        # a difference must be explained by at least one flipped tie, and ties are rare
     return n_tie
