@@ -151,12 +151,20 @@ class LightningModuleShim(nn.Module):
         self.trainer = _TrainerState()
         self.logged = {}
         self.hparams = {}
+        self.logger = None                 # anything with `.experiment.add_video(tag, vid, step, fps=)` / `.experiment.flush()` (VideoLogger below)
 
     def save_hyperparameters(self, *args, **kwargs):
         self.hparams.update(kwargs)
 
     def log(self, name, value, **kwargs):
         self.logged[name] = value
+
+    # Lightning's loop hooks the reference overrides (transformer.py:332-351); the launcher calls them at the same places
+    def on_train_epoch_start(self):
+        pass
+
+    def on_validation_epoch_start(self):
+        pass
 
     @property
     def device(self):
@@ -194,3 +202,33 @@ class LightningModuleShim(nn.Module):
         model.current_epoch = int(ckpt.get("epoch", 0))
         model.trainer.global_step = model.global_step
         return model
+
+
+class VideoLogger:
+    """The slice of Lightning's TensorBoardLogger the reference module touches (`self.logger.experiment.add_video(...)`,
+    `.flush()`, transformer.py:349-350) without TensorBoard: videos `[N, T, C, H, W]` in [0, 1] are written as uint8 `.npy` files
+    `<dir>/<tag>_<step>.npy`, scalars appended to `<dir>/scalars.tsv`."""
+
+    def __init__(self, log_dir):
+        import os
+        self.log_dir = log_dir
+        os.makedirs(log_dir, exist_ok=True)
+        self.experiment = self
+        self.videos = []
+
+    def add_video(self, tag, vid_tensor, global_step=None, fps=4):
+        import os
+        import numpy as np
+        arr = (vid_tensor.detach().float().clamp(0, 1) * 255.0).round().to(torch.uint8).cpu().numpy()
+        path = os.path.join(self.log_dir, f"{tag.replace('/', '_')}_{int(global_step or 0):06d}.npy")
+        np.save(path, arr)
+        self.videos.append((tag, path, int(global_step or 0), fps))
+
+    def add_scalar(self, tag, value, global_step=None):
+        import os
+        with open(os.path.join(self.log_dir, "scalars.tsv"), "a") as f:
+            f.write(f"{tag}\t{int(global_step or 0)}\t{float(value):.8g}\n")
+
+    def flush(self):
+        pass
+

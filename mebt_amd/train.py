@@ -183,6 +183,14 @@ def main():
         if batch is None:
             epoch += 1
             if args.check_val_every_n_epoch and epoch % args.check_val_every_n_epoch == 0:
+                model.current_epoch = epoch - 1            # Lightning counts the epoch that just ended from 0
+                if rank == 0:                              # sample -> decode -> logger video every vis_epoch epochs (transformer.py:336-351)
+                    if model.logger is None and model.first_stage_model is not None:
+                        from .lightning_shim import VideoLogger
+                        model.logger = VideoLogger(os.path.join(args.default_root_dir, "videos"))
+                    rng = (random.getstate(), np.random.get_state(), torch.get_rng_state())     # the visualisation draws on rank 0 only:
+                    model.on_validation_epoch_start()                                            # keep the ranks' host RNG streams aligned
+                    random.setstate(rng[0]); np.random.set_state(rng[1]); torch.set_rng_state(rng[2])
                 vloss, v1, v5, nb = validate()
                 if rank == 0:
                     print(f"epoch {epoch}: val/loss {vloss:.4f} acc1 {v1:.2f} acc5 {v5:.2f} ({nb} batches)", flush=True)

@@ -492,6 +492,43 @@ class Net2NetTransformer(LightningModuleShim):
         acc5 = (stats[2] * (100.0 / n)).to(torch.float32)
         return acc1, acc5, loss, ratio
 
+    def on_train_epoch_start(self):
+        epo = self.current_epoch           # reference :332-334 (reads the epoch, changes nothing)
+        return None
+
+    def on_validation_epoch_start(self):
+        """Every `vis_epoch` epochs: four clips sampled from an all-masked grid (32 MaskGIT steps, cosine schedule, context
+        temperature 6.0), decoded by the first stage and handed to the logger as `[4, T, C, H, W]` in [0, 1] (reference
+        :336-351).  The reference dereferences `self.first_stage_model` / `self.logger` unconditionally and so dies here in a
+        `vtokens` run without a first stage; this mirror skips the visualisation in that case (warning once)."""
+        if (self.current_epoch + 1) % self.vis_epoch != 0:
+            return
+        if self.first_stage_model is None or self.logger is None:
+            if not getattr(self, "_vis_warned", False):
+                import warnings
+                warnings.warn("on_validation_epoch_start: no first stage / logger attached, sample visualisation skipped")
+                self._vis_warned = True
+            return
+        import copy
+        orig_schedule = copy.deepcopy(self.mask_sampler.schedule)
+        self.mask_sampler.schedule = 'cosine'
+        was_training = self.transformer.training
+        self.transformer.eval()
+        try:
+            shape = (4, *self.mask_sampler.shape)
+            x = torch.zeros(shape, dtype=torch.long, device=self.device)
+            with torch.no_grad():
+                x = self.sample(x, None, 1.0, None, None, 32, None, None, context_temperature=6.0, skips=False)[0]
+                code_map = x.reshape(*shape)
+                img_x = [self.first_stage_model.decode(code_map[i:i + 1]) for i in range(code_map.shape[0])]
+            img_x = torch.cat(img_x, 0).clamp(-0.5, 0.5) + 0.5
+            img_x = img_x.permute(0, 2, 1, 3, 4)
+            self.logger.experiment.add_video('sample', img_x, self.current_epoch, fps=20)
+            self.logger.experiment.flush()
+        finally:
+            self.mask_sampler.schedule = orig_schedule
+            self.transformer.train(was_training)
+
     def training_step(self, batch, batch_idx):
         acc1, acc5, loss, ratio = self.shared_step(batch, batch_idx)
         self.log("train/loss", loss, prog_bar=True, logger=True, on_step=True, on_epoch=True, sync_dist=True)

