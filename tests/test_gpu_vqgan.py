@@ -314,7 +314,7 @@ def test_validation_epoch_hook_samples_decodes_and_logs_a_video(tmp_path):
         x = model.sample(torch.zeros(4, 2, 4, 4, dtype=torch.long, device=DEV), None, 1.0, None, None, 32, None, None,
                          context_temperature=6.0, skips=False)[0].reshape(4, 2, 4, 4)
         ref = torch.cat([vqm.decode(x[i:i + 1]) for i in range(4)], 0).clamp(-0.5, 0.5) + 0.5
-    assert torch.equal(vid, ref.permute(0, 2, 1, 3, 4))
+    assert (vid - ref.permute(0, 2, 1, 3, 4)).abs().max().item() < 1e-5        # GroupNorm statistics are summed with float atomics: not bitwise run to run
     # the file logger the launcher attaches
     model.mask_sampler.schedule = "linear"
     model.logger = VideoLogger(str(tmp_path))
