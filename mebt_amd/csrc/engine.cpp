@@ -69,7 +69,6 @@ struct FwdCtx {
     int last_bwd_lo = -1;      // lowest block the previous mebt_backward_layers call finished (doutm_ready is only valid for a contiguous descent)
     bool drop_on = false; uint64_t drop_seed = 0;
     GemmScratch tune = {nullptr, 0, nullptr, 0};     // GEMM tuner / split-K scratch, carved from the caller's workspace (bf16 mode)
-    GemmScratch tune_side = {nullptr, 0, nullptr, 0};   // the same flush buffer without the split-K slabs (side-stream products)
 };
 
 }  // namespace
@@ -98,12 +97,6 @@ struct mebt_model {
     hipEvent_t ev_fork = nullptr, ev_e1 = nullptr, ev_layer[2] = {nullptr, nullptr}, ev_join = nullptr;
     bool use_side = true;
     hipStream_t side_own = nullptr;      // the stream this object created (destroyed with it); `side` may point at a caller's stream instead
-    // forward, 'latent_enc' blocks: key = contexts (gpt.py:167-169), which no block rewrites unless the model has 'maskgit' blocks — so
-    // LN1(contexts) and the K/V projection of EVERY such block depend on the embedding only, not on the latent chain.  When the key side
-    // is much larger than the query side (config 4 revise: 31 744 context rows against 1 024 latent rows) they run ahead on the side
-    // stream, beside the chain's latency-bound M = B x 256 launches; the chain waits for block i's event right before its attention.
-    std::vector<hipEvent_t> ev_kv;
-    int kv_ahead_mode = -1;              // MEBT_KV_AHEAD: 0 never, 1 whenever the routing allows it, -1 (default) by the row-count rule
     // optimizer-in-backward (mebt_model_set_fused_adamw): when armed, the weight gradients of the blocks are applied
     // to W (AdamW) inside the weight-gradient launch instead of being stored in gW
     bool fused_on = false;
@@ -140,15 +133,14 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-static int gemm(const mebt_model* m, GemmParams p, hipStream_t st, bool on_side = false) {
+static int gemm(const mebt_model* m, GemmParams p, hipStream_t st) {
     if (p.K <= 0) {   // empty reduction (e.g. NC = 0): the product is zero
         if (p.c_f32 && !p.beta && p.M > 0 && p.N > 0 && p.epilogue == EPI_NONE && !p.bias)
             MEBT_HIP_CHECK(hipMemset2DAsync(p.C, (size_t)p.ldc * 4, 0, (size_t)p.N * 4, p.M, st));
         else if (p.M > 0 && p.N > 0) { mebt_set_error("gemm: K = 0 with a fused epilogue is not supported"); return MEBT_ESHAPE; }
         return MEBT_OK;
     }
-    // a product that runs beside the main stream's must not share its split-K slabs
-    p.scratch = m->ctx.tune.flush ? (on_side ? &m->ctx.tune_side : &m->ctx.tune) : nullptr;
+    p.scratch = m->ctx.tune.flush ? &m->ctx.tune : nullptr;
     ProfRec r;
     const bool prof = g_prof_on && p.M > 0 && p.N > 0;
     if (prof) {
@@ -280,11 +272,7 @@ extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) 
     if (m->side) {
         hipEvent_t* evs[] = {&m->ev_fork, &m->ev_e1, &m->ev_layer[0], &m->ev_layer[1], &m->ev_join};
         for (hipEvent_t* e : evs) MEBT_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        m->ev_kv.assign(d.n_layer, nullptr);
-        for (int i = 0; i < d.n_layer; ++i)
-            if (d.modes[i] == MEBT_MODE_LATENT_ENC) MEBT_HIP_CHECK(hipEventCreateWithFlags(&m->ev_kv[i], hipEventDisableTiming));
     }
-    if (const char* e = getenv("MEBT_KV_AHEAD")) m->kv_ahead_mode = atoi(e);
     *out = m;
     return MEBT_OK;
 }
@@ -295,7 +283,6 @@ extern "C" void mebt_model_destroy(mebt_model* m) {
         (void)hipStreamSynchronize(m->side);
         hipEvent_t evs[] = {m->ev_fork, m->ev_e1, m->ev_layer[0], m->ev_layer[1], m->ev_join};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : m->ev_kv) if (e) (void)hipEventDestroy(e);
         if (m->side_own) (void)hipStreamDestroy(m->side_own);
     }
     delete m;
@@ -342,16 +329,6 @@ static void mode_shape(const mebt_model* m, int mode, int NC, int NT, int& NQ, i
     }
 }
 
-// K/V of the 'latent_enc' blocks ahead of the latent chain (see mebt_model::ev_kv)?  Part of the workspace layout, so a pure function
-// of the model and the shape: the routing must allow it (a side stream exists, no block rewrites the contexts), and by default the
-// key side must be large in absolute terms and at least four times the latent rows (measured: tools/kv_ahead_ab.sh).
-static bool kv_ahead_on(const mebt_model* m, int B, int NC) {
-    if (!m->side_own || m->ev_kv.empty() || m->has_maskgit || m->kv_ahead_mode == 0 || NC <= 0) return false;
-    if (m->kv_ahead_mode > 0) return true;
-    const int64_t Mk = (int64_t)B * NC, Mq = (int64_t)B * m->d.n_latent;
-    return Mk >= 8192 && Mk >= 4 * Mq;
-}
-
 // Lays the workspace out; with c.base == nullptr only measures.  In inference (training == 0)
 // all per-layer buffers alias one layer-sized region and the stream outputs ping-pong.
 static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int NT, int training) {
@@ -365,7 +342,6 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
     } else {
         x.tune = {nullptr, 0, nullptr, 0};
     }
-    x.tune_side = x.tune; x.tune_side.splitk = nullptr; x.tune_side.splitk_bytes = 0;
     x.sos0 = c.take(B * NS * d * e);
     x.ctx = c.take((int64_t)B * NC * d * e);
     x.tgt0 = c.take((int64_t)B * NT * d * e);
@@ -383,15 +359,6 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
             x.L[i].c_out = c.take((int64_t)B * NC * d * e);
             x.L[i].t_out = c.take((int64_t)B * NT * d * e);
         }
-    // inference with K/V ahead: the per-layer region is reused block after block while the side stream is several blocks ahead, so
-    // every 'latent_enc' block keeps its own K/V; LN1(contexts) is consumed in stream order on the side stream: one buffer
-    const bool ahead = kv_ahead_on(m, B, NC);
-    void* kn_ahead = nullptr;
-    if (ahead && !training) {
-        kn_ahead = c.take((int64_t)B * NC * d * e);
-        for (int i = 0; i < m->d.n_layer; ++i)
-            if (m->d.modes[i] == MEBT_MODE_LATENT_ENC) x.L[i].k = c.take((int64_t)B * NC * 2 * d * e);
-    }
     const int64_t after_ping = c.off;
     int nS = 0, nT = 0;
     for (int i = 0; i < m->d.n_layer; ++i) {
@@ -407,11 +374,6 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
             a.q = c.take(Mq * 3 * d * e);
             a.k = (char*)a.q + d * e; a.v = (char*)a.q + 2 * d * e;
             a.ldqkv_q = 3 * d; a.ldqkv_k = 3 * d;
-        } else if (kn_ahead && mode == MEBT_MODE_LATENT_ENC) {
-            a.kn = kn_ahead; a.mean1k = nullptr; a.rstd1k = nullptr;      // statistics are only kept for backward
-            a.q = c.take(Mq * d * e);
-            a.v = (char*)a.k + d * e;                                      // a.k: taken above, outside the reused region
-            a.ldqkv_q = d; a.ldqkv_k = 2 * d;
         } else {
             a.kn = c.take(Mk * d * e);
             a.mean1k = (float*)c.take(Mk * 4); a.rstd1k = (float*)c.take(Mk * 4);
@@ -597,24 +559,6 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
     const void* Sv = x.sos0;
     const void* Tv = x.tgt0;
     const void* Cv = x.ctx;          // read-only unless the model has 'maskgit' blocks (gpt.py:191-192)
-    // K/V of every 'latent_enc' block ahead of the chain, on the side stream (kv_ahead_on)
-    const bool ahead = kv_ahead_on(m, B, NC);
-    if (ahead) {
-        hipStream_t sd = m->side;
-        RC(fork_side(m, st));                              // the embedding has been enqueued
-        for (int i = 0; i < m->d.n_layer; ++i) {
-            if (m->d.modes[i] != MEBT_MODE_LATENT_ENC) continue;
-            LayerAct& a = x.L[i];
-            const LayerOffsets& o = m->lo[i];
-            for (const auto& w : m->fw_waits)              // parameters of this block and below that may still be arriving
-                if (w.first <= i) MEBT_HIP_CHECK(hipStreamWaitEvent(sd, w.second, 0));
-            RC(ln_fwd(m, Cv, a.kn, o.ln1w, o.ln1b, a.mean1k, a.rstd1k, B * a.NK, 0, 0, 0, sd));
-            GemmParams pk = gp(a.kn, m->Wop(o.wk), a.k, B * a.NK, 2 * d, d, d, d, 2 * d, 1, 1);
-            pk.bias = m->P + o.bk;
-            RC(gemm(m, pk, sd, true));
-            MEBT_HIP_CHECK(hipEventRecord(m->ev_kv[i], sd));
-        }
-    }
     for (int i = 0; i < m->d.n_layer; ++i) {
         LayerAct& a = x.L[i];
         const LayerOffsets& o = m->lo[i];
@@ -642,7 +586,7 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
             }
             if (mode == MEBT_MODE_LATENT_ENC) {
                 a.k_in = Cv;
-                if (!ahead) job(Cv, a.kn, a.mean1k, a.rstd1k, Mk, 0, 0, 0);
+                job(Cv, a.kn, a.mean1k, a.rstd1k, Mk, 0, 0, 0);
             } else if (mode == MEBT_MODE_LATENT_DEC) {
                 a.k_in = Sv;
                 job(Sv, a.kn, a.mean1k, a.rstd1k, Mk, 0, 0, 0);
@@ -660,12 +604,6 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
             p.bias = m->P + o.bq;
             set_pf(m, p, o.wp, (int64_t)d * d);
             RC(gemm(m, p, st));
-        } else if (ahead && mode == MEBT_MODE_LATENT_ENC) {
-            GemmParams p = gp(a.qn, m->Wop(o.wq), a.q, Mq, d, d, d, d, d, 1, 1);
-            p.bias = m->P + o.bq;
-            set_pf(m, p, o.wp, (int64_t)d * d);
-            RC(gemm(m, p, st));
-            MEBT_HIP_CHECK(hipStreamWaitEvent(st, m->ev_kv[i], 0));      // this block's K / V from the side stream
         } else {
             GemmParams pk = gp(a.kn, m->Wop(o.wk), a.k, Mk, 2 * d, d, d, d, 2 * d, 1, 1);
             pk.bias = m->P + o.bk;
