@@ -274,10 +274,11 @@ int mebt_op_groupnorm_silu(int32_t dtype, const void* x, void* y, const float* g
  * [n_codes, d]; score (scratch [M, n_codes] fp32) receives z E^T from the exact-fp32 MFMA GEMM, esq scratch [n_codes]. */
 int mebt_op_codebook_argmin(const float* z, const float* embeddings, float* score, float* esq, int64_t* ids, int32_t M,
                             int32_t n_codes, int32_t d, mebt_stream_t stream);
-/* The same ids through a filtered search: approximate scores on the bf16 MFMA GEMM, then the exact fp32 distance of every code
- * that can still be the arg-min given the rounding bound (never a reduced-precision decision).  lowp: scratch of (M + n_codes) * d
- * bf16 values; esq: scratch [n_codes + 1]; embedding_dim a multiple of 64. */
-int mebt_op_codebook_argmin_filtered(const float* z, const float* embeddings, float* score, float* esq, void* lowp, int64_t* ids,
+/* The same ids through a filtered search: approximate scores on the bf16 MFMA GEMM (stored as bf16), then the exact fp32 distance of
+ * every code that can still be the arg-min given the rounding bound (never a reduced-precision decision).  score: scratch of at
+ * least M * n_codes * 2 bytes (the exact search's fp32 matrix qualifies); lowp: scratch of (M + n_codes) * d bf16 values; esq:
+ * scratch [n_codes + 1]; embedding_dim a multiple of 64. */
+int mebt_op_codebook_argmin_filtered(const float* z, const float* embeddings, void* score, float* esq, void* lowp, int64_t* ids,
                                      int32_t M, int32_t n_codes, int32_t d, mebt_stream_t stream);
 /* out[m, :] = embeddings[ids[m], :] (F.embedding of VQGAN.decode, vqgan.py:91), out of `dtype`. */
 int mebt_op_embedding_rows(int32_t dtype, const int64_t* ids, const float* embeddings, void* out, int64_t rows, int32_t d,

@@ -683,8 +683,9 @@ __global__ __launch_bounds__(256) void codebook_argmin_kernel(const float* score
 // Filtered search (large M x n_codes): the [M, n_codes] score matrix costs 137 GFLOP at config 5 / batch 16 — 1.16 ms on the exact
 // fp32 MFMA GEMM (77 % of its peak), a third of the whole encode.  The bf16 GEMM family computes APPROXIMATE scores 5x faster; this
 // kernel turns them into the same ids the exact search gives:
-//   d~_j = (|z|^2 - 2 s~_j) + |e_j|^2,  |d~_j - d_j| <= mu := 2^-7 |z| max_j |e_j| (1 + 2^-6)   (bf16 round-to-nearest: |x - x~| <= 2^-9 |x|
-//   per vector, Cauchy-Schwarz on both factors, doubled by the -2; the fp32 accumulation of the MFMA is inside the 2^-6 slack),
+//   d~_j = (|z|^2 - 2 s~_j) + |e_j|^2,  |d~_j - d_j| <= mu := (2^-7 + 2^-8) |z| max_j |e_j| (1 + 2^-6)   (bf16 round-to-nearest: |x - x~| <= 2^-9 |x|
+//   per vector, Cauchy-Schwarz on both factors, doubled by the -2: 2^-7; the score itself is stored as bf16: another 2^-9, doubled:
+//   2^-8; the fp32 accumulation of the MFMA is inside the 2^-6 slack),
 // so the true arg-min is among C = { j : d~_j <= min d~ + 2 mu }.  For every j in C the distance is re-evaluated in exact fp32 (a
 // sequential FMA chain over k, the order of the exact GEMM) and the first minimum in index order wins, as in codebook_argmin_kernel.
 // |C| is a handful on real codebooks; more than 1024 candidates (degenerate codebook) -> every code is re-evaluated.
@@ -699,8 +700,13 @@ __global__ __launch_bounds__(256) void vec_max_sqrt_kernel(const float* v, float
     if (threadIdx.x == 0) out[0] = sqrtf(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])));
 }
 constexpr int CB_CAP = 1024;
-__global__ __launch_bounds__(256) void codebook_filter_kernel(const float* score /*[M, n_codes] ~ z E^T (bf16 operands)*/, const float* z, const float* e,
-                                                              const float* esq, const float* emax, int64_t* ids, int n_codes, int d) {
+// scores arrive as bf16 (half the bytes of the [M, n_codes] matrix in both directions: the search is bound by that matrix, 1 GB in
+// fp32 at config 5 / batch 16); rounding the fp32 accumulator to bf16 adds <= 2^-9 |s| <= 2^-9 |z| max|e| (1 + 2^-6) per score, i.e.
+// 2^-8 |z| max|e| (1 + 2^-6) to d~, on top of mu above.  FAST (n_codes = 16384): the 64 approximate distances of a thread stay in
+// registers between the minimum pass and the candidate pass — one pass over the row, 16-byte loads.
+template <bool FAST>
+__global__ __launch_bounds__(256) void codebook_filter_kernel(const bf16_t* score /*[M, n_codes] ~ z E^T (bf16 operands, bf16 result)*/, const float* z,
+                                                              const float* e, const float* esq, const float* emax, int64_t* ids, int n_codes, int d) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     float* zl = reinterpret_cast<float*>(smem_c);                  // [d]
     int* cand = reinterpret_cast<int*>(zl + d);                    // [CB_CAP]
@@ -720,21 +726,48 @@ __global__ __launch_bounds__(256) void codebook_filter_kernel(const float* score
     }
     __syncthreads();
     const float zz = szz;
-    const float* srow = score + (size_t)m * n_codes;
+    const bf16_t* srow = score + (size_t)m * n_codes;
+    constexpr int NV = FAST ? 8 : 1;                                // 16-byte chunks per thread (FAST: 8 x 8 x 256 = 16384 codes)
+    float dv[NV][8];
     float best = INFINITY;
-    for (int j = threadIdx.x; j < n_codes; j += 256) best = fminf(best, (zz - 2.0f * srow[j]) + esq[j]);
+    if (FAST) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const int j0 = (c * 256 + threadIdx.x) * 8;
+            const bf16x8 sc = *reinterpret_cast<const bf16x8*>(srow + j0);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(esq + j0), q1 = *reinterpret_cast<const f32x4*>(esq + j0 + 4);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                dv[c][k] = (zz - 2.0f * (float)sc[k]) + (k < 4 ? q0[k] : q1[k - 4]);
+                best = fminf(best, dv[c][k]);
+            }
+        }
+    } else {
+        for (int j = threadIdx.x; j < n_codes; j += 256) best = fminf(best, (zz - 2.0f * (float)srow[j]) + esq[j]);
+    }
     best = -wave_max(-best);
     if (lane == 0) sv[wv] = best;
     __syncthreads();
     if (threadIdx.x == 0) smin = fminf(fminf(sv[0], sv[1]), fminf(sv[2], sv[3]));
     __syncthreads();
-    const float mu = 0.0078125f * 1.015625f * sqrtf(zz) * emax[0];
+    const float mu = (0.0078125f + 0.00390625f) * 1.015625f * sqrtf(zz) * emax[0];
     const float thr = smin + 2.0f * mu + 1e-30f;
-    for (int j = threadIdx.x; j < n_codes; j += 256)
-        if ((zz - 2.0f * srow[j]) + esq[j] <= thr) {
-            const unsigned pos = atomicAdd(&ncand, 1u);
-            if (pos < (unsigned)CB_CAP) cand[pos] = j;
-        }
+    if (FAST) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (dv[c][k] <= thr) {
+                    const unsigned pos = atomicAdd(&ncand, 1u);
+                    if (pos < (unsigned)CB_CAP) cand[pos] = (c * 256 + threadIdx.x) * 8 + k;
+                }
+    } else {
+        for (int j = threadIdx.x; j < n_codes; j += 256)
+            if ((zz - 2.0f * (float)srow[j]) + esq[j] <= thr) {
+                const unsigned pos = atomicAdd(&ncand, 1u);
+                if (pos < (unsigned)CB_CAP) cand[pos] = j;
+            }
+    }
     __syncthreads();
     const bool all = ncand > (unsigned)CB_CAP;               // block-uniform
     const int n = all ? n_codes : (int)ncand;
@@ -909,7 +942,7 @@ extern "C" int mebt_op_codebook_argmin(const float* z, const float* embeddings, 
 // The same ids through the filtered search (see codebook_filter_kernel): approximate scores on the bf16 MFMA GEMM, exact fp32
 // re-evaluation of the candidates that can be the arg-min.  lowp: scratch of (M + n_codes) * d bf16 values (the rounded copies of
 // z and of the embeddings; the library allocates nothing); esq: scratch [n_codes + 1].  d a multiple of 64.
-extern "C" int mebt_op_codebook_argmin_filtered(const float* z, const float* embeddings, float* score, float* esq, void* lowp, int64_t* ids,
+extern "C" int mebt_op_codebook_argmin_filtered(const float* z, const float* embeddings, void* score, float* esq, void* lowp, int64_t* ids,
                                                 int32_t M, int32_t n_codes, int32_t d, mebt_stream_t stream) {
     if (!z || !embeddings || !score || !esq || !lowp || !ids) { mebt_set_error("codebook: null pointer"); return MEBT_EINVAL; }
     if (M <= 0) return MEBT_OK;
@@ -922,11 +955,13 @@ extern "C" int mebt_op_codebook_argmin_filtered(const float* z, const float* emb
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.A = zb; g.B = eb; g.C = score; g.M = M; g.N = n_codes; g.K = d; g.lda = d; g.ldb = d; g.ldc = n_codes;
-    g.a_kc = 1; g.b_kc = 1; g.c_f32 = 1; g.split_k = 1;
+    g.a_kc = 1; g.b_kc = 1; g.c_f32 = 0; g.split_k = 1;        // bf16 scores: the first half of the caller's scratch
     if (int rc = launch_gemm(g, MEBT_BF16, S(stream))) return rc;
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n_codes + 3) / 4), dim3(256), 0, S(stream), embeddings, esq, n_codes, d);
     hipLaunchKernelGGL(vec_max_sqrt_kernel, dim3(1), dim3(256), 0, S(stream), esq, esq + n_codes, n_codes);
-    hipLaunchKernelGGL(codebook_filter_kernel, dim3(M), dim3(256), (size_t)d * 4 + CB_CAP * 4, S(stream), score, z, embeddings, esq, esq + n_codes, ids, n_codes, d);
+    const bf16_t* sb = reinterpret_cast<const bf16_t*>(score);
+    if (n_codes == 16384) hipLaunchKernelGGL(codebook_filter_kernel<true>, dim3(M), dim3(256), (size_t)d * 4 + CB_CAP * 4, S(stream), sb, z, embeddings, esq, esq + n_codes, ids, n_codes, d);
+    else hipLaunchKernelGGL(codebook_filter_kernel<false>, dim3(M), dim3(256), (size_t)d * 4 + CB_CAP * 4, S(stream), sb, z, embeddings, esq, esq + n_codes, ids, n_codes, d);
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;
 }

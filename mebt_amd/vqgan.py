@@ -331,7 +331,6 @@ class VQGAN(nn.Module):
         z, dims = self._conv("pre_vq_conv", h, B, dims, out_mode=1)                    # fp32 [B, t, h, w, c] for the search
         M = B * int(np.prod(dims))
         emb = self._prepared["emb"]
-        score = torch.empty(M, self.n_codes, device=x.device, dtype=torch.float32)
         esq = torch.empty(self.n_codes + 1, device=x.device, dtype=torch.float32)
         ids = torch.empty(M, device=x.device, dtype=torch.long)
         # large searches (config 5 at batch 16: 16384 x 16384 x 256): approximate scores on the bf16 MFMA GEMM + exact fp32 re-evaluation
@@ -339,9 +338,11 @@ class VQGAN(nn.Module):
         if (self.use_mfma and self.embedding_dim % 64 == 0 and self.n_codes % 8 == 0 and M * self.n_codes >= (1 << 24)
                 and os.environ.get("MEBT_CODEBOOK_FILTER", "1") != "0"):
             lowp = torch.empty((M + self.n_codes) * self.embedding_dim, device=x.device, dtype=torch.bfloat16)
+            score = torch.empty(M, self.n_codes, device=x.device, dtype=torch.bfloat16)     # approximate scores: half the bytes of the exact path's matrix
             check(_lib.load().mebt_op_codebook_argmin_filtered(ptr(z), ptr(emb), ptr(score), ptr(esq), ptr(lowp), ptr(ids), M, self.n_codes,
                                                                self.embedding_dim, cur_stream()))
         else:
+            score = torch.empty(M, self.n_codes, device=x.device, dtype=torch.float32)
             check(_lib.load().mebt_op_codebook_argmin(ptr(z), ptr(emb), ptr(score), ptr(esq), ptr(ids), M, self.n_codes, self.embedding_dim,
                                                       cur_stream()))
         self._last_z = z

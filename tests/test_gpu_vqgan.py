@@ -323,7 +323,7 @@ def test_validation_epoch_hook_samples_decodes_and_logs_a_video(tmp_path):
     (tag, path, step, fps), = model.logger.videos
     arr = np.load(path)
     assert arr.dtype == np.uint8 and arr.shape == (4, 4, 3, 16, 16)
-    assert np.abs(arr.astype(np.float32) / 255.0 - vid.cpu().numpy()).max() <= 0.5 / 255 + 1e-6
+    assert np.abs(arr.astype(np.float32) / 255.0 - vid.cpu().numpy()).max() <= 0.5 / 255 + 2e-5      # a second sample + decode run: not bitwise (GroupNorm atomics)
     # no first stage: skipped with a warning instead of the reference's AttributeError
     model.first_stage_model = None
     with pytest.warns(UserWarning):
