@@ -505,6 +505,7 @@ def main():
     stats = stats.cpu()
     n_targets = int(stats[3])                                  # masked tokens scored per rank per step
     ms = 1e3 * elapsed / args.steps
+    wire_bytes_per_step = (reducer.bytes_on_wire - wire0) / max(1, args.steps)     # payload of the timed steps only
     # host side of a step: wall time of two step() calls that only enqueue (empty queue in front, no synchronisation inside)
     sync()
     h0 = time.perf_counter()
@@ -513,7 +514,6 @@ def main():
     host_enqueue_ms = 1e3 * (time.perf_counter() - h0) / 2
     sync()
     value = world * n_targets * args.steps / elapsed
-    wire_bytes_per_step = (reducer.bytes_on_wire - wire0) / max(1, args.steps)
 
     # dominant kernel family: MFMA GEMMs — time every launch of 2 more steps with HIP events on the
     # launch stream (rank 0 records; every rank runs the steps because they contain collectives).  Taken BEFORE the
