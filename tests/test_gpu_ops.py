@@ -274,7 +274,10 @@ def test_attention_fwd_bwd_block8192(dtype, tol, generic, B, H, NQ, NK):
 
 @pytest.mark.parametrize("dtype,tol,generic", [(_lib.F32, 2e-5, 1), (_lib.BF16, 2e-2, 1), (_lib.BF16, 2e-2, 0)])
 @pytest.mark.parametrize("B,H,NQ,NK,HD", [(2, 2, 70, 45, 32), (2, 4, 64, 130, 64), (1, 3, 200, 1, 64), (2, 2, 33, 0, 64), (1, 2, 256, 513, 64),
-                                         (1, 2, 129, 257, 64), (1, 1, 300, 769, 64), (1, 2, 385, 256, 64)])
+                                         (1, 2, 129, 257, 64), (1, 1, 300, 769, 64), (1, 2, 385, 256, 64),
+                                         # the launcher's forward forms by grid size (attention_mfma.hip launch_attn_fwd_mfma): ragged long key sets on a
+                                         # small grid (split-keys form), ragged shapes on grids of more than 128 workgroups (8-wave forms, 1 / 2 stages)
+                                         (1, 2, 200, 3001, 64), (2, 1, 64, 1025, 64), (5, 16, 300, 769, 64), (9, 16, 128, 200, 64)])
 def test_attention_fwd_bwd(dtype, tol, generic, B, H, NQ, NK, HD):
     t = tdt(dtype)
     C = H * HD
