@@ -301,11 +301,6 @@ int mebt_debug_dropout_mask(uint64_t seed, uint32_t site, float p, int64_t n, fl
 void mebt_debug_side_stream(mebt_model* m, int32_t on);
 /* experiment: run that second stream's work on a caller-owned stream instead (NULL: back to the internal one) */
 void mebt_debug_set_side_stream(mebt_model* m, mebt_stream_t stream);
-/* Spatial split of mebt_backward_layers over the CUs: the blocks' dependency chain (dgrad, attention, LayerNorm) on
- * `chain_cus_per_xcd` CUs of every XCD, the gradient leaves (weight gradients, optimizer-in-backward) on the other
- * 32 - chain_cus_per_xcd, each on a CU-masked queue the handle owns; the caller's stream continues after both.  Same results as the
- * serial order (the same launches, other queues).  chain_cus_per_xcd in [4, 28]; 0 switches it off.  Returns a status. */
-int mebt_model_set_cu_split(mebt_model* m, int32_t chain_cus_per_xcd);
 /* Benchmarking / tests only: force the bf16 GEMM block tile (bm, bn in {128, 64}); (0, 0) restores the heuristic. */
 void mebt_debug_gemm_tile(int32_t bm, int32_t bn);
 /* Benchmarking / tests only: force the bf16 GEMM staging: 0 register-staged, 2 LDS-DMA 2 stages, 1 LDS-DMA

@@ -78,7 +78,6 @@ PROTOTYPES = {
     "mebt_debug_dropout_mask": (c_i32, [C.c_uint64, C.c_uint32, c_f32, c_i64, c_vp, c_vp]),
     "mebt_debug_side_stream": (None, [c_vp, c_i32]),
     "mebt_debug_set_side_stream": (None, [c_vp, c_vp]),
-    "mebt_model_set_cu_split": (c_i32, [c_vp, c_i32]),
     "mebt_debug_gemm_tile": (None, [c_i32, c_i32]),
     "mebt_debug_gemm_variant": (None, [c_i32]),
     "mebt_debug_grouped_stages": (None, [c_i32]),

@@ -97,13 +97,6 @@ struct mebt_model {
     hipEvent_t ev_fork = nullptr, ev_e1 = nullptr, ev_layer[2] = {nullptr, nullptr}, ev_join = nullptr;
     bool use_side = true;
     hipStream_t side_own = nullptr;      // the stream this object created (destroyed with it); `side` may point at a caller's stream instead
-    // Spatial split of the backward (mebt_model_set_cu_split): the dependency chain of the blocks (dgrad, attention, LayerNorm) runs
-    // on a stream whose queue may only use `split_n` CUs of every XCD, the gradient leaves (weight gradients + AdamW) on a stream
-    // that owns the other 32 - split_n: the two never wait for each other's workgroups to leave a CU.
-    hipStream_t chain = nullptr, side_split = nullptr;
-    hipEvent_t ev_split_in = nullptr, ev_split_out = nullptr;
-    int split_n = 0;
-    int tune_domain(hipStream_t st) const { return !split_n ? 0 : st == chain ? split_n : st == side_split ? 64 + 32 - split_n : 0; }
     // optimizer-in-backward (mebt_model_set_fused_adamw): when armed, the weight gradients of the blocks are applied
     // to W (AdamW) inside the weight-gradient launch instead of being stored in gW
     bool fused_on = false;
@@ -156,9 +149,7 @@ static int gemm(const mebt_model* m, GemmParams p, hipStream_t st) {
         r.bytes = ((double)p.M * p.K + (double)p.N * p.K) * esz + (double)p.M * p.N * (csz * (p.C ? 1 : 0) + (p.C2 ? esz : 0) + (p.aux ? esz : 0));
         (void)hipEventRecord(r.a, st);
     }
-    mebt_gemm_tune_domain(m->tune_domain(st));
     const int rc = launch_gemm(p, m->d.dtype, st);
-    mebt_gemm_tune_domain(0);
     if (prof) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
     return rc;
 }
@@ -178,9 +169,7 @@ static int gemm_pair(const mebt_model* m, const GemmParams& p0_in, const GemmPar
             r.bytes += ((double)q->M * q->K + (double)q->N * q->K) * 2.0 + (double)q->M * q->N * (2.0 * (q->C ? 1 : 0) + (q->aux ? 2.0 : 0));
         (void)hipEventRecord(r.a, st);
     }
-    mebt_gemm_tune_domain(m->tune_domain(st));
     const int rc = launch_gemm_pair(p0, p1, m->d.dtype, st);
-    mebt_gemm_tune_domain(0);
     if (g_prof_on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
     return rc;
 }
@@ -290,7 +279,6 @@ extern "C" int mebt_model_create(const mebt_model_desc* desc, mebt_model** out) 
 
 extern "C" void mebt_model_destroy(mebt_model* m) {
     if (!m) return;
-    (void)mebt_model_set_cu_split(m, 0);
     if (m->side) {
         (void)hipStreamSynchronize(m->side);
         hipEvent_t evs[] = {m->ev_fork, m->ev_e1, m->ev_layer[0], m->ev_layer[1], m->ev_join};
@@ -305,38 +293,6 @@ extern "C" void mebt_debug_set_side_stream(mebt_model* m, mebt_stream_t s) {
     if (!m || !m->side_own) return;
     (void)hipStreamSynchronize(m->side);
     m->side = s ? reinterpret_cast<hipStream_t>(s) : m->side_own;
-}
-
-// Spatial split of the backward over the CUs.  chain_cus_per_xcd = n in [4, 28]: the blocks' backward chain runs on n CUs of every XCD,
-// the gradient leaves on the other 32 - n (bit b of a queue's CU mask <-> XCD b % 8, CU slot b / 8: tools/cu_mask_probe.hip); 0: off.
-// The caller's stream waits for both at the end of mebt_backward_layers.  The GEMM tuner keys its table by the CU share, so the
-// picks of the two queues do not collide with the whole-chip picks.
-extern "C" int mebt_model_set_cu_split(mebt_model* m, int32_t chain_cus_per_xcd) {
-    if (!m) { mebt_set_error("null model"); return MEBT_EINVAL; }
-    const int n = chain_cus_per_xcd;
-    if (n != 0 && (n < 4 || n > 28)) { mebt_set_error("cu_split: CUs per XCD for the chain must be in [4, 28] (0 = off)"); return MEBT_EINVAL; }
-    if (m->split_n) {
-        (void)hipStreamSynchronize(m->chain);
-        (void)hipStreamSynchronize(m->side_split);
-        if (m->side == m->side_split) m->side = m->side_own;
-        (void)hipStreamDestroy(m->chain); (void)hipStreamDestroy(m->side_split);
-        (void)hipEventDestroy(m->ev_split_in); (void)hipEventDestroy(m->ev_split_out);
-        m->chain = m->side_split = nullptr; m->ev_split_in = m->ev_split_out = nullptr;
-        m->split_n = 0;
-    }
-    if (!n) return MEBT_OK;
-    if (!m->side_own) { mebt_set_error("cu_split: this handle has no side-stream events (host-only handle?)"); return MEBT_EINVAL; }
-    uint32_t lo[8] = {0}, hi[8] = {0};
-    for (int b = 0; b < 256; ++b) (b < 8 * n ? lo : hi)[b >> 5] |= 1u << (b & 31);
-    MEBT_HIP_CHECK(hipExtStreamCreateWithCUMask(&m->chain, 8, lo));
-    MEBT_HIP_CHECK(hipExtStreamCreateWithCUMask(&m->side_split, 8, hi));
-    MEBT_HIP_CHECK(hipEventCreateWithFlags(&m->ev_split_in, hipEventDisableTiming));
-    MEBT_HIP_CHECK(hipEventCreateWithFlags(&m->ev_split_out, hipEventDisableTiming));
-    (void)hipStreamSynchronize(m->side);
-    m->side = m->side_split;
-    m->use_side = true;
-    m->split_n = n;
-    return MEBT_OK;
 }
 
 extern "C" int mebt_model_param_counts(const mebt_model* m, int64_t* n_w, int64_t* n_p) {
@@ -793,7 +749,7 @@ static int head_backward_common(mebt_model* m, hipStream_t st) {
     FwdCtx& x = m->ctx;
     const int d = m->d.n_embd, V = m->d.vocab, R = x.B * x.NT;
     hipStream_t sd = st;
-    if (m->use_side && !m->split_n) {       // split mode: the head's two products stay on the caller's (whole-chip) stream
+    if (m->use_side) {
         RC(fork_side(m, st));
         sd = m->side;
         // a fresh backward: mark both scratch sets free
@@ -805,7 +761,7 @@ static int head_backward_common(mebt_model* m, hipStream_t st) {
              &x.L[m->d.n_layer - 1], 1));
     RC(ln_bwd(m, x.T_final, x.dhf, nullptr, m->lnf_w, m->lnf_b, x.meanf, x.rstdf, x.g_T, 0, 0, R, 0, 0, 0, st));
     x.gT_defined = true; x.gS_defined = false; x.gC_defined = false; x.doutm_ready = -1; x.last_bwd_lo = m->d.n_layer;
-    return m->split_n ? MEBT_OK : join_side(m, st);
+    return join_side(m, st);
 }
 
 static int backward_prologue(mebt_model* m, void* ws, hipStream_t st) {
@@ -941,9 +897,7 @@ static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd, bool with_col
                 if (it.K <= 0 && it.M > 0 && it.N > 0) RC(fused_adamw_slice(m, it.C, (int64_t)it.M * it.N, sd));
             }
         }
-        mebt_gemm_tune_domain(m->tune_domain(sd));
         const int rc = launch_wgrad_grouped(lv.w, dt, sd);
-        mebt_gemm_tune_domain(0);
         if (prof) { (void)hipEventRecord(r.b, sd); g_prof.push_back(r); }
         return rc;
     }
@@ -1112,23 +1066,9 @@ extern "C" int mebt_backward_layers(mebt_model* m, void* ws, int32_t layer_hi, i
     if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("backward: no training-mode forward on this workspace"); return MEBT_EINVAL; }
     if (layer_hi >= m->d.n_layer || layer_lo < 0 || layer_lo > layer_hi) { mebt_set_error("backward_layers: bad layer range"); return MEBT_EINVAL; }
     if (m->ctx.last_bwd_lo != layer_hi + 1) m->ctx.doutm_ready = -1;     // not the block right below the previous call's range
-    hipStream_t st = S(stream);
-    if (m->split_n && m->use_side) {         // the chain and the leaves on their own CU shares; the caller's stream waits for both
-        MEBT_HIP_CHECK(hipEventRecord(m->ev_split_in, st));
-        MEBT_HIP_CHECK(hipStreamWaitEvent(m->chain, m->ev_split_in, 0));
-        RC(fork_side(m, m->chain));
-        MEBT_HIP_CHECK(hipEventRecord(m->ev_layer[0], m->side));        // both scratch sets are free: the previous call joined
-        MEBT_HIP_CHECK(hipEventRecord(m->ev_layer[1], m->side));
-        for (int i = layer_hi; i >= layer_lo; --i) RC(backward_layer(m, i, m->chain));
-        m->ctx.last_bwd_lo = layer_lo;
-        RC(join_side(m, m->chain));
-        MEBT_HIP_CHECK(hipEventRecord(m->ev_split_out, m->chain));
-        MEBT_HIP_CHECK(hipStreamWaitEvent(st, m->ev_split_out, 0));
-        return MEBT_OK;
-    }
-    for (int i = layer_hi; i >= layer_lo; --i) RC(backward_layer(m, i, st));
+    for (int i = layer_hi; i >= layer_lo; --i) RC(backward_layer(m, i, S(stream)));
     m->ctx.last_bwd_lo = layer_lo;
-    return join_side(m, st);          // the caller may all-reduce these gradients next
+    return join_side(m, S(stream));          // the caller may all-reduce these gradients next
 }
 
 // embd dropout (gpt.py:238-240) on the stream gradients that reached the network inputs

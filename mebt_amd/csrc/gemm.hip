@@ -160,11 +160,6 @@ static void alts_keep(const TuneKey& key, std::vector<std::pair<int, float>> v) 
     g_alts[key] = v;
 }
 static std::mutex g_tune_mutex;
-// CU share of the queue the next launches go to (engine.cpp, mebt_model_set_cu_split): part of every key (0 = whole chip, the
-// shipped table's entries), and a tuning session of a share first waits for the other queue to drain so that it times its
-// candidates alone on its CUs
-static int g_tune_domain = 0;
-void mebt_gemm_tune_domain(int d) { g_tune_domain = d & 0xFF; }
 static int g_autotune = -1, g_tune_log = 0;
 static const char* g_tune_cache = nullptr;                       // MEBT_GEMM_TUNE_CACHE: text file of tuned choices
 
@@ -305,8 +300,6 @@ struct TuneRun {        // one tuning session: the caller's flush buffer + two e
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int begin(const GemmScratch* s) {
         sc = s;
-        static const bool sync_all = [] { const char* e = getenv("MEBT_GEMM_TUNE_SYNC"); return e && e[0] == '1'; }();
-        if (g_tune_domain || sync_all) MEBT_HIP_CHECK(hipDeviceSynchronize());      // candidates are timed with no other queue running
         MEBT_HIP_CHECK(hipEventCreate(&e0));
         MEBT_HIP_CHECK(hipEventCreate(&e1));
         return MEBT_OK;
@@ -347,14 +340,12 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
     float best = 1e30f;
     struct Cand { float ms; int bm, bn, staging; };
     std::vector<Cand> cands;
-    // experiment (MEBT_GEMM_LDS_CAP_KB): only candidates whose workgroup fits beside another queue's workgroups in the CU's 160 KiB
-    static const int lds_cap = [] { const char* e = getenv("MEBT_GEMM_LDS_CAP_KB"); return e ? atoi(e) * 1024 : 1 << 30; }();
     for (int t = 0; t < 7; ++t) {
         const int bm = tiles[t][0], bn = tiles[t][1];
         const long nt = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
         const bool few = nt < 96 && (long)bm * bn > 64 * 64 && out > 64 * 64;    // unsplit, this tile would leave most of the chip idle
         for (int st = 2; st <= 4 && !few; ++st) {
-            if (st * (bm + bn) * BK * 2 > 128 * 1024 || st * (bm + bn) * BK * 2 > lds_cap) continue;
+            if (st * (bm + bn) * BK * 2 > 128 * 1024) continue;
             float ms = 0.f;
             if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, st, 1, stream); }, stream, tr, ms)) return rc;
             if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d: %.1f us\n", bm, bn, st, ms * 1e3f);
@@ -362,7 +353,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
             if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = st; }
         }
         for (int st = 2; st <= 4 && !few; ++st) {                                 // software-pipelined main loop (staging 8 + ring depth)
-            if (st * (bm + bn) * BK * 2 > 160 * 1024 || st * (bm + bn) * BK * 2 > lds_cap) continue;
+            if (st * (bm + bn) * BK * 2 > 160 * 1024) continue;
             float ms = 0.f;
             if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, 8 + st, 1, stream); }, stream, tr, ms)) return rc;
             if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d pipelined: %.1f us\n", bm, bn, st, ms * 1e3f);
@@ -373,7 +364,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
             for (int S = 2; S <= 4; S *= 2) {
                 if (p.K % (S * BK) || p.K / S < 8 * BK || !splitk_fits(p, S)) continue;
                 for (int st = 2; st <= 3; ++st) {
-                    if (st * (bm + bn) * BK * 2 > 128 * 1024 || st * (bm + bn) * BK * 2 > lds_cap) continue;
+                    if (st * (bm + bn) * BK * 2 > 128 * 1024) continue;
                     float ms = 0.f;
                     int rc2 = MEBT_OK;
                     if (int rc = time_cold([&] { rc2 |= launch_bf16_splitk(p, bm, bn, st, S, stream); }, stream, tr, ms)) return rc;
@@ -385,7 +376,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
             }
         if (p.K % (2 * BK) == 0 && p.K >= 8 * BK && nt <= 640 && !few)         // two pipelines per workgroup (staging 16 + ring depth)
             for (int st = 2; st <= 3; ++st) {
-                if (!ks2_lds(bm, bn, st) || ks2_lds(bm, bn, st) > lds_cap) continue;
+                if (!ks2_lds(bm, bn, st)) continue;
                 float ms = 0.f;
                 if (int rc = time_cold([&] { launch_bf16_config(p, bm, bn, 16 + st, 1, stream); }, stream, tr, ms)) return rc;
                 if (g_tune_log >= 2) fprintf(stderr, "    cand %dx%d ring %d x2 pipelines: %.1f us\n", bm, bn, st, ms * 1e3f);
@@ -393,7 +384,7 @@ static int autotune_config(const GemmParams& p, hipStream_t stream, int& tbm, in
                 if (ms < best) { best = ms; tbm = bm; tbn = bn; staging = 16 + st; }
             }
     }
-    if ((long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 96 && (p.a_kc ? p.K % BK == 0 : true) && lds_cap >= 160 * 1024) {   // 8-wave 256 x 256 tile
+    if ((long)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 96 && (p.a_kc ? p.K % BK == 0 : true)) {   // 8-wave 256 x 256 tile
         float ms = 0.f;
         if (int rc = time_cold([&] { launch_bf16_config(p, 256, 256, 2, 1, stream); }, stream, tr, ms)) return rc;
         if (g_tune_log >= 2) fprintf(stderr, "    cand 256x256 (8 waves): %.1f us\n", ms * 1e3f);
@@ -476,7 +467,7 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         if (!forced && split == 1 && (long)p.M * p.N >= 128 * 128) {
             std::lock_guard<std::mutex> lk(g_tune_mutex);
             tune_init();
-            const TuneKey key{p.a_kc | (p.b_kc << 1) | (p.epilogue << 2) | (p.c_f32 << 5) | ((p.bias != nullptr) << 6) | ((p.drop.thresh != 0) << 7) | (g_tune_domain << 12),
+            const TuneKey key{p.a_kc | (p.b_kc << 1) | (p.epilogue << 2) | (p.c_f32 << 5) | ((p.bias != nullptr) << 6) | ((p.drop.thresh != 0) << 7),
                               tune_bucket(p.M), p.N, tune_bucket(p.K)};
             auto it = g_tuned.find(key);
             if (it == g_tuned.end() && g_autotune && idempotent && tune_scratch_of(p.scratch)) {
@@ -536,7 +527,7 @@ int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipS
     {
         std::unique_lock<std::mutex> lk(g_tune_mutex);
         tune_init();
-        const TuneKey key{0x20000000 | p0.b_kc | (p0.epilogue << 2) | (p1.epilogue << 5) | ((p0.drop.thresh != 0) << 8) | (g_tune_domain << 12),
+        const TuneKey key{0x20000000 | p0.b_kc | (p0.epilogue << 2) | (p1.epilogue << 5) | ((p0.drop.thresh != 0) << 8),
                           tune_bucket(p0.M), p0.N, tune_bucket(p0.K), tune_bucket(p1.M), p1.N, tune_bucket(p1.K)};
         auto it = g_tuned.find(key);
         if (it == g_tuned.end() && g_autotune && tune_scratch_of(p0.scratch)) {
@@ -548,8 +539,7 @@ int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipS
             std::vector<std::pair<int, float>> alts;
             for (int t = 0; t < 7; ++t)
                 for (int st = 2; st <= 4; ++st) {
-                    static const int lds_cap = [] { const char* e = getenv("MEBT_GEMM_LDS_CAP_KB"); return e ? atoi(e) * 1024 : 1 << 30; }();
-                    if (st * (tiles[t][0] + tiles[t][1]) * BK * 2 > 128 * 1024 || st * (tiles[t][0] + tiles[t][1]) * BK * 2 > lds_cap) continue;
+                    if (st * (tiles[t][0] + tiles[t][1]) * BK * 2 > 128 * 1024) continue;
                     float ms = 0.f;
                     if (int rc = time_cold([&] { launch_pair_config(g, tiles[t][0], tiles[t][1], st, stream); }, stream, tr, ms)) return rc;
                     alts.emplace_back((tiles[t][0] << 20) | (tiles[t][1] << 8) | st, ms);
@@ -598,7 +588,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
     {
         std::lock_guard<std::mutex> lk(g_tune_mutex);
         tune_init();
-        TuneKey key{0x40000000 | n | (c.fused ? 0x100 : 0) | (c.beta ? 0x200 : 0) | (c.Cb ? 0x400 : 0) | (g_tune_domain << 12)};
+        TuneKey key{0x40000000 | n | (c.fused ? 0x100 : 0) | (c.beta ? 0x200 : 0) | (c.Cb ? 0x400 : 0)};
         for (int i = 0; i < n; ++i) { key.push_back(c.g[i].M); key.push_back(c.g[i].N); key.push_back(tune_bucket(c.g[i].K)); }
         auto it = g_tuned.find(key);
         if (it == g_tuned.end() && g_autotune && !c.beta && tune_scratch_of(w.scratch)) {

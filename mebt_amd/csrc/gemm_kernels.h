@@ -1373,22 +1373,17 @@ static void layout_launch_grouped(GroupedWgrad& c, int tbm, int tbn, int stages,
         tiles += ((c.g[i].M + tbm - 1) / tbm) * c.g[i].ntx;
     }
     for (int i = c.n; i <= MEBT_MAX_GROUP; ++i) c.tile_start[i] = tiles;
-    // experiment (MEBT_WGRAD_LDS_KB): declare at least this much LDS per workgroup, i.e. choose how many of these workgroups a CU
-    // holds and how much LDS stays free for the chain's workgroups of another queue (co-residency instead of time slicing)
-    static const int lds_floor = [] { const char* e = getenv("MEBT_WGRAD_LDS_KB"); return e ? atoi(e) * 1024 : 0; }();
-#define GL(n_) ((n_) > lds_floor ? (n_) : lds_floor)
 #define LAUNCH_G(TM_, TN_)                                                                                                                   \
     do {                                                                                                                                    \
-        if (stages >= 4) hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 4>), dim3(tiles), dim3(256), GL(4 * (TM_ + TN_) * BK * 2), stream, c);      \
-        else if (stages == 3) hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 3>), dim3(tiles), dim3(256), GL(3 * (TM_ + TN_) * BK * 2), stream, c); \
-        else hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 2>), dim3(tiles), dim3(256), GL(2 * (TM_ + TN_) * BK * 2), stream, c);                 \
+        if (stages >= 4) hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 4>), dim3(tiles), dim3(256), 4 * (TM_ + TN_) * BK * 2, stream, c);      \
+        else if (stages == 3) hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 3>), dim3(tiles), dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, c); \
+        else hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 2>), dim3(tiles), dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, c);                 \
     } while (0)
     if (tbm == 128 && tbn == 128) LAUNCH_G(128, 128);
     else if (tbm == 128 && tbn == 64) LAUNCH_G(128, 64);
     else if (tbm == 64 && tbn == 128) LAUNCH_G(64, 128);
     else LAUNCH_G(64, 64);
 #undef LAUNCH_G
-#undef GL
 }
 
 template <bool AK, bool BKC>
@@ -1460,9 +1455,9 @@ static int layout_set_pair_attrs() {
 static int layout_set_grouped_attrs() {
 #define SET_G(TM_, TN_)                                                                                                                                        \
     do {                                                                                                                                                  \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TM_, TN_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TM_, TN_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TM_ + TN_) * BK * 2)); \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TM_, TN_, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM_ + TN_) * BK * 2)); \
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<TM_, TN_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (TM_ + TN_) * BK * 2)); \
     } while (0)
     SET_G(128, 128); SET_G(128, 64); SET_G(64, 128); SET_G(64, 64);
 #undef SET_G

@@ -97,7 +97,6 @@ int launch_colsum_grouped(GroupedColsum& c, int dtype, hipStream_t stream);
 int gemm_init_attributes();
 extern "C" int32_t mebt_gemm_autotune_enabled(void);      // is in-situ tuning on (MEBT_GEMM_AUTOTUNE / mebt_gemm_autotune)?  (public: include/mebt_hip.h)
 void mebt_gemm_force_split(int s);
-void mebt_gemm_tune_domain(int cu_share);                 // tuner key of the following launches (engine.cpp: the CU-masked queues of the split backward)
 
 // ---- embedding gather (reference transformer.py:255-277) and its scatter-add backward -----------
 struct EmbedParams {

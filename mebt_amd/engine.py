@@ -75,11 +75,6 @@ class NativeModel:
             from .parallel import pick_concurrent_stream            # a stream that really runs beside the compute stream
             self._side = pick_concurrent_stream(torch.cuda.current_stream())
             self.lib.mebt_debug_set_side_stream(self.h, self._side.cuda_stream)
-        # spatial split of the backward (include/mebt_hip.h: mebt_model_set_cu_split): MEBT_CU_SPLIT = CUs per XCD for the chain
-        self.cu_split = int(os.environ.get("MEBT_CU_SPLIT", "0") or 0)
-        if self.cu_split and torch.cuda.is_available():
-            check(self.lib.mebt_model_set_cu_split(self.h, self.cu_split))
-            self.side_stream = True
         self.n_layer, self.n_embd, self.vocab, self.n_latent = n_layer, n_embd, vocab, n_latent
         self.W = self.P = self.gW = self.gP = self.Wlp = None
         self.gWb = None             # bf16 wire-format weight gradients (data-parallel sharded path)
@@ -228,8 +223,6 @@ class NativeModel:
             self.backward_head(logits, loss_scale, upstream)
         if between:
             between("head", None, None)
-        if self.cu_split and between is None:
-            bucket_layers = self.n_layer        # one call: the two queues join once, at the end
         sizes = list(bucket_layers) if isinstance(bucket_layers, (list, tuple)) else None     # per-bucket layer counts, top down
         hi, nb = self.n_layer - 1, 0
         while hi >= 0:
