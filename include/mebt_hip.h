@@ -293,6 +293,10 @@ int mebt_op_cast_f16(const float* src, void* dst, int64_t n, mebt_stream_t strea
  * its scatter-add backward with their algorithmic bytes. */
 int mebt_profile_enable(int32_t on);
 int mebt_profile_read(int32_t family, double* launches, double* total_ms, double* total_flops);
+/* Data parallel, while profiling is enabled: every wait of a forward for a deferred parameter gather
+ * (mebt_model_set_forward_waits) is bracketed by an event pair.  Writes up to `cap` (first layer reading the bucket, ms the
+ * compute stream stood still) pairs in launch order and returns how many were recorded (negative: HIP error). */
+int32_t mebt_profile_read_waits(int32_t cap, int32_t* layer, double* ms);
 /* Tests only: multiplies out[0..n) (fp32, n % 4 == 0) in place by the dropout keep-scales (0 or 1/(1-p))
  * of site `site` under `seed` — fill `out` with ones to read the mask the kernels use.  Site ids: 16*layer
  * + {0 attention probabilities, 1 proj output, 2 MLP output}; 0xFFFF0/1/2 = embedded sos/contexts/targets. */

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "mebt_gemm_tune_alternatives": (c_i64, [C.c_char_p, c_i64]),
     "mebt_profile_enable": (c_i32, [c_i32]),
     "mebt_profile_read": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mebt_profile_read_waits": (c_i32, [c_i32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -195,6 +195,21 @@ extern "C" int mebt_profile_read(int32_t family, double* launches, double* total
     return MEBT_OK;
 }
 
+// the forward's waits for deferred parameter gathers recorded while profiling was on: (first layer that reads the bucket, ms the
+// compute stream waited), in launch order; returns the number of records (at most `cap` are written), negative on a HIP error
+extern "C" int32_t mebt_profile_read_waits(int32_t cap, int32_t* layer, double* ms) {
+    int32_t n = 0;
+    for (auto& r : g_prof) {
+        if (r.kind != 4) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) return -1;
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return -1;
+        if (n < cap && layer && ms) { layer[n] = (int32_t)r.flops; ms[n] = t; }
+        ++n;
+    }
+    return n;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------------------
@@ -487,7 +502,14 @@ static void pf2_head(const mebt_model* m, GemmParams& p, const LayerAct& a) { se
 // still be in flight when the forward starts; it only has to be complete when the first block of that bucket runs).
 static int fw_wait(const mebt_model* m, int layer, hipStream_t st) {
     for (const auto& w : m->fw_waits)
-        if (w.first == layer) MEBT_HIP_CHECK(hipStreamWaitEvent(st, w.second, 0));
+        if (w.first == layer) {
+            // profiling: an event pair around the wait = how long the compute stream really stood still for this bucket's
+            // parameters (0 when the all-gather had finished before the forward got here)
+            ProfRec r;
+            if (g_prof_on) { r.a = get_event(); r.b = get_event(); r.flops = layer; r.bytes = 0; r.kind = 4; (void)hipEventRecord(r.a, st); }
+            MEBT_HIP_CHECK(hipStreamWaitEvent(st, w.second, 0));
+            if (g_prof_on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
+        }
     return MEBT_OK;
 }
 static bool fw_pending(const mebt_model* m, int layer) {

@@ -200,6 +200,26 @@ static int tune_parse(const char* text, bool overwrite, bool replace = false) {
     }
     return taken;
 }
+// version line of a table text (1 for an unversioned text), without taking any entry
+static int tune_text_version(const char* text) {
+    int version = 1;
+    const char* c = text;
+    while (*c) {
+        char* e = nullptr;
+        const long n = strtol(c, &e, 10);
+        if (e == c || n <= 0 || n >= 64) break;
+        c = e;
+        long first = 0, v = 0;
+        bool ok = true;
+        for (long i = 0; i < n && ok; ++i) { const long x = strtol(c, &e, 10); ok = e != c; c = e; if (i == 0) first = x; }
+        if (!ok) break;
+        v = strtol(c, &e, 10);
+        if (e == c) break;
+        c = e;
+        if (n == 1 && first == -1) version = (int)v;
+    }
+    return version;
+}
 static void tune_init() {
     if (g_autotune >= 0) return;
     const char* e = getenv("MEBT_GEMM_AUTOTUNE");
@@ -216,7 +236,15 @@ static void tune_init() {
             while ((got = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, got);
             fclose(f);
             fresh = text.empty();
-            tune_parse(text.c_str(), true);
+            if (!fresh && tune_text_version(text.c_str()) != MEBT_TUNE_VERSION) {
+                // a cache written by a build whose variant codes meant something else (or an unversioned round-3 file): nothing of it
+                // is usable, and appending to it would only grow a file every later process ignores again — start it over
+                fprintf(stderr, "[mebt gemm autotune] %s holds a table of another version: rewritten for version %d\n", g_tune_cache, MEBT_TUNE_VERSION);
+                if (FILE* w = fopen(g_tune_cache, "w")) fclose(w);
+                fresh = true;
+            } else {
+                tune_parse(text.c_str(), true);
+            }
         }
         if (fresh)
             if (FILE* f = fopen(g_tune_cache, "a")) { fprintf(f, "1 -1 %d\n", MEBT_TUNE_VERSION); fclose(f); }

@@ -208,14 +208,14 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same draw for V = 16384 without top-p (every shipped script), the row in REGISTERS: thread t owns elements t + 256 j
-// (j = 0 .. 63), one pass over the logits instead of six to ten passes over an LDS copy:
+// The same draw for V = 16384 without top-p (every shipped script), the row in REGISTERS: 512 threads, thread t owns elements
+// t + 512 j (j = 0 .. 31), one pass over the logits instead of six to ten passes over an LDS copy:
 //  * top-k threshold (the k-th largest value, ties kept, transformer.py:891-895) without a radix select over 16384 entries (its four
 //    LDS-histogram passes serialised on a handful of bins — logits share their exponent bits — and were most of the 1.9 ms this
-//    kernel averaged on [32768, 16384] inputs): the k-th largest of the 256 per-thread maxima is a lower bound L of the
+//    kernel averaged on [32768, 16384] inputs): the k-th largest of the 512 per-thread maxima is a lower bound L of the
 //    threshold (at least k elements are >= L); the elements >= L are collected in LDS (a few dozen on ordinary rows) and the
 //    exact k-th largest is picked among them by rank counting.  More than 1024 candidates (degenerate rows: many equal values)
-//    or k > 256: the block falls back to the radix select, reading registers.
+//    or k > 512: the block falls back to the radix select, reading registers.
 //  * exp / division / noise only where the filtered value is not -inf (wave-uniform skips: with top_k = 32 that is 32 of 16384).
 //  * the probability map of debug=True is written straight to its rows of the [B, N, V] map (16-byte stores through an LDS transpose).
 // ------------------------------------------------------------------------------------------------
@@ -358,17 +358,21 @@ __global__ __launch_bounds__(FAST_T) void sample_fast_kernel(const SampleParams 
     if (p.probs) {                                        // rows of 64 KiB: transpose through LDS, 16-byte stores
         float* sv = reinterpret_cast<float*>(smem);
         size_t drow = (size_t)row;
-        if (p.probs_ti) {
-            const int b = row / p.probs_NT;
-            drow = (size_t)b * p.probs_N + (size_t)p.probs_ti[row];
+        bool in_map = true;
+        if (p.probs_ti) {                                 // precondition: 0 <= ti < N (as torch's scatter_ checks); a row outside the map is
+            const int b = row / p.probs_NT;              // skipped (block-uniform), never written out of bounds (scatter_ids_kernel does the same)
+            const int64_t t = p.probs_ti[row];
+            in_map = t >= 0 && t < (int64_t)p.probs_N;
+            drow = (size_t)b * p.probs_N + (size_t)(in_map ? t : 0);
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < FAST_E; ++j) sv[tid + FAST_T * j] = x[j];
         __syncthreads();
         f32x4* dst = reinterpret_cast<f32x4*>(p.probs + drow * V);
+        if (in_map)
 #pragma unroll
-        for (int i = 0; i < SV_MAX / 4 / FAST_T; ++i) dst[tid + FAST_T * i] = *reinterpret_cast<const f32x4*>(sv + 4 * (tid + FAST_T * i));
+            for (int i = 0; i < SV_MAX / 4 / FAST_T; ++i) dst[tid + FAST_T * i] = *reinterpret_cast<const f32x4*>(sv + 4 * (tid + FAST_T * i));
     }
     tot = blk_sum8(tot, sh);
     // gumbel_sort (:834-841): arg-max of (p / sum p) / q, zero-probability entries forced to 0.  First sweep: a = p * rcp(q) (the common

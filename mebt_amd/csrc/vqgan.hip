@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void conv3d_voxel_kernel(const mebt_conv3d_des
 
 // ------------------------------------------------------------------------------------------------
 // The same thin layers on the matrix cores (fp16 mode).  conv3d_voxel_kernel ran them on the vector ALUs: 1.0 ms for the 3 -> 32
-// first layer and 1.9 ms for the 64 -> 3 last layer at batch 16 (12 % of encode + decode; profiles/r04_vqgan16_kernel_table.txt).
+// first layer and 1.9 ms for the 64 -> 3 last layer at batch 16 (12 % of encode + decode; profiles/r04_vqgan16.txt).
 // Both use v_mfma_f32_16x16x32_f16 with the operands swapped (D^T = W A^T: a lane owns 4 consecutive output channels of one voxel).
 //
 // conv3d_first_mfma_kernel (fp32 [B, C, T, H, W] video in, CIN = 3): K = taps x CIN (81) padded to a multiple of 32.  There is no

@@ -359,20 +359,36 @@ class GradReducer:
         if getattr(native, "Wlp", None) is not None:
             native.sync_lowp(force=True)
 
-    def sync_tune_table(self, src=0):
+    def sync_tune_table(self, src=0, force=False):
         """Every rank adopts rank `src`'s table of tuned GEMM configurations (a collective).  Ranks that tune on their own can
         settle on different tiles for the same product — a rank with a slower pick is then the straggler of every later step
          — so in a data-parallel job ONLY rank `src` tunes in situ (`lead_tuning()` switches the others'
         tuner off) and the others replace their table with its table here.  TrainLoop calls this after optimizer steps 1, 2, 4,
-        8, ... and then every 256: unseen signatures (a new bucket of `t`) keep appearing for a while; between two calls a
-        follower launches its heuristic configuration for them (same results, possibly another speed).  Returns the table text."""
+        ..., 64 and then every 64: unseen signatures (a new bucket of `t`) keep appearing for a while; between two calls a
+        follower launches its heuristic configuration for them (same results, possibly another speed).
+        The text only travels when `src`'s table changed since the last call: first one int64 on the device (the
+        table's size in bytes, 0 = unchanged), then — only if it is non-zero — the pickled text.  With the shipped table the
+        normal case is "unchanged": one 8-byte broadcast and one host read per call.  Returns the table text (None when
+        nothing was sent)."""
         from . import _lib
         if not self.active:
             return _lib.tune_table_text()
-        box = [_lib.tune_table_text() if self.rank == src else None]
+        n = 0
+        text = None
+        if self.rank == src:
+            text = _lib.tune_table_text()
+            if force or text != getattr(self, "_tune_sent", None):
+                n = len(text)
+        nccl = dist.get_backend(self.group) == "nccl"
+        head = torch.tensor([n], dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()) if nccl else "cpu")
+        dist.broadcast(head, src=src, group=self.group)
+        if int(head.item()) == 0:
+            return None
+        box = [text if self.rank == src else None]
         dist.broadcast_object_list(box, src=src, group=self.group)
         if self.rank != src:
             _lib.tune_table_merge(box[0], replace=True)
+        self._tune_sent = box[0]
         return box[0]
 
     def lead_tuning(self, src=0):
@@ -383,7 +399,8 @@ class GradReducer:
 
     @staticmethod
     def tune_sync_due(step):
-        return step > 0 and ((step & (step - 1)) == 0 or step % 256 == 0)
+        """optimizer steps after which the followers adopt the lead's table: 1, 2, 4, ..., 64, then every 64"""
+        return step > 0 and (((step & (step - 1)) == 0 and step <= 64) or step % 64 == 0)
 
     def consolidate(self, native, optimizer_state=False):
         """Make the fp32 masters (and, on request, the AdamW moments) complete on every rank: after sharded steps each rank

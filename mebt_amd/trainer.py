@@ -41,6 +41,9 @@ class TrainLoop:
         self.sync_tune = bool(self.reducer.active and os.environ.get("MEBT_DP_SYNC_TUNE", "1") != "0")
         if self.sync_tune:
             self.reducer.lead_tuning()
+        # a benchmark sets this around its timed region (after one explicit sync_tune_table() behind its warm-up): the sync
+        # points are host reads of a broadcast, i.e. they drain the GPU queue of every rank
+        self.hold_tune_sync = False
         self.sharded = bool(self.reducer.active and self.reducer.mode == "sharded")
         wire = (self.sharded and self.reducer.wire == "bf16" and self.accum == 1 and model.compute_dtype == "bf16"
                 and os.environ.get("MEBT_DP_WIRE_GRADS", "1") != "0")
@@ -137,7 +140,7 @@ class TrainLoop:
             main.wait_stream(opt)                                   # the next forward reads the updated weights
         if self.accum > 1:
             nm.set_grad_accumulate(False)
-        if self.sync_tune and red.tune_sync_due(self.step_count):
+        if self.sync_tune and not self.hold_tune_sync and red.tune_sync_due(self.step_count):
             red.sync_tune_table()       # rank 0 is the only rank that tunes GEMM tiles in situ: the others adopt its table
         m.trainer.global_step += 1
         m.global_step += 1

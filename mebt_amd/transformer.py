@@ -601,7 +601,8 @@ class Net2NetTransformer(LightningModuleShim):
         noise = None if self.noise_hook is None else self._noise("exp", (B, NT, V), logits.device)
         # production (no hook): Exp(1) generated inside the kernel, seeded from torch's default generator
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else None
-        if probs_map is not None and not top_p and V == 16384:
+        fast = os.environ.get("MEBT_SAMPLE_FAST", "1") != "0"       # 0: the round-3 kernel for every shape (it has no scattered-map form)
+        if probs_map is not None and not top_p and V == 16384 and fast:
             lg = logits.to(torch.float32).contiguous()
             ids = torch.empty(B, NT, dtype=torch.long, device=lg.device)
             score = torch.empty(B, NT, dtype=torch.float32, device=lg.device)

@@ -520,7 +520,7 @@ def bidirect_sample(P, cfg, batch_size, total_length, step_size, context_size, t
 
 
 def extrapolate(P, cfg, vq_input, total_length, step_size, context_size, temperature, top_k, top_p,
-                vid_n_steps, vid_c_temp, noise_fn):
+                vid_n_steps, vid_c_temp, noise_fn, logits_fn=None):
     """sample_vqgan_transformer_videos.py:96-157 without the VQGAN decode: returns the code map."""
     B, T, H, W = vq_input.shape
     step, ctx = int(step_size * 0.25), int(context_size * 0.25)
@@ -534,7 +534,7 @@ def extrapolate(P, cfg, vq_input, total_length, step_size, context_size, tempera
         nxt = torch.zeros_like(x)
         nxt[:, :ctx] = code_map[-1][:, -ctx:]
         x = sample(P, cfg, nxt.view(B, -1), vid_n_steps, temperature, top_k, top_p, vid_c_temp, noise_fn,
-                   ci=ci, ti=ti, edit=True)[0].view(B, step, H, W)
+                   ci=ci, ti=ti, edit=True, logits_fn=logits_fn)[0].view(B, step, H, W)
         code_map.append(x[:, ctx:].clone())
     return torch.cat(code_map, 1)
 

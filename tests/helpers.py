@@ -87,13 +87,13 @@ def closed_form_hook():
 
 
 def record_measured(name, value, gate, note=""):
-    """Append a measured error figure and its gate to gpurun_out/r04_parity_measured.txt (copied to profiles/ after a GPU run), so
+    """Append a measured error figure and its gate to gpurun_out/parity_measured.txt (copied to profiles/ after a GPU run), so
     that drift of the bf16 bounds is visible from round to round (VERDICT r03 weak #2).  Never fails a test."""
     try:
         root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         d = os.path.join(root, "gpurun_out")
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "r04_parity_measured.txt"), "a") as f:
+        with open(os.path.join(d, "parity_measured.txt"), "a") as f:
             f.write(f"{name}\tmeasured {float(value):.4e}\tgate {float(gate):.4e}\t{note}\n")
     except OSError:
         pass

@@ -147,7 +147,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank_double_batch(dtype, mode, wire, def
 WIRE_BF16_VS_FP32_M_RELL2 = {4: 1e-2, 8: 1.6e-2}      # 8 ranks: 7 roundings on the wire per element; gate = 2 x measured (see profiles/r04_parity_measured.txt)
 
 
-@pytest.mark.parametrize("ranks", [4, 8])
+@pytest.mark.parametrize("ranks", [4, pytest.param(8, marks=pytest.mark.skipif(os.environ.get("MEBT_LONG_TESTS") != "1", reason="MEBT_LONG_TESTS=1: the 8-rank case (31 s; last result in profiles/r05_gpu_suite_long.txt)"))])
 def test_bf16_wire_against_fp32_wire_at_four_ranks(ranks):
     """the default bf16 wire sums N gradients with N - 1 bf16 roundings per element.  Four ranks sharing
     the GPU (batch 1 each), bf16 engine, sharded mode: the same three steps with the gradients reduced in bf16 and in fp32.  Both
@@ -341,6 +341,12 @@ def test_bench_gpus_2_starts_its_own_ranks():
     dp = r["data_parallel"]
     assert dp["dp_mode"] == "sharded" and dp["wire"] == "bf16" and dp["rccl_ranks"] == 2 and dp["dp_fallback"] is None
     assert dp["bytes_on_wire_per_step"] > 1e9 and dp["scaling_efficiency"] > 0 and "exposed_comm_ms" in dp
+    # the line judges itself against the N = 1 headline (the fused step) and carries what a first multi-GPU run needs for diagnosis
+    assert abs(dp["scaling_efficiency"] - dp["one_rank_ms"]["fused_optimizer"] / r["ms_per_step"]) < 2e-3
+    assert abs(dp["scaling_efficiency_vs_separate_optimizer"] - dp["one_rank_ms"]["separate_optimizer"] / r["ms_per_step"]) < 2e-3
+    assert isinstance(dp["comm_env"], dict) and "rccl_version" in dp["comm_env"]
+    waits = dp["exposed_forward_wait_ms_per_bucket"]        # gloo staging is synchronous: the keys exist, the waits are ~0
+    assert waits is None or all(v >= 0 for v in waits.values())
     assert "cuda_initialized=False" in out.stderr
 
 

@@ -191,6 +191,13 @@ def _dp_worker(rank, world, port, ret):
         assert _lib.tune_table_merge("4 3 1536 1024 1024 5\n", overwrite=True) == 0      # unversioned text: another build's codes
         text = red.sync_tune_table()
         assert text == _lib.tune_table_text() and "4 3 1536 1024 1024 100673538" in text and "1664" not in text
+        # the text only travels when rank 0's table changed since the last sync: 8 bytes otherwise
+        assert red.sync_tune_table() is None
+        if rank == 0:
+            assert _lib.tune_table_merge(f"{version}\n4 3 2048 1024 1024 100673539\n", overwrite=True) == 1
+        text2 = red.sync_tune_table()
+        assert text2 == _lib.tune_table_text() and "4 3 2048 1024 1024 100673539" in text2
+        assert [red.tune_sync_due(k) for k in (16, 32, 64, 96, 128, 192)] == [True, True, True, False, True, True]
         assert [red.tune_sync_due(k) for k in (0, 1, 2, 3, 4, 5, 8, 255, 256, 257, 512)] == [False, True, True, False, True, False, True, False, True, False, True]
         if rank == 0:
             ret.put(({k: v.detach().numpy().copy() for k, v in st.P.items()}, float(t)))   # numpy: pickled by value
