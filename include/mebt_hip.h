@@ -77,7 +77,9 @@ int64_t mebt_workspace_bytes(const mebt_model* m, int32_t B, int32_t NC, int32_t
 /* embed + GPT.forward: replaces reference transformer.py:255-283 / :298-322 + gpt.py:234-253.
  * x_ids [B,N] i64 token grid, ci [B,NC] / ti [B,NT] i64 position sets, logits [B,NT,V] fp32 out.
  * training: bit 0 keeps the activations in `ws` for mebt_loss / mebt_backward_*, bit 1 enables
- * dropout (masks keyed by dropout_seed; ignored when all p_drop are 0). */
+ * dropout (masks keyed by dropout_seed; ignored when all p_drop are 0), bit 2 (inference of a bf16 model only): `logits` points at
+ * a bf16 [B,NT,V] buffer and the head stores its fp32 accumulators rounded to bf16 (the sampling loops' draw reads them with
+ * mebt_op_sample_lp; the public logits of reconstruct_mask stay fp32). */
 int mebt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
                  const int64_t* x_ids, const int64_t* ci, const int64_t* ti, float* logits,
                  int32_t training, uint64_t dropout_seed, mebt_stream_t stream);
@@ -220,6 +222,12 @@ int mebt_op_topk_threshold(const float* logits, int32_t top_k, float* kth, int64
 int mebt_op_sample_scatter(const float* logits, const float* noise, uint64_t seed, float temperature, int32_t top_k, int64_t* ids,
                            float* score, float* probs_map, const int64_t* ti, int32_t B, int32_t N, int32_t NT, int32_t V,
                            mebt_stream_t stream);
+/* The same draw on the logits as the head of an in-engine sampling loop wrote them: fp32 (logits_bf16 = 0) or bf16 (1: mebt_forward
+ * with flag 4 — half the bytes of the [rows, V] tensor on both sides).  rows = B * NT; noise = NULL: Exp(1) drawn in the kernel from
+ * `seed`; probs_map + ti (both or neither): the debug=True probability map as in mebt_op_sample_scatter.  V = 16384, no top-p. */
+int mebt_op_sample_lp(const void* logits, int32_t logits_bf16, const float* noise, uint64_t seed, float temperature, int32_t top_k,
+                      int64_t* ids, float* score, float* probs_map, const int64_t* ti, int32_t B, int32_t N, int32_t NT, int32_t V,
+                      mebt_stream_t stream);
 int mebt_op_scatter_ids(int64_t* x, const int64_t* ti, const int64_t* ids, int32_t B, int32_t N, int32_t NT,
                         mebt_stream_t stream);
 /* MaskGen.generate_next_mask + gumbel_top_k (mask_sampler.py:178-246): order targets by
@@ -293,6 +301,10 @@ int mebt_op_cast_f16(const float* src, void* dst, int64_t n, mebt_stream_t strea
  * its scatter-add backward with their algorithmic bytes. */
 int mebt_profile_enable(int32_t on);
 int mebt_profile_read(int32_t family, double* launches, double* total_ms, double* total_flops);
+/* Every GEMM-family launch recorded while profiling was enabled, one text line each (`tag dims... ms gflop`; tag g = one product:
+ * M N K a_kc b_kc epilogue c_f32; p = pair launch: M0 N0 K0 M1 N1 K1 b_kc; w = grouped weight gradients: items, output Ki-elements,
+ * longest K).  Returns the bytes needed incl. the terminating 0 and writes the text when `cap` suffices (negative: HIP error). */
+int64_t mebt_profile_dump(char* buf, int64_t cap);
 /* Data parallel, while profiling is enabled: every wait of a forward for a deferred parameter gather
  * (mebt_model_set_forward_waits) is bracketed by an event pair.  Writes up to `cap` (first layer reading the bucket, ms the
  * compute stream stood still) pairs in launch order and returns how many were recorded (negative: HIP error). */

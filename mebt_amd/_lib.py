@@ -63,6 +63,7 @@ PROTOTYPES = {
     "mebt_op_sample": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "mebt_op_sample_seeded": (c_i32, [c_vp, C.c_uint64, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "mebt_op_sample_scatter": (c_i32, [c_vp, c_vp, C.c_uint64, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "mebt_op_sample_lp": (c_i32, [c_vp, c_i32, c_vp, C.c_uint64, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "mebt_op_wgrad_grouped": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32, c_f32,
                                       c_f32, c_f32, c_i32, c_f32, c_vp]),
     "mebt_op_topk_threshold": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp]),
@@ -90,6 +91,7 @@ PROTOTYPES = {
     "mebt_gemm_tune_alternatives": (c_i64, [C.c_char_p, c_i64]),
     "mebt_profile_enable": (c_i32, [c_i32]),
     "mebt_profile_read": (c_i32, [c_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mebt_profile_dump": (c_i64, [C.c_char_p, c_i64]),
     "mebt_profile_read_waits": (c_i32, [c_i32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
 }
 

@@ -11,6 +11,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <string>
 #include <cstdlib>
 
 namespace {
@@ -121,7 +122,11 @@ static int join_side(mebt_model* m, hipStream_t st);
 // profiling of the GEMM family with HIP events on the launch stream
 // ---------------------------------------------------------------------------------------------------
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops, bytes; int kind = 0; };    // kind 0: GEMM family, 2: embed forward, 3: embed backward
+struct ProfRec {
+    hipEvent_t a, b; double flops, bytes; int kind = 0;      // kind 0: GEMM family, 2: embed forward, 3: embed backward, 4: forward wait
+    int tag = 0;              // kind 0: 'g' single product, 'p' pair, 'w' grouped weight gradients
+    int dims[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // g: M N K a_kc b_kc epilogue c_f32; p: M0 N0 K0 M1 N1 K1 b_kc; w: n, sum M*N, K of the longest reduction
+};
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_ev_pool;
@@ -145,6 +150,7 @@ static int gemm(const mebt_model* m, GemmParams p, hipStream_t st) {
     const bool prof = g_prof_on && p.M > 0 && p.N > 0;
     if (prof) {
         r.a = get_event(); r.b = get_event(); r.flops = 2.0 * p.M * p.N * p.K;
+        r.tag = 'g'; r.dims[0] = p.M; r.dims[1] = p.N; r.dims[2] = p.K; r.dims[3] = p.a_kc; r.dims[4] = p.b_kc; r.dims[5] = p.epilogue; r.dims[6] = p.c_f32;
         const double esz = m->d.dtype == MEBT_BF16 ? 2.0 : 4.0, csz = (p.c_f32 || m->d.dtype == MEBT_F32) ? 4.0 : 2.0;
         r.bytes = ((double)p.M * p.K + (double)p.N * p.K) * esz + (double)p.M * p.N * (csz * (p.C ? 1 : 0) + (p.C2 ? esz : 0) + (p.aux ? esz : 0));
         (void)hipEventRecord(r.a, st);
@@ -164,6 +170,7 @@ static int gemm_pair(const mebt_model* m, const GemmParams& p0_in, const GemmPar
     ProfRec r;
     if (g_prof_on) {
         r.a = get_event(); r.b = get_event(); r.flops = 2.0 * p0.M * p0.N * p0.K + 2.0 * p1.M * p1.N * p1.K;
+        r.tag = 'p'; r.dims[0] = p0.M; r.dims[1] = p0.N; r.dims[2] = p0.K; r.dims[3] = p1.M; r.dims[4] = p1.N; r.dims[5] = p1.K; r.dims[6] = p0.b_kc;
         r.bytes = 0;
         for (const GemmParams* q : {&p0, &p1})
             r.bytes += ((double)q->M * q->K + (double)q->N * q->K) * 2.0 + (double)q->M * q->N * (2.0 * (q->C ? 1 : 0) + (q->aux ? 2.0 : 0));
@@ -193,6 +200,26 @@ extern "C" int mebt_profile_read(int32_t family, double* launches, double* total
     }
     *launches = n; *total_ms = ms; *total_flops = fl;
     return MEBT_OK;
+}
+
+// every GEMM-family launch recorded while profiling was on, one text line each: `tag dims... ms gflop` (tag g: M N K a_kc b_kc epilogue
+// c_f32; p: M0 N0 K0 M1 N1 K1 b_kc; w: items, output Ki-elements, longest K).  Same size protocol as mebt_gemm_tune_export
+// (returns the bytes needed incl. the terminating 0, writes when `cap` suffices).  tools/step_gemm_table.py
+extern "C" int64_t mebt_profile_dump(char* buf, int64_t cap) {
+    std::string text;
+    char line[256];
+    for (auto& r : g_prof) {
+        if (r.kind != 0 || !r.tag) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) return -1;
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return -1;
+        snprintf(line, sizeof line, "%c %d %d %d %d %d %d %d %.5f %.4f\n", (char)r.tag, r.dims[0], r.dims[1], r.dims[2], r.dims[3], r.dims[4], r.dims[5],
+                 r.dims[6], t, r.flops * 1e-9);
+        text += line;
+    }
+    const int64_t need = (int64_t)text.size() + 1;
+    if (buf && cap >= need) memcpy(buf, text.c_str(), (size_t)need);
+    return need;
 }
 
 // the forward's waits for deferred parameter gathers recorded while profiling was on: (first layer that reads the bucket, ms the
@@ -536,6 +563,8 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
     if (!ws || !logits) { mebt_set_error("forward: null pointer"); return MEBT_EINVAL; }
     if (!embedded && (!x_ids || !ti || (NC > 0 && !ci))) { mebt_set_error("forward: null pointer"); return MEBT_EINVAL; }
     const bool drop_on = (training & 2) != 0 && (m->d.embd_pdrop > 0.f || m->d.resid_pdrop > 0.f || m->d.attn_pdrop > 0.f);
+    const bool logits_lp = (training & 4) != 0;
+    if (logits_lp && ((training & 1) || m->d.dtype != MEBT_BF16)) { mebt_set_error("forward: bf16 logits (flag 4) are for inference of a bf16 model"); return MEBT_EINVAL; }
     training = training & 1;
     FwdCtx& x = m->ctx;
     x.valid = false;
@@ -683,7 +712,7 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
     RC(fw_wait(m, m->d.n_layer, st));                      // the head weight
     {
         GemmParams p = gp(x.hf, m->Wop(m->head_w), logits, B * NT, V, d, d, d, V, 1, 1);
-        p.c_f32 = 1;
+        p.c_f32 = logits_lp ? 0 : 1;
         RC(gemm(m, p, st));
     }
     m->fw_waits.clear();                                   // one-shot
@@ -898,9 +927,11 @@ static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd, bool with_col
         const bool prof = g_prof_on;
         if (prof) {
             r.a = get_event(); r.b = get_event(); r.flops = 0; r.bytes = 0;
+            r.tag = 'w'; r.dims[0] = lv.w.n;
             for (int i = 0; i < lv.w.n; ++i) {
                 const GroupedWgrad::Item& it = lv.w.g[i];
                 if (it.K <= 0) continue;
+                r.dims[1] += it.M * it.N / 1024; if (it.K > r.dims[2]) r.dims[2] = it.K;
                 r.flops += 2.0 * it.M * it.N * it.K;
                 // fp32 gradient store, or (optimizer-in-backward) read p,m,v + write p,m,v and the bf16 mirror
                 r.bytes += ((double)it.M * it.K + (double)it.N * it.K) * 2.0 + (double)it.M * it.N * (m->fused_on ? 26.0 : 4.0);

@@ -229,6 +229,7 @@ void mebt_attn_force_generic(int on);
 // ---- sampler (reference transformer.py:826-910, :413-439, mask_sampler.py:178-246) -----------------
 struct SampleParams {
     const float* logits;   // [rows,V]
+    int logits_bf16 = 0;   // `logits` points at bf16 values (the head's bf16 output of the in-engine sampling loops): register kernel only
     const float* noise;    // [rows,V] Exp(1), or null: drawn in the kernel from the counter-based generator keyed by noise_seed
     uint64_t noise_seed = 0;
     float temperature; int top_k; float top_p;   // top_k <= 0 / top_p <= 0: disabled

@@ -237,6 +237,9 @@ __device__ __forceinline__ float blk_max8(float v, float* sh) {
     return fmaxf(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])), fmaxf(fmaxf(sh[4], sh[5]), fmaxf(sh[6], sh[7])));
 }
 
+// LT: float, or bf16_t for the logits the head wrote in bf16 for the sampling loops of a bf16 model (half the bytes on both sides of
+// the [rows, V] tensor; the values are the bf16 roundings of the same fp32 accumulators, converted back exactly on load)
+template <typename LT>
 __global__ __launch_bounds__(FAST_T) void sample_fast_kernel(const SampleParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 64 KiB only when probabilities are written
     __shared__ float sh[8];
@@ -247,11 +250,11 @@ __global__ __launch_bounds__(FAST_T) void sample_fast_kernel(const SampleParams 
     __shared__ float thr;
     constexpr int V = SV_MAX;
     const int tid = threadIdx.x, row = blockIdx.x;
-    const float* lg = p.logits + (size_t)row * V;
+    const LT* lg = reinterpret_cast<const LT*>(p.logits) + (size_t)row * V;
     const float tdiv = p.temperature + 1e-8f;
     float x[FAST_E];
 #pragma unroll
-    for (int j = 0; j < FAST_E; ++j) x[j] = lg[tid + FAST_T * j];
+    for (int j = 0; j < FAST_E; ++j) x[j] = (float)lg[tid + FAST_T * j];
     if (tdiv != 1.0f) {                                   // x / 1.0f == x: the division is skipped only where it is the identity
 #pragma unroll
         for (int j = 0; j < FAST_E; ++j) x[j] = x[j] / tdiv;      // transformer.py:860
@@ -487,10 +490,16 @@ int launch_sample(const SampleParams& p, hipStream_t stream) {
     const bool tp = p.top_p > 0.f;
     static const bool fast_on = [] { const char* e = getenv("MEBT_SAMPLE_FAST"); return !(e && e[0] == '0'); }();
     if (p.probs_ti && (tp || p.V != SV_MAX || !fast_on)) { mebt_set_error("sample: the scattered probability map needs V = 16384 without top-p"); return MEBT_ESHAPE; }
+    if (p.logits_bf16 && (tp || p.V != SV_MAX || !fast_on)) { mebt_set_error("sample: bf16 logits need V = 16384 without top-p (the register kernel)"); return MEBT_ESHAPE; }
     if (!tp && p.V == SV_MAX && fast_on) {
         const size_t fl = p.probs ? (size_t)SV_MAX * 4 : 0;
-        if (fl) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
-        hipLaunchKernelGGL(sample_fast_kernel, dim3(p.rows), dim3(FAST_T), fl, stream, p);
+        if (p.logits_bf16) {
+            if (fl) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_fast_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
+            hipLaunchKernelGGL(sample_fast_kernel<bf16_t>, dim3(p.rows), dim3(FAST_T), fl, stream, p);
+        } else {
+            if (fl) MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_fast_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
+            hipLaunchKernelGGL(sample_fast_kernel<float>, dim3(p.rows), dim3(FAST_T), fl, stream, p);
+        }
         MEBT_HIP_CHECK(hipGetLastError());
         return MEBT_OK;
     }

@@ -136,9 +136,10 @@ class NativeModel:
         return self.ws
 
     # ---- compute -----------------------------------------------------------------------------------
-    def forward(self, x_ids, ci, ti, training=False, logits=None, dropout_seed=0, dropout=True):
+    def forward(self, x_ids, ci, ti, training=False, logits=None, dropout_seed=0, dropout=True, logits_bf16=False):
         """x_ids [B,N] i64, ci [B,NC], ti [B,NT] -> logits [B,NT,V] fp32.  training keeps the
-        activations for backward / the fused loss; dropout (only with training) enables the masks."""
+        activations for backward / the fused loss; dropout (only with training) enables the masks.
+        logits_bf16 (inference of a bf16 model): the head stores bf16 logits — for the sampling loops, whose draw kernel reads them."""
         assert x_ids.dtype == torch.long and ti.dtype == torch.long
         x_ids, ti = x_ids.contiguous(), ti.contiguous()
         ci = ci.contiguous() if ci is not None else None
@@ -147,11 +148,12 @@ class NativeModel:
         NT = ti.shape[1]
         self.sync_lowp()
         ws = self.workspace(B, NC, NT, training)
+        logits_bf16 = bool(logits_bf16) and not training and self.dtype == "bf16"
         if logits is None:
-            logits = torch.empty(B, NT, self.vocab, device=self.device, dtype=torch.float32)
+            logits = torch.empty(B, NT, self.vocab, device=self.device, dtype=torch.bfloat16 if logits_bf16 else torch.float32)
         check(self.lib.mebt_forward(self.h, ptr(ws), ws.numel(), B, N, NC, NT, ptr(x_ids),
                                     ptr(ci) if NC > 0 else None, ptr(ti), ptr(logits),
-                                    (1 | (2 if dropout else 0)) if training else 0,
+                                    (1 | (2 if dropout else 0)) if training else (4 if logits_bf16 else 0),
                                     int(dropout_seed), cur_stream()))
         self._keep = (x_ids, ci, ti, logits)   # the native context holds raw pointers to these
         if training:

@@ -455,6 +455,22 @@ class Net2NetTransformer(LightningModuleShim):
         nm = self._ensure_native()
         return nm.forward(x_ids, context_indices, target_indices, training=False), None
 
+    def _sampling_logits(self, x_indices, context_indices, target_indices, top_p=None, temperature=1.0):
+        """the forward of the sampling loops (sample / draft / revise).  A bf16 model hands its logits to the draw kernel in bf16 —
+        the fp32 [B, NT, V] tensor was written once and read once just to be sampled from (2.1 GB each way at block 8192) — unless
+        the draw needs the generic kernel (top-p, another vocabulary), MEBT_SAMPLE_BF16_LOGITS=0, or the temperature is below 0.5:
+        a bf16 logit carries 8 significant bits, so several candidates can round to the same maximum and a (near-)greedy draw
+        (`draft_t = 0.0` of the shipped scripts) would pick among them by its noise — at temperature >= 0.5 the rounding (<= 0.4 %
+        of a logit) is far below the draw's own randomness.  The fp32 engine (the reference's arithmetic) and the public
+        `reconstruct_mask` keep fp32 logits."""
+        nm = self._ensure_native()
+        if (nm.dtype == "bf16" and not top_p and nm.vocab == 16384 and float(temperature) >= 0.5
+                and os.environ.get("MEBT_SAMPLE_BF16_LOGITS", "1") != "0"
+                and os.environ.get("MEBT_SAMPLE_FAST", "1") != "0"):
+            B = x_indices.shape[0]
+            return nm.forward(x_indices.reshape(B, -1), context_indices, target_indices, training=False, logits_bf16=True)
+        return self.reconstruct_mask(x_indices, context_indices, target_indices)[0]
+
     def top_k_logits(self, logits, k):
         return top_k_logits(logits, k)
 
@@ -602,6 +618,17 @@ class Net2NetTransformer(LightningModuleShim):
         # production (no hook): Exp(1) generated inside the kernel, seeded from torch's default generator
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else None
         fast = os.environ.get("MEBT_SAMPLE_FAST", "1") != "0"       # 0: the round-3 kernel for every shape (it has no scattered-map form)
+        if logits.dtype == torch.bfloat16:                 # the head's bf16 output (_sampling_logits): register kernel, bf16 loads
+            assert not top_p and V == 16384 and fast
+            lg = logits.contiguous()
+            ids = torch.empty(B, NT, dtype=torch.long, device=lg.device)
+            score = torch.empty(B, NT, dtype=torch.float32, device=lg.device)
+            ti = target_indices.contiguous() if probs_map is not None else None
+            nz = None if noise is None else noise.to(torch.float32).contiguous()
+            _lib.check(_lib.load().mebt_op_sample_lp(_lib.ptr(lg), 1, _lib.ptr(nz), int(seed or 0), float(temperature), int(top_k or 0),
+                                                     _lib.ptr(ids), _lib.ptr(score), _lib.ptr(probs_map), _lib.ptr(ti), B,
+                                                     probs_map.shape[1] if probs_map is not None else NT, NT, V, _lib.cur_stream()))
+            return ids, score, None
         if probs_map is not None and not top_p and V == 16384 and fast:
             lg = logits.to(torch.float32).contiguous()
             ids = torch.empty(B, NT, dtype=torch.long, device=lg.device)
@@ -661,7 +688,7 @@ class Net2NetTransformer(LightningModuleShim):
             n_masked = torch.ceil(self.mask_sampler.schedule_fn(tt) * edit_N)
             if int((n_masked > target_indices.shape[-1]).sum()) == B:       # :401-402
                 continue
-            logits, _ = self.reconstruct_mask(partial, context_indices, target_indices, debug)
+            logits = self._sampling_logits(partial, context_indices, target_indices, top_p, temperature)
             target_indices = target_indices.view(B, -1)
             ids, scores, _ = self._sample_tokens(logits, temperature, top_k, top_p, probs_map=partial_probs if debug else None,
                                                  target_indices=target_indices)
@@ -680,7 +707,7 @@ class Net2NetTransformer(LightningModuleShim):
     def _gibbs_pass(self, x, masks, temperature, top_k, top_p, debug):
         partial = x
         for ctx, tgt in zip(*masks):
-            logits, _ = self.reconstruct_mask(partial, ctx.contiguous(), tgt.contiguous(), debug)
+            logits = self._sampling_logits(partial, ctx.contiguous(), tgt.contiguous(), top_p, temperature)
             ids, _, _ = self._sample_tokens(logits, temperature, top_k, top_p)
             partial = self._scatter(partial, tgt.reshape(x.shape[0], -1), ids)
         return partial

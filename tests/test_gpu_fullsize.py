@@ -166,3 +166,22 @@ def test_sample_loop_full_size_invariants():
     a = model.sample(x0, None, 0.0, None, None, 4, None, None, context_temperature=0.0, skips=False)[0]
     b = model.sample(x0, None, 0.0, None, None, 4, None, None, context_temperature=0.0, skips=False)[0]
     assert torch.equal(a, b)
+    # these loops handed bf16 logits from the head to the draw kernel (mebt_forward flag 4 -> mebt_op_sample_lp): they are the fp32
+    # logits of the public forward rounded once (other tile = other summation order: one bf16 ulp at most), and a draw from them
+    # is the draw from those values
+    idx = torch.stack([torch.randperm(1024, generator=torch.Generator().manual_seed(3 + b_)) for b_ in range(2)]).to(DEV)
+    ci_, ti_ = idx[:, :384].contiguous(), idx[:, 384:].contiguous()
+    xr = torch.randint(0, 16384, (2, 1024), generator=torch.Generator().manual_seed(5)).to(DEV)
+    lb = model._sampling_logits(xr, ci_, ti_)
+    l32 = model.reconstruct_mask(xr, ci_, ti_)[0]
+    assert lb.dtype == torch.bfloat16 and l32.dtype == torch.float32 and lb.shape == l32.shape
+    ulp = l32.abs().clamp(min=2.0 ** -126) * 2.0 ** -7
+    assert ((lb.float() - l32).abs() <= ulp).all()
+    assert (lb == l32.bfloat16()).float().mean().item() > 0.99
+    assert model._sampling_logits(xr, ci_, ti_, temperature=1e-8).dtype == torch.float32     # (near-)greedy draws keep fp32 logits
+    import os
+    os.environ["MEBT_SAMPLE_BF16_LOGITS"] = "0"
+    try:
+        assert model._sampling_logits(xr, ci_, ti_).dtype == torch.float32
+    finally:
+        del os.environ["MEBT_SAMPLE_BF16_LOGITS"]

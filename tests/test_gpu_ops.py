@@ -460,6 +460,54 @@ def test_sampler_register_kernel_edges_and_scattered_probability_map():
     np.testing.assert_allclose(pmap.cpu().numpy(), ref_map.numpy(), rtol=3e-5, atol=1e-9)
 
 
+def test_sampler_bf16_logits_same_draw_as_fp32_kernel_on_the_rounded_values():
+    """`mebt_op_sample_lp` on bf16 logits (what the head of a bf16 model hands to the draw in the sampling loops: mebt_forward flag 4)
+    against the oracle and the fp32 kernel on the SAME values converted back to fp32: ids, scores and the scattered probability map
+    identical — the bf16 path changes where the logits are rounded, not the draw (reference transformer.py:826-889 on those values)."""
+    from oracle import mebt_oracle as orc
+    V, B, N, NT = 16384, 2, 11, 6
+    g = torch.Generator().manual_seed(77)
+    lg32 = torch.randn(B * NT, V, generator=g) * 2.5
+    lg32[3, 40:60] = float("-inf")
+    lb = lg32.bfloat16()
+    back = lb.float()
+    nz = torch.empty(B * NT, V).exponential_(generator=g)
+    ti = torch.stack([torch.randperm(N, generator=g)[:NT] for _ in range(B)])
+    lbd, backd, nzd, tid = lb.to(DEV), back.to(DEV), nz.to(DEV), ti.to(DEV)
+    for temp, k in ((1.0, 0), (0.9, 32), (1.0, 600)):
+        ids_r, probs_r = orc.sample_from_logits(back, temp, k or None, None, nz)
+        out = {}
+        for name in ("lp", "f32"):
+            ids = torch.empty(B * NT, dtype=torch.long, device=DEV)
+            score = torch.empty(B * NT, device=DEV)
+            pmap = -torch.ones(B, N, V, device=DEV)
+            if name == "lp":
+                check(lib().mebt_op_sample_lp(ptr(lbd), 1, ptr(nzd), 0, temp, k, ptr(ids), ptr(score), ptr(pmap), ptr(tid), B, N, NT, V, cur_stream()))
+            else:
+                check(lib().mebt_op_sample_scatter(ptr(backd), ptr(nzd), 0, temp, k, ptr(ids), ptr(score), ptr(pmap), ptr(tid), B, N, NT, V, cur_stream()))
+            torch.cuda.synchronize()
+            out[name] = (ids.cpu(), score.cpu(), pmap.cpu())
+        assert torch.equal(out["lp"][0], ids_r) and torch.equal(out["lp"][0], out["f32"][0]), (temp, k)
+        assert torch.equal(out["lp"][1], out["f32"][1]) and torch.equal(out["lp"][2], out["f32"][2]), (temp, k)
+        ref_map = -torch.ones(B, N, V)
+        ref_map.scatter_(1, ti.unsqueeze(-1).expand(-1, -1, V), probs_r.view(B, NT, V))
+        np.testing.assert_allclose(out["lp"][2].numpy(), ref_map.numpy(), rtol=3e-5, atol=1e-9)
+    # without a map, drawn from the in-kernel generator: same ids as the fp32 kernel on the same values and seed
+    ids_a = torch.empty(B * NT, dtype=torch.long, device=DEV)
+    ids_b = torch.empty(B * NT, dtype=torch.long, device=DEV)
+    sc_a, sc_b = torch.empty(B * NT, device=DEV), torch.empty(B * NT, device=DEV)
+    check(lib().mebt_op_sample_lp(ptr(lbd), 1, None, 1234567, 1.0, 32, ptr(ids_a), ptr(sc_a), None, None, B, NT, NT, V, cur_stream()))
+    check(lib().mebt_op_sample_seeded(ptr(backd), 1234567, 1.0, 32, 0.0, ptr(ids_b), ptr(sc_b), None, B * NT, V, cur_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(ids_a, ids_b) and torch.equal(sc_a, sc_b)
+    # fp32 logits through the same entry point
+    check(lib().mebt_op_sample_lp(ptr(backd), 0, None, 1234567, 1.0, 32, ptr(ids_a), ptr(sc_a), None, None, B, NT, NT, V, cur_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(ids_a, ids_b)
+    with pytest.raises(Exception):      # another vocabulary: the register kernel only
+        check(lib().mebt_op_sample_lp(ptr(lbd), 1, None, 1, 1.0, 0, ptr(ids_a), ptr(sc_a), None, None, B, NT, NT, 8192, cur_stream()))
+
+
 @pytest.mark.parametrize("NT,NC,ctemp", [(8192, 0, 2.0), (8128, 64, 0.0), (5000, 3192, 1.3), (33, 7, 4.5)])
 def test_next_mask_kernel_long_rows(NT, NC, ctemp):
     """generate_next_mask at the 128-frame geometry (up to 8192 targets per row; 1024-thread LDS bitonic sort) against the oracle's

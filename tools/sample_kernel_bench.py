@@ -12,13 +12,17 @@ for rows in (1024, 32768):
     ids = torch.empty(rows, dtype=torch.long, device="cuda")
     sc = torch.empty(rows, device="cuda")
     probs = torch.empty(rows, V, device="cuda")
-    for k, wp in ((0, False), (32, False), (0, True), (32, True)):
-        fn = lambda: check(lib.mebt_op_sample_seeded(ptr(lg), 1234, 1.0, k, 0.0, ptr(ids), ptr(sc), ptr(probs) if wp else None, rows, V, cur_stream()))
+    lb = lg.bfloat16()
+    for k, wp, bf in ((0, False, 0), (32, False, 0), (0, True, 0), (32, True, 0), (0, False, 1), (32, False, 1)):
+        if bf:      # the head's bf16 logits of a bf16 model's sampling loops (mebt_op_sample_lp): half the bytes read
+            fn = lambda: check(lib.mebt_op_sample_lp(ptr(lb), 1, None, 1234, 1.0, k, ptr(ids), ptr(sc), None, None, 1, rows, rows, V, cur_stream()))
+        else:
+            fn = lambda: check(lib.mebt_op_sample_seeded(ptr(lg), 1234, 1.0, k, 0.0, ptr(ids), ptr(sc), ptr(probs) if wp else None, rows, V, cur_stream()))
         for _ in range(2): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5): fn()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 5
-        gb = rows * V * 4 * (2 if wp else 1) / 1e9
-        print(f"rows {rows:6d} top_k {k:3d} probs {int(wp)}: {us:9.1f} us  {gb / us * 1e6:7.1f} GB/s")
+        gb = rows * V * (2 if bf else 4) * (2 if wp else 1) / 1e9
+        print(f"rows {rows:6d} top_k {k:3d} probs {int(wp)} {'bf16' if bf else 'fp32'} logits: {us:9.1f} us  {gb / us * 1e6:7.1f} GB/s moved  ({rows * V * 4 / us * 1e-3:7.1f} GB/s fp32-equivalent)")
