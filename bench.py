@@ -268,7 +268,12 @@ def secondary_c4(args, device, lib):
             fl = 64 * 4 * forward_flops_per_sample(uo, 7936, 256)
             out["c4_revise_64_forwards"] = {"batch": 4, "s": round(dt, 3), "forwards_per_s": round(64 / dt, 1), "tflops": round(fl / dt / 1e12, 1),
                                             "frac_of_bf16_mfma_peak": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
-                                            "note": "64 forwards at (NC, NT) = (7936, 256) + sampling + scatter, block 8192", **gemm_share(f)}
+                                            "note": "64 forwards at (NC, NT) = (7936, 256) + sampling + scatter, block 8192; tflops = the reference's "
+                                                    "algorithmic FLOPs (every forward re-projects every context position) / time",
+                                            "kv_cache": None if getattr(um, "_kv_last", None) is None else
+                                            {"context_rows_projected": um._kv_last[0], "context_rows_uncached": um._kv_last[1],
+                                             "note": "latent_enc keys / values of all positions cached per loop (mebt_forward_kvcache): only positions whose token changed are re-projected; MEBT_KV_CACHE=0 disables"},
+                                            **gemm_share(f)}
     if "sample" in legs:
         # the 30-step MaskGIT-style sample at the same geometry (the other C4 inference schedule), cosine mask
         # schedule as the sampling script sets it: NT shrinks from 8192 to 0 over the steps

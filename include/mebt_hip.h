@@ -83,6 +83,19 @@ int64_t mebt_workspace_bytes(const mebt_model* m, int32_t B, int32_t NC, int32_t
 int mebt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
                  const int64_t* x_ids, const int64_t* ci, const int64_t* ti, float* logits,
                  int32_t training, uint64_t dropout_seed, mebt_stream_t stream);
+/* The same forward (inference, bf16 model) for the sampling loops (transformer.py:353-447, :544-663), which call it dozens of times
+ * on token grids that differ in a few hundred positions: the key / value projections of the latent_enc blocks — `contexts` is
+ * read-only through the network (gpt.py:187-192), so a context position's K / V row depends on its token id, its position and the
+ * block's weights only — are kept in a caller-owned cache over ALL N positions, [latent_enc blocks][B][N][2 d] bf16
+ * (mebt_kvcache_bytes).  Each call first recomputes the rows of the positions `dirty` [B, ND] (a subset of every sample's `ci`
+ * row: embedding, LN1, projection on B * ND rows instead of B * NC) and then reads every block's keys / values at `ci`.  The caller
+ * keeps the invariant that a position in `ci` is either in `dirty` or was projected by an earlier call with the token id it still
+ * has; the first call of a loop passes dirty = ci.  Same logits as mebt_forward up to the bf16 rounding of a projection tiled for
+ * another row count.  flags: 0, or 4 = bf16 logits. */
+int64_t mebt_kvcache_bytes(const mebt_model* m, int32_t B, int32_t N);
+int mebt_forward_kvcache(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
+                         const int64_t* x_ids, const int64_t* ci, const int64_t* ti, void* logits, int32_t flags,
+                         void* kv_cache, const int64_t* dirty, int32_t ND, mebt_stream_t stream);
 /* GPT.forward on caller-embedded inputs (reference gpt.py:234-253): sos [B,NS,d], contexts [B,NC,d],
  * targets [B,NT,d] fp32 -> logits [B,NT,V].  Inference (no activations kept); see mebt_gpt_forward_train. */
 int mebt_gpt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t NC, int32_t NT, const float* sos,

@@ -38,6 +38,8 @@ PROTOTYPES = {
     "mebt_model_sync_lowp": (c_i32, [c_vp, c_vp]),
     "mebt_workspace_bytes": (c_i64, [c_vp, c_i32, c_i32, c_i32, c_i32]),
     "mebt_forward": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.c_uint64, c_vp]),
+    "mebt_kvcache_bytes": (c_i64, [c_vp, c_i32, c_i32]),
+    "mebt_forward_kvcache": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
     "mebt_gpt_forward": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mebt_gpt_forward_train": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, C.c_uint64, c_vp]),
     "mebt_gpt_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -155,6 +155,18 @@ struct ChunkDma {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma16(rsrc, lds_addr_of(dst + (wave + NW * i) * 1024), goff[i] + (uint32_t)chunk * step);
     }
+    // the same chunk with its rows taken from positions of a larger buffer: row r of the chunk image <- buffer row sidx[first + r]
+    // (an index list staged in LDS; rows at or beyond `nrows` are zero-filled).  The swizzle belongs to the image row, the address to
+    // the gathered row.  `rsrc` must span the whole buffer of this sample.
+    __device__ __forceinline__ void issue_gather(char* dst, int chunk, int wave, int lane, const int* sidx, int nrows, int ld) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * (wave + NW * i) + (lane >> 3), slot = lane & 7;
+            const int r = chunk * (32 * NW) + row;
+            const uint32_t off = r < nrows ? ((uint32_t)sidx[r] * ld + 8 * (slot ^ swz(row))) * 2 : (uint32_t)MEBT_OOB;
+            dma16(rsrc, lds_addr_of(dst + (wave + NW * i) * 1024), off);
+        }
+    }
 };
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -181,22 +193,37 @@ __global__ __launch_bounds__(NW * SPLIT * 64) void attn_fwd_mfma(const AttnParam
     const int b = blockIdx.z, h = blockIdx.y;
     const int q = blockIdx.x * (NW * 16) + wave * 16 + (lane & 15);
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (size_t)b * p.NQ * p.ldq + h * 64;
-    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (size_t)b * p.NK * p.ldk + h * 64;
-    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * p.NK * p.ldv + h * 64;
+    const bool gather = p.kidx != nullptr;          // keys / values = rows kidx[b, :] of a cache of kidx_rows positions per sample
+    const int krows = gather ? p.kidx_rows : p.NK;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (size_t)b * krows * p.ldk + h * 64;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * krows * p.ldv + h * 64;
     bf16x8 qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = frag_global(Q, q, p.NQ, p.ldq, ks, lane);
     ChunkDma<NW> lk, lv;
-    lk.init(K, p.NK, p.ldk, wave, lane);
-    lv.init(V, p.NK, p.ldv, wave, lane);
+    lk.init(K, krows, p.ldk, wave, lane);
+    lv.init(V, krows, p.ldv, wave, lane);
+    // gathered keys: this sample's index list goes to LDS behind the rings first (plain loads, older than every DMA of the kernel
+    // and waited for here: the counted waits of the loop see DMAs only)
+    int* sidx = reinterpret_cast<int*>(smem_all + SPLIT * NST * SBYTES);
+    if (gather) {
+        const int32_t* gi = p.kidx + (size_t)b * p.NK;
+        for (int i = tid; i < p.NK; i += NW * SPLIT * 64) sidx[i] = gi[i];
+        __syncthreads();
+    }
     const int nchunks_all = (p.NK + CROWS - 1) / CROWS;
     const int nchunks = SPLIT == 1 ? nchunks_all : (nchunks_all - half + SPLIT - 1) / SPLIT;      // this group's chunks: half, half + SPLIT, ...
     const int niter = (nchunks_all + SPLIT - 1) / SPLIT;                                            // barrier rounds of the workgroup
 #pragma unroll
     for (int a = 0; a < NST; ++a)
         if (a < nchunks) {
-            lk.issue(smem + a * SBYTES, a * SPLIT + half, wave);
-            lv.issue(smem + a * SBYTES + CBYTES, a * SPLIT + half, wave);
+            if (gather) {
+                lk.issue_gather(smem + a * SBYTES, a * SPLIT + half, wave, lane, sidx, p.NK, p.ldk);
+                lv.issue_gather(smem + a * SBYTES + CBYTES, a * SPLIT + half, wave, lane, sidx, p.NK, p.ldv);
+            } else {
+                lk.issue(smem + a * SBYTES, a * SPLIT + half, wave);
+                lv.issue(smem + a * SBYTES + CBYTES, a * SPLIT + half, wave);
+            }
         }
     const float c = 0.125f * LOG2E;     // 1/sqrt(64) folded with log2(e)
     const int mtiles = mebt_attn_dmask_tiles(p.NK);
@@ -305,8 +332,13 @@ __global__ __launch_bounds__(NW * SPLIT * 64) void attn_fwd_mfma(const AttnParam
         if (SPLIT == 1 ? ci + NST < nchunks : it + NST < niter) {      // SPLIT: both groups keep the same barrier count
             __builtin_amdgcn_s_barrier();                     // every wave is done reading this stage
             if (ci + NST < nchunks) {
-                lk.issue(stage, (ci + NST) * SPLIT + half, wave);
-                lv.issue(stage + CBYTES, (ci + NST) * SPLIT + half, wave);
+                if (gather) {
+                    lk.issue_gather(stage, (ci + NST) * SPLIT + half, wave, lane, sidx, p.NK, p.ldk);
+                    lv.issue_gather(stage + CBYTES, (ci + NST) * SPLIT + half, wave, lane, sidx, p.NK, p.ldv);
+                } else {
+                    lk.issue(stage, (ci + NST) * SPLIT + half, wave);
+                    lv.issue(stage + CBYTES, (ci + NST) * SPLIT + half, wave);
+                }
             }
         }
         if (++st == NST) st = 0;
@@ -603,11 +635,12 @@ static int check_layout(const AttnParams& p) {
     if ((p.ldq | p.ldk | p.ldv | p.ldo) % 8) { mebt_set_error("mfma attention: row strides must be multiples of 8 elements"); return MEBT_ESHAPE; }
     static bool inited = false;
     if (!inited) {
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * CHUNK_BYTES));
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CHUNK_BYTES));
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CHUNK_BYTES));
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * CHUNK_BYTES));
-        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * CHUNK_BYTES));
+        // the forward kernels may carry a key index list behind their rings (AttnParams::kidx): the whole LDS is admissible
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS));
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS));
         inited = true;
@@ -628,18 +661,20 @@ int launch_attn_fwd_mfma(const AttnParams& p_in, hipStream_t stream) {
     // form wins on every routing (10.7 vs 15.0 us at 512 keys); with 128 (batch 4) the 4-wave form does: 93 vs 112 us at 7936 keys
     const long grid8 = (long)((p.NQ + 127) / 128) * p.H * p.B;
     const bool four = force ? force == 4 : grid8 <= 128;
+    const int xl = p.kidx ? ((p.NK * 4 + 15) & ~15) : 0;       // the key index list of a sample, staged behind the rings
+    if (xl && xl + 4 * CHUNK_BYTES > 160 * 1024) { mebt_set_error("mfma attention: a gathered key set holds at most 8192 keys"); return MEBT_ESHAPE; }
     if (four) {
         const dim3 grid((p.NQ + 63) / 64, p.H, p.B);
         // short key sets: two stages of 128 keys (64 KiB: two workgroups per CU); long ones: four stages, one workgroup per CU
         static const int split_on = [] { const char* e = getenv("MEBT_ATTN_FWD_SPLIT"); return e ? atoi(e) : 1; }();
-        if (p.NK <= 1024) hipLaunchKernelGGL((attn_fwd_mfma<4, 2>), grid, dim3(256), 2 * CHUNK_BYTES, stream, p);
+        if (p.NK <= 1024) hipLaunchKernelGGL((attn_fwd_mfma<4, 2>), grid, dim3(256), 2 * CHUNK_BYTES + xl, stream, p);
         else if (split_on && (long)grid.x * p.H * p.B <= 256)      // one workgroup per CU at most: a second group of waves per query block
-            hipLaunchKernelGGL((attn_fwd_mfma<4, 2, 2>), grid, dim3(512), 4 * CHUNK_BYTES, stream, p);
-        else hipLaunchKernelGGL((attn_fwd_mfma<4, 4>), grid, dim3(256), 4 * CHUNK_BYTES, stream, p);
+            hipLaunchKernelGGL((attn_fwd_mfma<4, 2, 2>), grid, dim3(512), 4 * CHUNK_BYTES + xl, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_mfma<4, 4>), grid, dim3(256), 4 * CHUNK_BYTES + xl, stream, p);
     } else {
         const dim3 grid((p.NQ + BLOCK_ROWS - 1) / BLOCK_ROWS, p.H, p.B);
-        if (p.NK <= CHUNK) hipLaunchKernelGGL((attn_fwd_mfma<8, 1>), grid, dim3(WAVES * 64), 2 * CHUNK_BYTES, stream, p);
-        else hipLaunchKernelGGL((attn_fwd_mfma<8, 2>), grid, dim3(WAVES * 64), 2 * 2 * CHUNK_BYTES, stream, p);
+        if (p.NK <= CHUNK) hipLaunchKernelGGL((attn_fwd_mfma<8, 1>), grid, dim3(WAVES * 64), 2 * CHUNK_BYTES + xl, stream, p);
+        else hipLaunchKernelGGL((attn_fwd_mfma<8, 2>), grid, dim3(WAVES * 64), 2 * 2 * CHUNK_BYTES + xl, stream, p);
     }
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;

@@ -958,6 +958,43 @@ int launch_copy_rows(const void* src, void* dst, long rows, int d, int src_f32, 
     return MEBT_OK;
 }
 
+// Rows of `row_bytes` bytes (a multiple of 16) moved by a per-sample position list idx [B, n]: gather dst[b * n + j] = src[b * npos +
+// idx[b, j]], or scatter dst[b * npos + idx[b, j]] = src[b * n + j] (duplicate-free lists, as every index set of the mask sampler
+// is).  One wave per row, 16 bytes per lane and pass.  Positions outside [0, npos) are skipped.
+namespace {
+__global__ __launch_bounds__(256) void index_rows_kernel(const char* src, char* dst, const int64_t* idx, long rows, int n, int npos, int row_bytes, int scatter) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long b = r / n;
+    const long pos = idx[r];
+    if (pos < 0 || pos >= npos) return;
+    const char* s = src + (size_t)(scatter ? r : b * npos + pos) * row_bytes;
+    char* d = dst + (size_t)(scatter ? b * npos + pos : r) * row_bytes;
+    for (int o = lane * 16; o < row_bytes; o += 1024) *reinterpret_cast<u32x4*>(d + o) = *reinterpret_cast<const u32x4*>(s + o);
+}
+}  // namespace
+namespace {
+__global__ __launch_bounds__(256) void cast_i64_i32_kernel(const int64_t* src, int32_t* dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (int32_t)src[i];
+}
+}  // namespace
+int launch_cast_i64_i32(const int64_t* src, int32_t* dst, size_t n, hipStream_t stream) {
+    if (!n) return MEBT_OK;
+    hipLaunchKernelGGL(cast_i64_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, n);
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+int launch_index_rows(const void* src, void* dst, const int64_t* idx, int B, int n, int npos, int row_bytes, int scatter, hipStream_t stream) {
+    const long rows = (long)B * n;
+    if (rows <= 0) return MEBT_OK;
+    if (row_bytes % 16) { mebt_set_error("index_rows: rows must be a multiple of 16 bytes"); return MEBT_ESHAPE; }
+    hipLaunchKernelGGL(index_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const char*)src, (char*)dst, idx, rows, n, npos, row_bytes, scatter);
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}
+
 int launch_cast_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t stream) {
     if (n == 0) return MEBT_OK;
     if (n % 4) { mebt_set_error("cast: length must be a multiple of 4"); return MEBT_ESHAPE; }

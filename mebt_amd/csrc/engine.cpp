@@ -48,6 +48,7 @@ struct FwdCtx {
     void* ws = nullptr;
     int B = 0, N = 0, NC = 0, NT = 0;
     const int64_t *x_ids = nullptr, *ci = nullptr, *ti = nullptr;
+    int32_t* ci32 = nullptr;         // inference: int32 copy of `ci` (the gathering attention of the key / value cache)
     void *sos0 = nullptr, *ctx = nullptr, *tgt0 = nullptr;
     std::vector<LayerAct> L;
     const void *S_final = nullptr, *T_final = nullptr;
@@ -387,6 +388,7 @@ static void carve(const mebt_model* m, Carve& c, FwdCtx& x, int B, int NC, int N
     x.sos0 = c.take(B * NS * d * e);
     x.ctx = c.take((int64_t)B * NC * d * e);
     x.tgt0 = c.take((int64_t)B * NT * d * e);
+    x.ci32 = training ? nullptr : (int32_t*)c.take((int64_t)B * NC * 4);
     x.L.assign(m->d.n_layer, LayerAct());
     const int64_t layer_base = c.off;
     int64_t layer_max = c.off;
@@ -554,9 +556,14 @@ extern "C" int mebt_model_set_forward_waits(mebt_model* m, int32_t n, const int3
     return MEBT_OK;
 }
 
+// Cache of the latent_enc blocks' key / value projections over ALL positions of the token grid (mebt_forward_kvcache): `contexts` is
+// read-only through the network (gpt.py:187-192), so the K / V row of a context position depends on its token id, its position and
+// the block's weights only — the sampling loops change a few hundred positions per forward and re-project thousands.
+struct KvCacheArgs { void* cache; const int64_t* dirty; int ND; };
+
 static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
                         const int64_t* x_ids, const int64_t* ci, const int64_t* ti, const float* const* embedded,
-                        float* logits, int32_t training, uint64_t dropout_seed, mebt_stream_t stream) {
+                        float* logits, int32_t training, uint64_t dropout_seed, mebt_stream_t stream, const KvCacheArgs* kv = nullptr) {
     if (!m || !m->W) { mebt_set_error("forward: model not bound"); return MEBT_EINVAL; }
     if (B <= 0 || N <= 0 || NC < 0 || NT <= 0) { mebt_set_error("forward: need B > 0, N > 0, NC >= 0, NT > 0"); return MEBT_ESHAPE; }
     if (N > m->d.block_size) { mebt_set_error("forward: sequence longer than block_size (pos_emb rows)"); return MEBT_ESHAPE; }
@@ -566,6 +573,12 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
     const bool logits_lp = (training & 4) != 0;
     if (logits_lp && ((training & 1) || m->d.dtype != MEBT_BF16)) { mebt_set_error("forward: bf16 logits (flag 4) are for inference of a bf16 model"); return MEBT_EINVAL; }
     training = training & 1;
+    const bool kvc = kv && kv->cache;
+    if (kvc && (training || embedded || m->d.dtype != MEBT_BF16 || kv->ND < 0 || kv->ND > NC || (kv->ND > 0 && !kv->dirty))) {
+        mebt_set_error("forward_kvcache: inference of a bf16 model on token ids, with 0 <= ND <= NC");
+        return MEBT_EINVAL;
+    }
+    const int ND = kvc ? kv->ND : 0;
     FwdCtx& x = m->ctx;
     x.valid = false;
     Carve c{(char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255), 0};
@@ -592,10 +605,10 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         x.x_ids = nullptr; x.ci = nullptr; x.ti = nullptr;
     } else {
         EmbedParams ep;
-        ep.x_ids = x_ids; ep.ci = ci; ep.ti = ti;
+        ep.x_ids = x_ids; ep.ci = kvc ? kv->dirty : ci; ep.ti = ti;       // cached: only the re-projected positions are embedded as contexts
         ep.tok_emb = m->P + m->tok_emb; ep.pos_emb = m->P + m->pos_emb; ep.mask_emb = m->P + m->mask_emb; ep.sos_emb = m->P + m->sos_emb;
         ep.sos = x.sos0; ep.ctx = x.ctx; ep.tgt = x.tgt0;
-        ep.B = B; ep.N = N; ep.NC = NC; ep.NT = NT; ep.NS = NS; ep.d = d; ep.vocab = V; ep.block_size = m->d.block_size;
+        ep.B = B; ep.N = N; ep.NC = kvc ? ND : NC; ep.NT = NT; ep.NS = NS; ep.d = d; ep.vocab = V; ep.block_size = m->d.block_size;
         ep.drop = make_drop(dropout_seed, 0, p_emb);       // gpt.py:238-240
         ProfRec r;
         if (g_prof_on) {     // algorithmic bytes: rows read once (fp32 tables), rows written once, the index vectors
@@ -610,11 +623,19 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
     const void* Sv = x.sos0;
     const void* Tv = x.tgt0;
     const void* Cv = x.ctx;          // read-only unless the model has 'maskgit' blocks (gpt.py:191-192)
+    if (kvc && m->has_maskgit) { mebt_set_error("forward_kvcache: 'maskgit' blocks rewrite the contexts"); return MEBT_EINVAL; }
+    int enc_seen = 0;
+    // keys / values of the cached blocks: gathered by the MFMA attention kernel through an int32 copy of `ci` (head size 64, at most
+    // 8192 keys: the list lives in LDS), otherwise copied into the block's contiguous buffer
+    static const bool gather_on = [] { const char* e = getenv("MEBT_KV_GATHER"); return !(e && e[0] == '0'); }();
+    const bool kv_gather = kvc && gather_on && NC > 0 && NC <= 8192 && d / H == 64 && x.ci32 != nullptr;
+    if (kv_gather) RC(launch_cast_i64_i32(ci, x.ci32, (size_t)B * NC, st));
     for (int i = 0; i < m->d.n_layer; ++i) {
         LayerAct& a = x.L[i];
         const LayerOffsets& o = m->lo[i];
         const int mode = m->d.modes[i];
-        const int Mq = B * a.NQ, Mk = B * a.NK;
+        const bool kv_layer = kvc && mode == MEBT_MODE_LATENT_ENC;
+        const int Mq = B * a.NQ, Mk = kv_layer ? B * ND : B * a.NK;       // cached: only the dirty positions are normalised and projected
         RC(fw_wait(m, i, st));                             // a bucket of Linear weights that starts at this block
         a.q_in = (mode == MEBT_MODE_LATENT_DEC) ? Tv : (mode == MEBT_MODE_MASKGIT) ? Cv : Sv;
         // LN1 on query and key with the SAME parameters (gpt.py:180-181), then the projections
@@ -663,13 +684,23 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
             p.bias = m->P + o.bq;
             if (Mk <= 0) set_pf(m, p, o.wp, (int64_t)d * d);
             RC(gemm_pair(m, pk, p, st));         // key/value and query projections in one launch
+            if (kv_layer) {     // dirty rows -> their positions of this block's cache; the block's keys / values = the cache rows at `ci`
+                char* cache = (char*)kv->cache + (size_t)enc_seen * B * N * (2 * d) * 2;
+                RC(launch_index_rows(a.k, cache, kv->dirty, B, ND, N, 2 * d * 2, 1, st));
+                if (!kv_gather) RC(launch_index_rows(cache, a.k, ci, B, NC, N, 2 * d * 2, 0, st));   // no gathering attention for this shape: contiguous copy
+            }
         }
+        if (mode == MEBT_MODE_LATENT_ENC) ++enc_seen;
         // softmax(q k^T / sqrt(hd)) v  (gpt.py:131-137)
         AttnParams ap;
         memset(&ap, 0, sizeof(ap));
         ap.q = a.q; ap.k = a.k; ap.v = a.v; ap.o = a.att; ap.lse = a.lse;
         ap.B = B; ap.H = H; ap.NQ = a.NQ; ap.NK = a.NK; ap.HD = d / H;
         ap.ldq = a.ldqkv_q; ap.ldk = a.ldqkv_k; ap.ldv = a.ldqkv_k; ap.ldo = d;
+        if (kv_layer && kv_gather) {       // the attention kernel reads the cache rows at `ci` itself (index list in LDS): no copy
+            char* cache = (char*)kv->cache + (size_t)(enc_seen - 1) * B * N * (2 * d) * 2;
+            ap.k = cache; ap.v = cache + (size_t)d * 2; ap.kidx = x.ci32; ap.kidx_rows = N;
+        }
         ap.drop = make_drop(dropout_seed, 16 * i + SITE_ATTN, p_att);   // gpt.py:135
         ap.dmask = (p_att > 0.f && training) ? a.dmask : nullptr;
         RC(launch_attn_fwd(ap, dt, st));
@@ -726,6 +757,27 @@ extern "C" int mebt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B
                             const int64_t* x_ids, const int64_t* ci, const int64_t* ti, float* logits,
                             int32_t training, uint64_t dropout_seed, mebt_stream_t stream) {
     return forward_impl(m, ws, ws_bytes, B, N, NC, NT, x_ids, ci, ti, nullptr, logits, training, dropout_seed, stream);
+}
+
+// bytes of the key / value cache of mebt_forward_kvcache for B samples of N positions: [latent_enc blocks][B][N][2 d] bf16
+extern "C" int64_t mebt_kvcache_bytes(const mebt_model* m, int32_t B, int32_t N) {
+    if (!m || B <= 0 || N <= 0) return -1;
+    int n_enc = 0;
+    for (int i = 0; i < m->d.n_layer; ++i) n_enc += m->d.modes[i] == MEBT_MODE_LATENT_ENC;
+    return (int64_t)n_enc * B * N * 2 * m->d.n_embd * 2;
+}
+// mebt_forward (inference, bf16 model) with the latent_enc blocks' keys / values taken from `kv_cache` at the positions `ci`.
+// Before they are read, the rows of the positions dirty [B, ND] (a subset of every sample's `ci` row) are recomputed from x_ids —
+// embedding, LN1 and key / value projection of each latent_enc block, on B * ND rows instead of B * NC — and stored.  The caller
+// keeps the invariant that every position in `ci` either is in `dirty` or was projected by an earlier call with the token id it
+// still has (the first call of a sampling loop passes dirty = ci).  flags: 4 = bf16 logits (see mebt_forward).
+extern "C" int mebt_forward_kvcache(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t N, int32_t NC, int32_t NT,
+                                    const int64_t* x_ids, const int64_t* ci, const int64_t* ti, void* logits, int32_t flags,
+                                    void* kv_cache, const int64_t* dirty, int32_t ND, mebt_stream_t stream) {
+    if (!kv_cache) { mebt_set_error("forward_kvcache: null cache"); return MEBT_EINVAL; }
+    if (flags & ~4) { mebt_set_error("forward_kvcache: inference only (flags: 0 or 4)"); return MEBT_EINVAL; }
+    const KvCacheArgs kv{kv_cache, dirty, ND};
+    return forward_impl(m, ws, ws_bytes, B, N, NC, NT, x_ids, ci, ti, nullptr, reinterpret_cast<float*>(logits), flags, 0, stream, &kv);
 }
 
 extern "C" int mebt_gpt_forward(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, int32_t NC, int32_t NT,

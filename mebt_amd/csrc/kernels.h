@@ -162,6 +162,10 @@ int launch_apply_dropout(const void* src, void* dst, size_t n, int src_f32, int 
 int launch_copy_rows(const void* src, void* dst, long rows, int d, int src_f32, int dst_f32, int s_seg, int s_stride, int s_off,
                      int d_seg, int d_stride, int d_off, hipStream_t stream);
 
+// rows moved by a per-sample position list idx [B, n] (gather: dst[b * n + j] = src[b * npos + idx[b, j]]; scatter: the inverse)
+int launch_cast_i64_i32(const int64_t* src, int32_t* dst, size_t n, hipStream_t stream);
+int launch_index_rows(const void* src, void* dst, const int64_t* idx, int B, int n, int npos, int row_bytes, int scatter, hipStream_t stream);
+
 // out[n] += sum_m X[m,n]   (bias gradients, mask_emb / sos_emb gradients)
 int launch_colsum(const void* X, int M, int N, int ldx, float* out, int dtype, hipStream_t stream);
 
@@ -219,6 +223,10 @@ struct AttnParams {
     // 64*tile + 16*kb + 4*g + r (the 16 score elements one lane of the forward / dQ kernels holds per tile).
     // mebt_attn_dmask_bytes() bytes, or null: hash everywhere.
     uint16_t* dmask = nullptr;
+    // MFMA forward only (the sampling loops' key / value cache, mebt_forward_kvcache): key / value row r of sample b is row
+    // kidx[b * NK + r] of a buffer that holds `kidx_rows` rows per sample (k, v point at sample 0, position 0).  NK <= 8192.
+    const int32_t* kidx = nullptr;
+    int kidx_rows = 0;
 };
 __host__ __device__ static inline int mebt_attn_dmask_tiles(int NK) { return 4 * ((NK + 255) / 256); }
 static inline size_t mebt_attn_dmask_bytes(int B, int H, int NQ, int NK) { return (size_t)B * H * NQ * mebt_attn_dmask_tiles(NK) * 8; }

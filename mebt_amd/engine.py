@@ -160,6 +160,29 @@ class NativeModel:
             self.generation += 1
         return logits
 
+    def new_kv_cache(self, B, N):
+        """the key / value cache of `forward_cached` for B samples of N positions (include/mebt_hip.h: mebt_forward_kvcache)"""
+        nbytes = self.lib.mebt_kvcache_bytes(self.h, int(B), int(N))
+        if nbytes <= 0:
+            return None
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+
+    def forward_cached(self, x_ids, ci, ti, cache, dirty, logits_bf16=False):
+        """inference forward with the latent_enc blocks' keys / values read from `cache` at `ci`; the rows of `dirty` [B, ND]
+        (None: every position of `ci`) are re-projected first.  bf16 models only."""
+        assert self.dtype == "bf16" and x_ids.dtype == torch.long
+        x_ids, ti, ci = x_ids.contiguous(), ti.contiguous(), ci.contiguous()
+        dirty = ci if dirty is None else dirty.contiguous()
+        B, N = x_ids.shape
+        NC, NT, ND = ci.shape[1], ti.shape[1], dirty.shape[1]
+        self.sync_lowp()
+        ws = self.workspace(B, NC, NT, False)
+        logits = torch.empty(B, NT, self.vocab, device=self.device, dtype=torch.bfloat16 if logits_bf16 else torch.float32)
+        check(self.lib.mebt_forward_kvcache(self.h, ptr(ws), ws.numel(), B, N, NC, NT, ptr(x_ids), ptr(ci) if NC > 0 else None, ptr(ti),
+                                            ptr(logits), 4 if logits_bf16 else 0, ptr(cache), ptr(dirty) if ND > 0 else None, ND, cur_stream()))
+        self._keep = (x_ids, ci, ti, logits, dirty)
+        return logits
+
     def gpt_forward(self, sos, contexts, targets):
         """GPT.forward boundary: fp32 embeddings in, logits out (inference)."""
         sos, contexts, targets = (t.to(self.device, torch.float32).contiguous() for t in (sos, contexts, targets))

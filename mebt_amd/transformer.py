@@ -200,6 +200,48 @@ class MebtAdamW(torch.optim.Optimizer):
             g.update(saved)
 
 
+class _KvSession:
+    """One sampling loop's cache of the latent_enc blocks' key / value projections over all N positions (engine:
+    mebt_forward_kvcache).  `contexts` is read-only through the network (reference modules/gpt.py:187-192), so a context position's
+    K / V rows change only when its token id does — the loops (reference transformer.py:353-447, :544-663) re-sample a few hundred
+    positions per forward.  Each forward names the positions to re-project (`dirty`); default = the previous forward's targets (the
+    only ids that changed since), the first forward of a session re-projects every context position.
+    MEBT_KV_CACHE_CHECK=1 (tests): a per-position record of the token id each cache row was computed for, checked against the ids
+    at every context position of every forward (one host synchronisation per forward)."""
+
+    def __init__(self, native, B, N):
+        self.native, self.B, self.N = native, B, N
+        self.cache = native.new_kv_cache(B, N)
+        self.fresh = True
+        self.prev_targets = None
+        self.check = os.environ.get("MEBT_KV_CACHE_CHECK", "0") == "1"
+        self.stamp = torch.full((B, N), -1, dtype=torch.long, device=native.device) if self.check else None
+        self.rows_projected = 0           # context rows re-projected so far (statistics for bench / tests)
+        self.rows_uncached = 0            # ... and what the same forwards project without the cache
+
+    def forward(self, x_ids, ci, ti, dirty, logits_bf16):
+        if self.fresh or ci.shape[1] == 0:
+            d = ci
+        elif dirty is not None:
+            d = dirty
+        else:
+            d = self.prev_targets
+        if d is None:
+            d = ci
+        d = d.reshape(self.B, -1)
+        if self.check:
+            self.stamp.scatter_(1, d, x_ids.gather(1, d))
+            if ci.shape[1]:
+                stale = int((self.stamp.gather(1, ci) != x_ids.gather(1, ci)).sum())
+                assert stale == 0, f"key/value cache: {stale} context positions were projected for another token id"
+        logits = self.native.forward_cached(x_ids, ci, ti, self.cache, d, logits_bf16)
+        self.fresh = False
+        self.prev_targets = ti
+        self.rows_projected += self.B * d.shape[1]
+        self.rows_uncached += self.B * ci.shape[1]
+        return logits
+
+
 class Net2NetTransformer(LightningModuleShim):
     def __init__(self, transformer_config, first_stage_config, mask_config, ckpt_path=None, ignore_keys=[],
                  first_stage_key="video", cond_stage_key="label", pkeep=1.0, sos_token=0):
@@ -455,7 +497,27 @@ class Net2NetTransformer(LightningModuleShim):
         nm = self._ensure_native()
         return nm.forward(x_ids, context_indices, target_indices, training=False), None
 
-    def _sampling_logits(self, x_indices, context_indices, target_indices, top_p=None, temperature=1.0):
+    def _kv_scope(self, B, N):
+        """context manager: the outermost sampling loop of a bf16 model with latent_enc blocks owns a key / value cache (_KvSession);
+        MEBT_KV_CACHE=0 switches it off (every forward then re-projects every context position, as the reference does)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            nm = self._ensure_native()
+            own = (getattr(self, "_kv", None) is None and nm.dtype == "bf16" and os.environ.get("MEBT_KV_CACHE", "1") != "0"
+                   and nm.lib.mebt_kvcache_bytes(nm.h, 1, 1) > 0 and not getattr(nm, "has_maskgit", False))
+            if own:
+                self._kv = _KvSession(nm, B, N)
+            try:
+                yield
+            finally:
+                if own:
+                    self._kv_last = (self._kv.rows_projected, self._kv.rows_uncached)
+                    self._kv = None
+        return scope()
+
+    def _sampling_logits(self, x_indices, context_indices, target_indices, top_p=None, temperature=1.0, dirty=None):
         """the forward of the sampling loops (sample / draft / revise).  A bf16 model hands its logits to the draw kernel in bf16 —
         the fp32 [B, NT, V] tensor was written once and read once just to be sampled from (2.1 GB each way at block 8192) — unless
         the draw needs the generic kernel (top-p, another vocabulary), MEBT_SAMPLE_BF16_LOGITS=0, or the temperature is below 0.5:
@@ -464,10 +526,13 @@ class Net2NetTransformer(LightningModuleShim):
         of a logit) is far below the draw's own randomness.  The fp32 engine (the reference's arithmetic) and the public
         `reconstruct_mask` keep fp32 logits."""
         nm = self._ensure_native()
-        if (nm.dtype == "bf16" and not top_p and nm.vocab == 16384 and float(temperature) >= 0.5
-                and os.environ.get("MEBT_SAMPLE_BF16_LOGITS", "1") != "0"
-                and os.environ.get("MEBT_SAMPLE_FAST", "1") != "0"):
-            B = x_indices.shape[0]
+        lp = (nm.dtype == "bf16" and not top_p and nm.vocab == 16384 and float(temperature) >= 0.5
+              and os.environ.get("MEBT_SAMPLE_BF16_LOGITS", "1") != "0" and os.environ.get("MEBT_SAMPLE_FAST", "1") != "0")
+        B = x_indices.shape[0]
+        kv = getattr(self, "_kv", None)
+        if kv is not None:          # the loop's key / value cache: only `dirty` (default: the previous forward's targets) is re-projected
+            return kv.forward(x_indices.reshape(B, -1), context_indices.reshape(B, -1), target_indices.reshape(B, -1), dirty, lp)
+        if lp:
             return nm.forward(x_indices.reshape(B, -1), context_indices, target_indices, training=False, logits_bf16=True)
         return self.reconstruct_mask(x_indices, context_indices, target_indices)[0]
 
@@ -683,12 +748,23 @@ class Net2NetTransformer(LightningModuleShim):
             history.append(partial.clone())
             V = self.transformer.head.weight.shape[0]
             partial_probs = -torch.ones(B, N, V, device=dev)
+        with self._kv_scope(B, N):
+            return self._sample_loop(B, N, edit_N, partial, context_indices, target_indices, temperature, top_k, top_p, n_steps, strategy,
+                                     context_temperature, ctemp_schedule, debug, history, context_history,
+                                     partial_probs if debug else None)
+
+    def _sample_loop(self, B, N, edit_N, partial, context_indices, target_indices, temperature, top_k, top_p, n_steps, strategy,
+                     context_temperature, ctemp_schedule, debug, history, context_history, partial_probs):
+        nc_done = None                     # context entries whose keys / values the cache already holds (None: nothing yet)
         for t_next in np.linspace(0, 1, n_steps + 1)[1:]:
             tt = torch.full((B,), fill_value=t_next)                        # float32, like reference :398
             n_masked = torch.ceil(self.mask_sampler.schedule_fn(tt) * edit_N)
             if int((n_masked > target_indices.shape[-1]).sum()) == B:       # :401-402
                 continue
-            logits = self._sampling_logits(partial, context_indices, target_indices, top_p, temperature)
+            # generate_next_mask appends the newly fixed tokens to the context (mask_sampler.py:228-233): only they are new to the cache
+            dirty = None if nc_done is None else context_indices[:, nc_done:]
+            logits = self._sampling_logits(partial, context_indices, target_indices, top_p, temperature, dirty=dirty)
+            nc_done = context_indices.shape[1]
             target_indices = target_indices.view(B, -1)
             ids, scores, _ = self._sample_tokens(logits, temperature, top_k, top_p, probs_map=partial_probs if debug else None,
                                                  target_indices=target_indices)
@@ -704,12 +780,25 @@ class Net2NetTransformer(LightningModuleShim):
             return partial.view(B, -1), context_indices, target_indices, history, context_history, partial_probs
         return partial.view(B, -1), context_indices, target_indices
 
-    def _gibbs_pass(self, x, masks, temperature, top_k, top_p, debug):
+    def _gibbs_pass(self, x, masks, temperature, top_k, top_p, debug, kind):
+        """one draft (`kind` = 'draft') or revise pass over its list of (context, target) index sets.  Key / value cache: the only
+        context positions whose token changed since the previous forward are that forward's targets that are context now — by
+        construction the LAST w columns of this context set (mask_sampler.py:334 / :354: revise appends the chunk just re-sampled,
+        draft the chunk just fixed), w = the previous chunk's width."""
         partial = x
-        for ctx, tgt in zip(*masks):
-            logits = self._sampling_logits(partial, ctx.contiguous(), tgt.contiguous(), top_p, temperature)
-            ids, _, _ = self._sample_tokens(logits, temperature, top_k, top_p)
-            partial = self._scatter(partial, tgt.reshape(x.shape[0], -1), ids)
+        B = x.shape[0]
+        prev_tgt = None
+        with self._kv_scope(B, x.shape[1]):
+            for ctx, tgt in zip(*masks):
+                ctx, tgt = ctx.contiguous(), tgt.contiguous()
+                dirty = None
+                if prev_tgt is not None:
+                    w = prev_tgt.shape[1] - (tgt.shape[1] if kind == "draft" else 0)
+                    dirty = ctx[:, ctx.shape[1] - w:] if 0 < w <= ctx.shape[1] else None
+                logits = self._sampling_logits(partial, ctx, tgt, top_p, temperature, dirty=dirty)
+                ids, _, _ = self._sample_tokens(logits, temperature, top_k, top_p)
+                partial = self._scatter(partial, tgt.reshape(B, -1), ids)
+                prev_tgt = tgt
         return partial
 
     def _full_sets(self, B, N, device, context_indices, target_indices):
@@ -728,7 +817,7 @@ class Net2NetTransformer(LightningModuleShim):
         ci, ti = self._full_sets(B, N, x.device, context_indices, target_indices)
         masks = self.mask_sampler.create_gibbs_draft_mask(ci, ti, n_steps, x.device)
         assert not self.transformer.training
-        return self._gibbs_pass(x, masks, temperature, top_k, top_p, debug).view(B, -1)
+        return self._gibbs_pass(x, masks, temperature, top_k, top_p, debug, "draft").view(B, -1)
 
     @torch.no_grad()
     def revise(self, x, c, temperature=1.0, top_k=None, top_p=None, n_steps=8, debug=False, context_indices=None,
@@ -740,7 +829,7 @@ class Net2NetTransformer(LightningModuleShim):
         ci, ti = self._full_sets(B, N, x.device, context_indices, target_indices)
         masks = self.mask_sampler.create_gibbs_revise_mask(ci, ti, n_steps, x.device)
         assert not self.transformer.training
-        return self._gibbs_pass(x, masks, temperature, top_k, top_p, debug).view(B, -1)
+        return self._gibbs_pass(x, masks, temperature, top_k, top_p, debug, "revise").view(B, -1)
 
     @torch.no_grad()
     def draft_and_revise(self, x, c, n_draft=8, draft_t=1.0, draft_k=None, draft_p=None, n_revise=8, revise_t=1.0,
@@ -750,12 +839,13 @@ class Net2NetTransformer(LightningModuleShim):
         B, N = x.shape[0], int(np.prod(x.shape[1:]))
         x = x.reshape(B, N)
         assert not self.transformer.training
-        if not skip_draft:
-            x = self.draft(x, c, draft_t, draft_k, draft_p, n_draft, debug, context_indices, target_indices)
-        if edit:
-            context_indices = target_indices = None
-        for _ in range(M):
-            x = self.revise(x, c, revise_t, revise_k, revise_p, n_revise, debug, context_indices, target_indices)
+        with self._kv_scope(B, N):          # one key / value cache for the draft and every revise pass (the first forward of a pass
+            if not skip_draft:             # re-projects the previous pass's last chunk: _KvSession's default `dirty`)
+                x = self.draft(x, c, draft_t, draft_k, draft_p, n_draft, debug, context_indices, target_indices)
+            if edit:
+                context_indices = target_indices = None
+            for _ in range(M):
+                x = self.revise(x, c, revise_t, revise_k, revise_p, n_revise, debug, context_indices, target_indices)
         return x.view(B, -1)
 
 

@@ -185,3 +185,71 @@ def test_sample_loop_full_size_invariants():
         assert model._sampling_logits(xr, ci_, ti_).dtype == torch.float32
     finally:
         del os.environ["MEBT_SAMPLE_BF16_LOGITS"]
+
+
+def test_key_value_cache_of_the_sampling_loops():
+    """The sampling loops of a bf16 model keep the latent_enc blocks' key / value projections of all N positions (engine:
+    mebt_forward_kvcache; `contexts` is read-only through the network, reference modules/gpt.py:187-192) and re-project only the
+    positions whose token changed.  (1) a cached forward == the plain forward on the same state (same kernels on the attention side;
+    the projection runs on other row counts, i.e. possibly another tile: bf16 rounding of a different summation order at most),
+    first with every context position dirty, then after re-sampling part of the grid with only those positions dirty;
+    (2) draft_and_revise / sample at Sky size under MEBT_KV_CACHE_CHECK=1: every context position of every forward holds the
+    projection of its CURRENT token id (the per-position record of the session), and the loops re-project a small fraction of what
+    the uncached loops project; (3) MEBT_KV_CACHE=0 gives the plain loops."""
+    import os
+    from mebt_amd.transformer import _KvSession
+    torch.manual_seed(23)
+    cfg = presets.sky_16f(dropout=0.0)
+    cfg.model.mask.params.schedule = "cosine"
+    model = presets.build_model(cfg, compute_dtype="bf16").to(DEV).eval()
+    nm = model._ensure_native()
+    B, N = 2, 1024
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 16384, (B, N), generator=g).to(DEV)
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).to(DEV)
+    ci, ti = perm[:, :768].contiguous(), perm[:, 768:].contiguous()
+    os.environ["MEBT_KV_CACHE_CHECK"] = "1"
+    try:
+        ses = _KvSession(nm, B, N)
+        ref = model.reconstruct_mask(x, ci, ti)[0]
+        got = ses.forward(x, ci, ti, None, False)
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() < 2e-2 * scale, ((got - ref).abs().max().item(), scale)
+        assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.97
+        # re-sample the 256 targets, rotate the sets: the old targets become context, 256 old context positions become targets
+        x2 = x.clone()
+        x2.scatter_(1, ti, torch.randint(0, 16384, (B, 256), generator=g).to(DEV))
+        ci2 = torch.cat([ci[:, 256:], ti], 1).contiguous()
+        ti2 = ci[:, :256].contiguous()
+        ref2 = model.reconstruct_mask(x2, ci2, ti2)[0]
+        got2 = ses.forward(x2, ci2, ti2, ti, False)                 # dirty = the re-sampled positions only
+        assert ses.rows_projected == B * (768 + 256) and ses.rows_uncached == B * (768 + 768)
+        assert (got2 - ref2).abs().max().item() < 2e-2 * ref2.abs().max().item()
+        # a stale row is caught by the record: change a context token without declaring it dirty
+        x3 = x2.clone()
+        x3[0, ci2[0, 5]] = (x3[0, ci2[0, 5]] + 1) % 16384
+        with pytest.raises(AssertionError, match="another token id"):
+            ses.forward(x3, ci2, ti2, ti2[:, :0], False)
+        # the loops (the invariant is asserted inside every forward)
+        x0 = torch.zeros(B, 4, 16, 16, dtype=torch.long, device=DEV)
+        out = model.draft_and_revise(x0, None, 4, 1.0, None, None, 4, 1.0, None, None, 2, False)
+        assert out.shape == (B, N) and int(out.min()) >= 0 and int(out.max()) < 16384
+        proj, unc = model._kv_last
+        assert proj < 0.45 * unc, (proj, unc)           # draft 4 + 2 x revise 4: N + 3 * N / 4 ... rows instead of the contexts of 12 forwards
+        out = model.sample(x0, None, 1.0, None, None, 8, None, None, context_temperature=4.5, skips=False)
+        assert out[0].shape == (B, N)
+        proj, unc = model._kv_last
+        assert proj <= B * N and proj < 0.5 * unc, (proj, unc)       # every position enters the context once
+        # revise only, as the shipped draft-and-revise scripts run it (--np_draft): first forward projects N - w rows, the other 2 n - 1 forwards w each
+        out = model.draft_and_revise(torch.randint(0, 16384, (B, 4, 16, 16), generator=g).to(DEV), None, 8, 1.0, None, None, 8, 1.0, None, None, 2, True)
+        proj, unc = model._kv_last
+        assert proj == B * ((N - 128) + 15 * 128) and unc == B * 16 * (N - 128), (proj, unc)
+    finally:
+        del os.environ["MEBT_KV_CACHE_CHECK"]
+    os.environ["MEBT_KV_CACHE"] = "0"
+    try:
+        model._kv_last = None
+        model.sample(x0, None, 1.0, None, None, 4, None, None, context_temperature=4.5, skips=False)
+        assert model._kv_last is None
+    finally:
+        del os.environ["MEBT_KV_CACHE"]
