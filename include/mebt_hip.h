@@ -237,10 +237,14 @@ int mebt_op_sample_scatter(const float* logits, const float* noise, uint64_t see
                            mebt_stream_t stream);
 /* The same draw on the logits as the head of an in-engine sampling loop wrote them: fp32 (logits_bf16 = 0) or bf16 (1: mebt_forward
  * with flag 4 — half the bytes of the [rows, V] tensor on both sides).  rows = B * NT; noise = NULL: Exp(1) drawn in the kernel from
- * `seed`; probs_map + ti (both or neither): the debug=True probability map as in mebt_op_sample_scatter.  V = 16384, no top-p. */
+ * `seed`; probs_map + ti (both or neither): the debug=True probability map as in mebt_op_sample_scatter.  V = 16384, no top-p.
+ * draw: 0 = arg-max p / q with q ~ Exp(1) per element (the reference's arithmetic, transformer.py:826-841: bit-exact ids for an
+ * injected `noise`); 1 (noise = NULL only) = inverse CDF from ONE uniform per row keyed by (seed, row) — a sample of the same
+ * categorical distribution p (what the reference's draw is) without the per-element hash, logarithm and reciprocal: the production
+ * draw of the sampling loops. */
 int mebt_op_sample_lp(const void* logits, int32_t logits_bf16, const float* noise, uint64_t seed, float temperature, int32_t top_k,
                       int64_t* ids, float* score, float* probs_map, const int64_t* ti, int32_t B, int32_t N, int32_t NT, int32_t V,
-                      mebt_stream_t stream);
+                      int32_t draw, mebt_stream_t stream);
 int mebt_op_scatter_ids(int64_t* x, const int64_t* ti, const int64_t* ids, int32_t B, int32_t N, int32_t NT,
                         mebt_stream_t stream);
 /* MaskGen.generate_next_mask + gumbel_top_k (mask_sampler.py:178-246): order targets by

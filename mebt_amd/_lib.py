@@ -65,7 +65,7 @@ PROTOTYPES = {
     "mebt_op_sample": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "mebt_op_sample_seeded": (c_i32, [c_vp, C.c_uint64, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "mebt_op_sample_scatter": (c_i32, [c_vp, c_vp, C.c_uint64, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
-    "mebt_op_sample_lp": (c_i32, [c_vp, c_i32, c_vp, C.c_uint64, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "mebt_op_sample_lp": (c_i32, [c_vp, c_i32, c_vp, C.c_uint64, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "mebt_op_wgrad_grouped": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32, c_f32,
                                       c_f32, c_f32, c_i32, c_f32, c_vp]),
     "mebt_op_topk_threshold": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp]),

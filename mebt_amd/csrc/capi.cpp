@@ -165,9 +165,12 @@ extern "C" int mebt_op_sample_scatter(const float* logits, const float* noise, u
 // bf16 output of a bf16 model, mebt_forward flag 4).  rows = B * NT.  noise = NULL: Exp(1) drawn in the kernel from `seed`.
 // probs_map / ti = NULL: no probabilities are written; otherwise each row's probabilities go to row ti[b, j] of the [B, N, V]
 // map (sample(debug=True), transformer.py:426-436).  V = 16384, no top-p (the register kernel).
+// draw: 0 = arg-max p / q, q ~ Exp(1) per element (the reference's arithmetic, transformer.py:826-841; q = `noise`, or generated per
+// element from `seed`); 1 (noise = NULL only) = inverse CDF from one uniform per row: the same categorical distribution at a
+// fraction of the arithmetic (the production draw of the sampling loops).
 extern "C" int mebt_op_sample_lp(const void* logits, int32_t logits_bf16, const float* noise, uint64_t seed, float temperature, int32_t top_k,
                                  int64_t* ids, float* score, float* probs_map, const int64_t* ti, int32_t B, int32_t N, int32_t NT, int32_t V,
-                                 mebt_stream_t stream) {
+                                 int32_t draw, mebt_stream_t stream) {
     if (!logits || !ids) { mebt_set_error("sample_lp: null pointer"); return MEBT_EINVAL; }
     if ((probs_map != nullptr) != (ti != nullptr)) { mebt_set_error("sample_lp: probs_map and ti go together"); return MEBT_EINVAL; }
     if (B <= 0 || NT <= 0 || (probs_map && N < NT)) { mebt_set_error("sample_lp: need B > 0 and 0 < NT <= N"); return MEBT_ESHAPE; }
@@ -175,6 +178,9 @@ extern "C" int mebt_op_sample_lp(const void* logits, int32_t logits_bf16, const 
     p.logits = reinterpret_cast<const float*>(logits); p.logits_bf16 = logits_bf16 ? 1 : 0; p.noise = noise; p.noise_seed = seed;
     p.temperature = temperature; p.top_k = top_k; p.top_p = 0.f; p.ids = ids; p.score = score; p.probs = probs_map; p.rows = B * NT; p.V = V;
     p.probs_ti = ti; p.probs_N = probs_map ? N : 0; p.probs_NT = probs_map ? NT : 0;
+    if (draw != 0 && draw != 1) { mebt_set_error("sample_lp: draw must be 0 (arg-max p / q) or 1 (inverse CDF)"); return MEBT_EINVAL; }
+    if (draw == 1 && noise) { mebt_set_error("sample_lp: the inverse-CDF draw takes no noise tensor"); return MEBT_EINVAL; }
+    p.icdf = draw;
     return launch_sample(p, S(stream));
 }
 

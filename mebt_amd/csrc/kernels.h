@@ -238,6 +238,8 @@ void mebt_attn_force_generic(int on);
 struct SampleParams {
     const float* logits;   // [rows,V]
     int logits_bf16 = 0;   // `logits` points at bf16 values (the head's bf16 output of the in-engine sampling loops): register kernel only
+    int icdf = 0;          // noise == null only, register kernel only: draw by inverse CDF from ONE uniform per row (seed, row) instead of
+                           // arg-max p / q over per-element Exp(1) noise — the same categorical distribution (sampler.hip)
     const float* noise;    // [rows,V] Exp(1), or null: drawn in the kernel from the counter-based generator keyed by noise_seed
     uint64_t noise_seed = 0;
     float temperature; int top_k; float top_p;   // top_k <= 0 / top_p <= 0: disabled

@@ -252,9 +252,24 @@ __global__ __launch_bounds__(FAST_T) void sample_fast_kernel(const SampleParams 
     const int tid = threadIdx.x, row = blockIdx.x;
     const LT* lg = reinterpret_cast<const LT*>(p.logits) + (size_t)row * V;
     const float tdiv = p.temperature + 1e-8f;
+    // element ownership: thread t holds x[8 g + k] = element 8 t + k + 4096 g (g = 0 .. 3, k = 0 .. 7): four runs of eight consecutive
+    // elements, read with 16-byte loads (one per run for bf16 logits, two for fp32) — 32 four-byte (two-byte) loads per thread before.
+    // Within a thread the element index grows with the register index (the tie rules below rely on it).
     float x[FAST_E];
 #pragma unroll
-    for (int j = 0; j < FAST_E; ++j) x[j] = (float)lg[tid + FAST_T * j];
+    for (int g8 = 0; g8 < FAST_E / 8; ++g8) {
+        const LT* src = lg + 8 * tid + 4096 * g8;
+        if constexpr (sizeof(LT) == 2) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[8 * g8 + k] = (float)v[k];
+        } else {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { x[8 * g8 + k] = lo[k]; x[8 * g8 + 4 + k] = hi[k]; }
+        }
+    }
+    auto elem_of = [&](int j) { return 8 * tid + (j & 7) + 4096 * (j >> 3); };
     if (tdiv != 1.0f) {                                   // x / 1.0f == x: the division is skipped only where it is the identity
 #pragma unroll
         for (int j = 0; j < FAST_E; ++j) x[j] = x[j] / tdiv;      // transformer.py:860
@@ -343,12 +358,24 @@ __global__ __launch_bounds__(FAST_T) void sample_fast_kernel(const SampleParams 
     // compared with, and the arg-max below does not depend on the common factor)
     const float mx = blk_max8(lm, sh);                     // the filter never removes the row maximum
     float se = 0.f;
+    if (p.icdf && !p.noise) {
+        // production draw: exp(x - mx) as one fma + v_exp_f32 (relative error ~1e-6 at |x - mx| <= 20: the probabilities are this
+        // path's own, nothing is compared bit for bit); the injected-noise path below keeps expf, whose values the parity tests pin
+        const float mx2 = mx * 1.4426950408889634f;
 #pragma unroll
-    for (int j = 0; j < FAST_E; ++j) {
-        float e = 0.f;
-        if (__builtin_amdgcn_ballot_w64(x[j] > -INFINITY)) e = expf(x[j] - mx);    // expf(-inf - mx) = 0: skipped per wave where nothing survives
-        x[j] = e;
-        se += e;
+        for (int j = 0; j < FAST_E; ++j) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(x[j], 1.4426950408889634f, -mx2));      // exp2(-inf) = 0
+            x[j] = e;
+            se += e;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < FAST_E; ++j) {
+            float e = 0.f;
+            if (__builtin_amdgcn_ballot_w64(x[j] > -INFINITY)) e = expf(x[j] - mx);    // expf(-inf - mx) = 0: skipped per wave where nothing survives
+            x[j] = e;
+            se += e;
+        }
     }
     se = blk_sum8(se, sh);
     const float inv_se = 1.0f / se;
@@ -370,14 +397,65 @@ __global__ __launch_bounds__(FAST_T) void sample_fast_kernel(const SampleParams 
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < FAST_E; ++j) sv[tid + FAST_T * j] = x[j];
+        for (int g8 = 0; g8 < FAST_E / 8; ++g8) {           // the thread's runs of eight go to LDS as two 16-byte stores each
+            f32x4* d8 = reinterpret_cast<f32x4*>(sv + 8 * tid + 4096 * g8);
+            d8[0] = f32x4{x[8 * g8], x[8 * g8 + 1], x[8 * g8 + 2], x[8 * g8 + 3]};
+            d8[1] = f32x4{x[8 * g8 + 4], x[8 * g8 + 5], x[8 * g8 + 6], x[8 * g8 + 7]};
+        }
         __syncthreads();
         f32x4* dst = reinterpret_cast<f32x4*>(p.probs + drow * V);
         if (in_map)
 #pragma unroll
             for (int i = 0; i < SV_MAX / 4 / FAST_T; ++i) dst[tid + FAST_T * i] = *reinterpret_cast<const f32x4*>(sv + 4 * (tid + FAST_T * i));
     }
+    const float loc = tot;                                // this thread's share of the row's probability mass
     tot = blk_sum8(tot, sh);
+    if (p.icdf && !p.noise) {
+        // Production draw (no injected noise).  The reference draws arg-max p / q with q ~ Exp(1) per element (:826-841), i.e. ONE
+        // sample of the categorical distribution p; per element that costs a hash, a logarithm, a reciprocal and a compare — the
+        // kernel was bound by exactly that arithmetic (983 us per [32768, 16384] draw against 350 us for reading the logits).  The
+        // same distribution from one uniform per row: the first element, in the order thread 0's 32 elements (8 t + k + 4096 g, g major),
+        // thread 1's, ..., whose running sum of p reaches u * sum(p).  Zero-probability (filtered) elements are never chosen; if rounding leaves the
+        // target above the last running sum, the last element with p > 0 is taken.
+        __shared__ float wtot[8];
+        __shared__ int owner_lo, owner_last;
+        uint32_t h = pair_hash(p.noise_seed, 0x5A3B1Fu, (uint64_t)row);
+        h *= 0xC2B2AE35u;
+        h ^= h >> 16;
+        const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float target = u * tot;
+        const int lane = tid & 63, wv = tid >> 6;
+        float incl = loc;                                  // inclusive scan of the thread sums inside the wave (Hillis-Steele)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wtot[wv] = incl;
+        if (tid == 0) { owner_lo = FAST_T; owner_last = -1; }
+        __syncthreads();
+        float base = incl - loc;
+        for (int w = 0; w < wv; ++w) base += wtot[w];
+        const bool has = loc > 0.f;
+        if (has && base + loc >= target) atomicMin(&owner_lo, tid);
+        if (has) atomicMax(&owner_last, tid);
+        __syncthreads();
+        const int owner = owner_lo < FAST_T ? owner_lo : owner_last;     // owner_last >= 0: the row maximum has p > 0
+        if (tid == owner) {
+            float acc = base;
+            int pick = -1;
+#pragma unroll
+            for (int j = 0; j < FAST_E; ++j)
+                if (x[j] > 0.f && (pick < 0 || acc < target)) { acc += x[j]; pick = j; }
+            // `pick` = the first positive element at which the running sum reached the target, else the last positive one
+            float pv = 0.f;
+#pragma unroll
+            for (int j = 0; j < FAST_E; ++j) if (j == pick) pv = x[j];
+            p.ids[row] = elem_of(pick);
+            if (p.score) p.score[row] = pv;
+        }
+        return;
+    }
     // gumbel_sort (:834-841): arg-max of (p / sum p) / q, zero-probability entries forced to 0.  First sweep: a = p * rcp(q) (the common
     // factor 1 / sum p dropped, v_rcp_f32 instead of two IEEE divisions) keeping each thread's best entry with its p and q; the row
     // maximum A of a; then the exact key (p / tot) / q of every thread's best within 4e-6 of A decides (lowest index at equal keys) —
@@ -388,7 +466,7 @@ __global__ __launch_bounds__(FAST_T) void sample_fast_kernel(const SampleParams 
     int e1 = V;
 #pragma unroll
     for (int j = 0; j < FAST_E; ++j) {
-        const int e = tid + FAST_T * j;
+        const int e = elem_of(j);
         const float pe = x[j];
         float a = 0.f, q = 1.f;
         if (__builtin_amdgcn_ballot_w64(pe > 0.f)) {
@@ -490,6 +568,7 @@ int launch_sample(const SampleParams& p, hipStream_t stream) {
     const bool tp = p.top_p > 0.f;
     static const bool fast_on = [] { const char* e = getenv("MEBT_SAMPLE_FAST"); return !(e && e[0] == '0'); }();
     if (p.probs_ti && (tp || p.V != SV_MAX || !fast_on)) { mebt_set_error("sample: the scattered probability map needs V = 16384 without top-p"); return MEBT_ESHAPE; }
+    if (p.icdf && (p.noise || tp || p.V != SV_MAX || !fast_on)) { mebt_set_error("sample: the inverse-CDF draw needs in-kernel noise, V = 16384 and no top-p (the register kernel)"); return MEBT_ESHAPE; }
     if (p.logits_bf16 && (tp || p.V != SV_MAX || !fast_on)) { mebt_set_error("sample: bf16 logits need V = 16384 without top-p (the register kernel)"); return MEBT_ESHAPE; }
     if (!tp && p.V == SV_MAX && fast_on) {
         const size_t fl = p.probs ? (size_t)SV_MAX * 4 : 0;

@@ -76,6 +76,7 @@ class NativeModel:
             self._side = pick_concurrent_stream(torch.cuda.current_stream())
             self.lib.mebt_debug_set_side_stream(self.h, self._side.cuda_stream)
         self.n_layer, self.n_embd, self.vocab, self.n_latent = n_layer, n_embd, vocab, n_latent
+        self.has_maskgit = any(m == "maskgit" for m in modes)      # such blocks rewrite the contexts: no key / value cache
         self.W = self.P = self.gW = self.gP = self.Wlp = None
         self.gWb = None             # bf16 wire-format weight gradients (data-parallel sharded path)
         self.ws = None

@@ -683,16 +683,23 @@ class Net2NetTransformer(LightningModuleShim):
         # production (no hook): Exp(1) generated inside the kernel, seeded from torch's default generator
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else None
         fast = os.environ.get("MEBT_SAMPLE_FAST", "1") != "0"       # 0: the round-3 kernel for every shape (it has no scattered-map form)
-        if logits.dtype == torch.bfloat16:                 # the head's bf16 output (_sampling_logits): register kernel, bf16 loads
+        # Production draw (no injected noise), register kernel: inverse CDF from one uniform per row — a sample of the same categorical
+        # distribution the reference's arg-max p / q, q ~ Exp(1), draws (:826-841), without its per-element hash / log / reciprocal
+        # (include/mebt_hip.h: mebt_op_sample_lp, draw = 1).  MEBT_SAMPLE_ICDF=0: arg-max p / q with in-kernel Exp(1) noise.  With
+        # injected noise (tests, parity) the draw is always the reference's arithmetic.
+        icdf = noise is None and not top_p and V == 16384 and fast and not want_probs and os.environ.get("MEBT_SAMPLE_ICDF", "1") != "0"
+        if logits.dtype == torch.bfloat16 or icdf:         # bf16: the head's bf16 output (_sampling_logits)
             assert not top_p and V == 16384 and fast
-            lg = logits.contiguous()
+            bf = logits.dtype == torch.bfloat16
+            lg = logits.contiguous() if bf else logits.to(torch.float32).contiguous()
             ids = torch.empty(B, NT, dtype=torch.long, device=lg.device)
             score = torch.empty(B, NT, dtype=torch.float32, device=lg.device)
             ti = target_indices.contiguous() if probs_map is not None else None
             nz = None if noise is None else noise.to(torch.float32).contiguous()
-            _lib.check(_lib.load().mebt_op_sample_lp(_lib.ptr(lg), 1, _lib.ptr(nz), int(seed or 0), float(temperature), int(top_k or 0),
+            _lib.check(_lib.load().mebt_op_sample_lp(_lib.ptr(lg), 1 if bf else 0, _lib.ptr(nz), int(seed or 0), float(temperature), int(top_k or 0),
                                                      _lib.ptr(ids), _lib.ptr(score), _lib.ptr(probs_map), _lib.ptr(ti), B,
-                                                     probs_map.shape[1] if probs_map is not None else NT, NT, V, _lib.cur_stream()))
+                                                     probs_map.shape[1] if probs_map is not None else NT, NT, V, 1 if icdf else 0,
+                                                     _lib.cur_stream()))
             return ids, score, None
         if probs_map is not None and not top_p and V == 16384 and fast:
             lg = logits.to(torch.float32).contiguous()

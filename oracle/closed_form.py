@@ -125,3 +125,20 @@ def exp1_counter(seed, rows, V):
     h ^= h >> np.uint64(16)
     u = ((h >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
     return (-np.log(u.astype(np.float64))).astype(np.float32).reshape(rows, V)
+
+
+def uniform_counter(seed, rows):
+    """CPU twin of the per-row uniform of the sampler's inverse-CDF draw (mebt_amd/csrc/sampler.hip: `pair_hash(seed, 0x5A3B1F, row)`
+    + one more multiply / xor-shift round, 24 bits -> u in (0, 1)).  Exact."""
+    idx = np.arange(rows, dtype=np.uint64)
+    seed = np.uint64(seed)
+    M = np.uint64(0xFFFFFFFF)
+    lo, hi = idx & M, idx >> np.uint64(32)
+    h = ((lo ^ (seed & M)) + ((hi + np.uint64(0x5A3B1F)) & M) * np.uint64(0x632BE5AB) + (seed >> np.uint64(32))) & M
+    h = (h * np.uint64(0x9E3779B1)) & M
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x85EBCA77)) & M
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & M
+    h ^= h >> np.uint64(16)
+    return ((h >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)

@@ -482,7 +482,7 @@ def test_sampler_bf16_logits_same_draw_as_fp32_kernel_on_the_rounded_values():
             score = torch.empty(B * NT, device=DEV)
             pmap = -torch.ones(B, N, V, device=DEV)
             if name == "lp":
-                check(lib().mebt_op_sample_lp(ptr(lbd), 1, ptr(nzd), 0, temp, k, ptr(ids), ptr(score), ptr(pmap), ptr(tid), B, N, NT, V, cur_stream()))
+                check(lib().mebt_op_sample_lp(ptr(lbd), 1, ptr(nzd), 0, temp, k, ptr(ids), ptr(score), ptr(pmap), ptr(tid), B, N, NT, V, 0, cur_stream()))
             else:
                 check(lib().mebt_op_sample_scatter(ptr(backd), ptr(nzd), 0, temp, k, ptr(ids), ptr(score), ptr(pmap), ptr(tid), B, N, NT, V, cur_stream()))
             torch.cuda.synchronize()
@@ -496,16 +496,92 @@ def test_sampler_bf16_logits_same_draw_as_fp32_kernel_on_the_rounded_values():
     ids_a = torch.empty(B * NT, dtype=torch.long, device=DEV)
     ids_b = torch.empty(B * NT, dtype=torch.long, device=DEV)
     sc_a, sc_b = torch.empty(B * NT, device=DEV), torch.empty(B * NT, device=DEV)
-    check(lib().mebt_op_sample_lp(ptr(lbd), 1, None, 1234567, 1.0, 32, ptr(ids_a), ptr(sc_a), None, None, B, NT, NT, V, cur_stream()))
+    check(lib().mebt_op_sample_lp(ptr(lbd), 1, None, 1234567, 1.0, 32, ptr(ids_a), ptr(sc_a), None, None, B, NT, NT, V, 0, cur_stream()))
     check(lib().mebt_op_sample_seeded(ptr(backd), 1234567, 1.0, 32, 0.0, ptr(ids_b), ptr(sc_b), None, B * NT, V, cur_stream()))
     torch.cuda.synchronize()
     assert torch.equal(ids_a, ids_b) and torch.equal(sc_a, sc_b)
     # fp32 logits through the same entry point
-    check(lib().mebt_op_sample_lp(ptr(backd), 0, None, 1234567, 1.0, 32, ptr(ids_a), ptr(sc_a), None, None, B, NT, NT, V, cur_stream()))
+    check(lib().mebt_op_sample_lp(ptr(backd), 0, None, 1234567, 1.0, 32, ptr(ids_a), ptr(sc_a), None, None, B, NT, NT, V, 0, cur_stream()))
     torch.cuda.synchronize()
     assert torch.equal(ids_a, ids_b)
     with pytest.raises(Exception):      # another vocabulary: the register kernel only
-        check(lib().mebt_op_sample_lp(ptr(lbd), 1, None, 1, 1.0, 0, ptr(ids_a), ptr(sc_a), None, None, B, NT, NT, 8192, cur_stream()))
+        check(lib().mebt_op_sample_lp(ptr(lbd), 1, None, 1, 1.0, 0, ptr(ids_a), ptr(sc_a), None, None, B, NT, NT, 8192, 0, cur_stream()))
+
+
+def test_sampler_inverse_cdf_draw_is_a_sample_of_the_same_distribution():
+    """The production draw of the sampling loops (mebt_op_sample_lp, draw = 1; no injected noise): ONE uniform per row keyed by
+    (seed, row), the first element — in the kernel's order: thread 0's four runs of eight elements, thread 1's, ... — whose running sum of p
+    reaches u * sum(p).  The reference's draw (arg-max p / q, q ~ Exp(1), transformer.py:826-841) is a sample of the categorical
+    distribution p; so is this.  Checked: (1) against a float64 inverse CDF in the kernel's element order driven by the CPU twin of
+    the uniform (oracle/closed_form.py:uniform_counter): the same element, or — where fp32 rounding of the running sum can move the
+    crossing — a neighbour in that order among the positive-probability elements; (2) score = p[id] of the fp32 kernel's
+    probabilities; (3) top-k: never an element the filter removed; (4) one-hot rows; (5) the empirical distribution over 16384 rows
+    of identical logits (chi-square); (6) determinism per (seed, row)."""
+    from oracle import closed_form as cf
+    from oracle import mebt_oracle as orc
+    V, R = 16384, 64
+    g = torch.Generator().manual_seed(91)
+    logits = torch.randn(R, V, generator=g) * 2.5
+    logits[5] = -float("inf"); logits[5, 777] = 0.3                         # one-hot
+    logits[6, 100:9000] = -float("inf")
+    ld = logits.to(DEV)
+    seed = 0x51ED_0000_1234
+    # kernel order: thread t owns elements 8 t + k + 4096 g (g = 0 .. 3 major, k = 0 .. 7), threads in order
+    order = (8 * torch.arange(512).view(512, 1, 1) + torch.arange(8).view(1, 1, 8) + 4096 * torch.arange(4).view(1, 4, 1)).reshape(-1)
+    for temp, k in ((1.0, 0), (0.8, 32), (1.0, 700)):
+        ids = torch.empty(R, dtype=torch.long, device=DEV)
+        score = torch.empty(R, device=DEV)
+        check(lib().mebt_op_sample_lp(ptr(ld), 0, None, seed, temp, k, ptr(ids), ptr(score), None, None, 1, R, R, V, 1, cur_stream()))
+        torch.cuda.synchronize()
+        ids, score = ids.cpu(), score.cpu()
+        _, probs = orc.sample_from_logits(logits, temp, k or None, None, torch.ones(R, V))
+        u = torch.from_numpy(cf.uniform_counter(seed, R)).double()
+        po = probs.double()[:, order]
+        cum = po.cumsum(1)
+        target = u * cum[:, -1]
+        for r in range(R):
+            pos_idx = (po[r] > 0).nonzero().flatten()
+            exact = int((cum[r] >= target[r]).nonzero().flatten()[0]) if bool((cum[r] >= target[r]).any()) else int(pos_idx[-1])
+            while po[r, exact] == 0:                                        # the crossing element has p > 0 by construction
+                exact += 1
+            got = int((order == ids[r]).nonzero().flatten()[0])
+            assert po[r, got] > 0, (temp, k, r)
+            a, b = int((pos_idx == exact).nonzero().flatten()[0]), int((pos_idx == got).nonzero().flatten()[0])
+            assert abs(a - b) <= 1, (temp, k, r, exact, got)
+            if a != b:                                                      # a neighbour only where the running sum is within rounding of the target
+                lo = min(exact, got)
+                assert abs(float(cum[r, lo] - target[r])) < 2e-5 * float(cum[r, -1]), (temp, k, r)
+        np.testing.assert_allclose(score.numpy(), probs.gather(1, ids.view(R, 1)).squeeze(1).numpy(), rtol=3e-5, atol=1e-12)
+        assert int(ids[5]) == 777
+        ids2 = torch.empty(R, dtype=torch.long, device=DEV)
+        check(lib().mebt_op_sample_lp(ptr(ld), 0, None, seed, temp, k, ptr(ids2), None, None, None, 1, R, R, V, 1, cur_stream()))
+        assert torch.equal(ids2.cpu(), ids)
+        check(lib().mebt_op_sample_lp(ptr(ld), 0, None, seed + 1, temp, k, ptr(ids2), None, None, None, 1, R, R, V, 1, cur_stream()))
+        assert (ids2.cpu() != ids).float().mean().item() > 0.4
+        # bf16 logits: the same draw on the rounded values
+        lb = logits.bfloat16()
+        idb, idf = torch.empty(R, dtype=torch.long, device=DEV), torch.empty(R, dtype=torch.long, device=DEV)
+        lbd, lbf = lb.to(DEV), lb.float().to(DEV)
+        check(lib().mebt_op_sample_lp(ptr(lbd), 1, None, seed, temp, k, ptr(idb), None, None, None, 1, R, R, V, 1, cur_stream()))
+        check(lib().mebt_op_sample_lp(ptr(lbf), 0, None, seed, temp, k, ptr(idf), None, None, None, 1, R, R, V, 1, cur_stream()))
+        assert torch.equal(idb, idf)
+    # distribution: 16384 rows of the SAME logits, 12 elements carry the mass
+    row = torch.full((V,), -30.0)
+    sup = torch.tensor([3, 511, 512, 1000, 4097, 8191, 8192, 12000, 16000, 16383, 700, 701])
+    row[sup] = torch.tensor([2.0, 1.5, 1.0, 0.5, 0.0, -0.5, 1.2, 0.3, -1.0, 0.8, 0.1, 1.7])
+    Rn = 16384
+    many = row.repeat(Rn, 1).to(DEV)
+    ids = torch.empty(Rn, dtype=torch.long, device=DEV)
+    check(lib().mebt_op_sample_lp(ptr(many), 0, None, 987654321, 1.0, 0, ptr(ids), None, None, None, 1, Rn, Rn, V, 1, cur_stream()))
+    torch.cuda.synchronize()
+    p = torch.softmax(row.double(), 0)
+    counts = torch.bincount(ids.cpu(), minlength=V).double()
+    assert counts[sup].sum() >= Rn - 2                                      # the rest of the row carries 2e-10 of the mass
+    chi2 = float((((counts[sup] - Rn * p[sup]) ** 2) / (Rn * p[sup])).sum())
+    assert chi2 < 40.0, chi2                                                # 11 degrees of freedom: P(chi2 > 40) = 4e-5
+    with pytest.raises(Exception):      # the inverse-CDF draw takes no noise tensor
+        nz = torch.ones(R, V, device=DEV)
+        check(lib().mebt_op_sample_lp(ptr(ld), 0, ptr(nz), 1, 1.0, 0, ptr(ids2), None, None, None, 1, R, R, V, 1, cur_stream()))
 
 
 @pytest.mark.parametrize("NT,NC,ctemp", [(8192, 0, 2.0), (8128, 64, 0.0), (5000, 3192, 1.3), (33, 7, 4.5)])
