@@ -36,12 +36,19 @@ def bidirect_sample(model, batch_size, total_length, step_size, context_size, te
     x = torch.zeros(shape, dtype=torch.long, device=dev)
     ci = ti = None
     boot_probs = None
+    # The reference keeps the [B, N, V] probability maps of debug=True (:41-46) only to read them at the final codes (:86-92).  A
+    # position's final code was drawn in the last step that had it as a target, which is also the step that last wrote its map row:
+    # the value read is that draw's own score.  So the drivers track the [B, N] chosen-probability map instead (2.1 GB less written
+    # per step at block 8192); MEBT_BIDIRECT_FULL_MAP=1 keeps the full maps.
+    import os
+    chosen = os.environ.get("MEBT_BIDIRECT_FULL_MAP", "0") != "1"
     if bootstrap > 0:                                       # one token revealed per step, reference :41-42
         x, ci, ti, _, _, boot_probs = model.sample(x, None, 1., None, None, bootstrap, ci, ti, context_temperature=vid_c_temp,
-                                                   skips=False, ctemp_schedule=ctemp_schedule, strategy='bootstrap', debug=True)
+                                                   skips=False, ctemp_schedule=ctemp_schedule, strategy='bootstrap', debug=True,
+                                                   _chosen_probs=chosen)
     x, ci, _, _, _, final_probs = model.sample(x, None, temperature, top_k, top_p, vid_n_steps, ci, ti,
                                                context_temperature=vid_c_temp, skips=False, ctemp_schedule=ctemp_schedule,
-                                               strategy=strategy, debug=True)
+                                               strategy=strategy, debug=True, _chosen_probs=chosen)
     vq = x.reshape(shape)
     code_map = [vq]
     curr_t = step
@@ -65,8 +72,11 @@ def bidirect_sample(model, batch_size, total_length, step_size, context_size, te
     prob_map = final_probs if boot_probs is None else torch.where(final_probs < 0., boot_probs, final_probs)
     # log-probability of the chosen codes of the first window (the reference gathers with the whole code
     # map, which only type-checks when there was no continuation — the case of every shipped script)
-    first = code_map.reshape(batch_size, -1)[:, :prob_map.shape[1]]
-    log["score"] = torch.gather(prob_map, -1, first.unsqueeze(-1)).squeeze(-1).log().sum(-1)
+    if prob_map.dim() == 2:                                 # chosen-probability maps: already the value at the chosen code
+        log["score"] = prob_map.log().sum(-1)
+    else:
+        first = code_map.reshape(batch_size, -1)[:, :prob_map.shape[1]]
+        log["score"] = torch.gather(prob_map, -1, first.unsqueeze(-1)).squeeze(-1).log().sum(-1)
     return log
 
 

@@ -731,8 +731,10 @@ class Net2NetTransformer(LightningModuleShim):
     @torch.no_grad()
     def sample(self, x, c, temperature=1.0, top_k=None, top_p=None, n_steps=8, context_indices=None,
                target_indices=None, strategy='maskgit', context_temperature=4.5, phase_history=None, refine_steps=1,
-               forget_pivot=False, skips=[False, False, False], debug=False, ctemp_schedule='linear', edit=False):
-        """MaskGIT-style iterative decoding (reference :353-447)."""
+               forget_pivot=False, skips=[False, False, False], debug=False, ctemp_schedule='linear', edit=False, _chosen_probs=False):
+        """MaskGIT-style iterative decoding (reference :353-447).  `_chosen_probs` (with debug=True; this package's drivers only):
+        the sixth element of the tuple is a [B, N] map of the probability of the id chosen at each position (-1 where never sampled)
+        instead of the [B, N, V] probability map — all `bidirect_sample` reads from that map is its value at the chosen code."""
         B = x.shape[0]
         N = int(np.prod(x.shape[1:]))
         edit_N = target_indices.shape[1] if edit else N
@@ -754,7 +756,7 @@ class Net2NetTransformer(LightningModuleShim):
         if debug:
             history.append(partial.clone())
             V = self.transformer.head.weight.shape[0]
-            partial_probs = -torch.ones(B, N, V, device=dev)
+            partial_probs = -torch.ones((B, N) if _chosen_probs else (B, N, V), device=dev)
         with self._kv_scope(B, N):
             return self._sample_loop(B, N, edit_N, partial, context_indices, target_indices, temperature, top_k, top_p, n_steps, strategy,
                                      context_temperature, ctemp_schedule, debug, history, context_history,
@@ -773,8 +775,11 @@ class Net2NetTransformer(LightningModuleShim):
             logits = self._sampling_logits(partial, context_indices, target_indices, top_p, temperature, dirty=dirty)
             nc_done = context_indices.shape[1]
             target_indices = target_indices.view(B, -1)
-            ids, scores, _ = self._sample_tokens(logits, temperature, top_k, top_p, probs_map=partial_probs if debug else None,
+            chosen_only = debug and partial_probs is not None and partial_probs.dim() == 2
+            ids, scores, _ = self._sample_tokens(logits, temperature, top_k, top_p, probs_map=partial_probs if debug and not chosen_only else None,
                                                  target_indices=target_indices)
+            if chosen_only:        # the map's value at the chosen id of every current target = the draw's score (:409, :426-436)
+                partial_probs.scatter_(1, target_indices, scores)
             partial = self._scatter(partial, target_indices, ids)
             ctemp = context_temperature * CTEMP_SCHEDULES[ctemp_schedule](t_next)   # :440
             if debug:
