@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.29 TB/s measured with a float4 copy, same guide)
-TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 --pmc summaries, newest first
+TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")     # committed rocprofv3 --pmc summaries, newest first
 
 
 def synthetic_batch(B, shape, rank, device):
