@@ -244,6 +244,12 @@ def test_key_value_cache_of_the_sampling_loops():
         out = model.draft_and_revise(torch.randint(0, 16384, (B, 4, 16, 16), generator=g).to(DEV), None, 8, 1.0, None, None, 8, 1.0, None, None, 2, True)
         proj, unc = model._kv_last
         assert proj == B * ((N - 128) + 15 * 128) and unc == B * 16 * (N - 128), (proj, unc)
+        # the script drivers on top of `sample`: bootstrap + continuation windows with a fixed context, and extrapolate(edit=True)
+        from mebt_amd.sampling import bidirect_sample, extrapolate
+        log = bidirect_sample(model, B, 32, 16, 8, temperature=1.0, top_k=32, top_p=None, vid_n_steps=4, vid_c_temp=2.0, bootstrap=3)
+        assert tuple(log["code_maps"].shape) == (B, 8, 16, 16) and bool(torch.isfinite(log["score"]).all())
+        log = extrapolate(model, torch.randint(0, 16384, (B, 4, 16, 16), generator=g).to(DEV), 32, 16, 8, temperature=0.9, top_k=64, vid_n_steps=3, vid_c_temp=2.5)
+        assert tuple(log["code_maps"].shape) == (B, 8, 16, 16)
     finally:
         del os.environ["MEBT_KV_CACHE_CHECK"]
     os.environ["MEBT_KV_CACHE"] = "0"
