@@ -226,9 +226,13 @@ void mebt_attn_force_generic(int) {}
         default: mebt_set_error("attention: head size must be 32, 64 or 128"); return MEBT_ESHAPE; \
     }
 
+// does the forward of this (dtype, head size) run on the MFMA kernels, i.e. can it gather its keys / values (AttnParams::kidx)?
+bool attn_fwd_can_gather(int dtype, int HD) { return dtype == MEBT_BF16 && HD == 64 && !g_force_generic; }
+
 int launch_attn_fwd(const AttnParams& p, int dtype, hipStream_t stream) {
     if (p.B <= 0 || p.NQ <= 0) return MEBT_OK;
     if (dtype == MEBT_BF16 && p.HD == 64 && !g_force_generic && p.NK > 0) return launch_attn_fwd_mfma(p, stream);
+    if (p.kidx && p.NK > 0) { mebt_set_error("attention: gathered keys / values (kidx) need the MFMA forward (bf16, head size 64)"); return MEBT_ESHAPE; }
     if (dtype == MEBT_BF16) { DISPATCH_HD(run_fwd, bf16_t) } else { DISPATCH_HD(run_fwd, float) }
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;

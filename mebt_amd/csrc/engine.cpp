@@ -627,8 +627,8 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
     int enc_seen = 0;
     // keys / values of the cached blocks: gathered by the MFMA attention kernel through an int32 copy of `ci` (head size 64, at most
     // 8192 keys: the list lives in LDS), otherwise copied into the block's contiguous buffer
-    static const bool gather_on = [] { const char* e = getenv("MEBT_KV_GATHER"); return !(e && e[0] == '0'); }();
-    const bool kv_gather = kvc && gather_on && NC > 0 && NC <= 8192 && d / H == 64 && x.ci32 != nullptr;
+    const bool gather_on = [] { const char* e = getenv("MEBT_KV_GATHER"); return !(e && e[0] == '0'); }();      // read per forward (tests flip it)
+    const bool kv_gather = kvc && gather_on && NC > 0 && NC <= 8192 && attn_fwd_can_gather(dt, d / H) && x.ci32 != nullptr;
     if (kv_gather) RC(launch_cast_i64_i32(ci, x.ci32, (size_t)B * NC, st));
     for (int i = 0; i < m->d.n_layer; ++i) {
         LayerAct& a = x.L[i];

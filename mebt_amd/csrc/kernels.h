@@ -233,6 +233,7 @@ static inline size_t mebt_attn_dmask_bytes(int B, int H, int NQ, int NK) { retur
 int launch_attn_fwd(const AttnParams& p, int dtype, hipStream_t stream);
 int launch_attn_bwd(const AttnParams& p, int dtype, hipStream_t stream);
 void mebt_attn_force_generic(int on);
+bool attn_fwd_can_gather(int dtype, int HD);     // the forward of this (dtype, head size) honours AttnParams::kidx
 
 // ---- sampler (reference transformer.py:826-910, :413-439, mask_sampler.py:178-246) -----------------
 struct SampleParams {

@@ -225,6 +225,14 @@ def test_key_value_cache_of_the_sampling_loops():
         got2 = ses.forward(x2, ci2, ti2, ti, False)                 # dirty = the re-sampled positions only
         assert ses.rows_projected == B * (768 + 256) and ses.rows_uncached == B * (768 + 768)
         assert (got2 - ref2).abs().max().item() < 2e-2 * ref2.abs().max().item()
+        # the attention kernel gathering the cache rows itself == the cache rows copied into a contiguous buffer first (MEBT_KV_GATHER=0):
+        # the same values in the same chunk order, bit for bit
+        os.environ["MEBT_KV_GATHER"] = "0"
+        try:
+            got2c = ses.forward(x2, ci2, ti2, ti2[:, :0], False)
+        finally:
+            del os.environ["MEBT_KV_GATHER"]
+        assert torch.equal(got2c, ses.forward(x2, ci2, ti2, ti2[:, :0], False))
         # a stale row is caught by the record: change a context token without declaring it dirty
         x3 = x2.clone()
         x3[0, ci2[0, 5]] = (x3[0, ci2[0, 5]] + 1) % 16384
