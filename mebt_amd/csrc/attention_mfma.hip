@@ -159,11 +159,16 @@ struct ChunkDma {
     // (an index list staged in LDS; rows at or beyond `nrows` are zero-filled).  The swizzle belongs to the image row, the address to
     // the gathered row.  `rsrc` must span the whole buffer of this sample.
     __device__ __forceinline__ void issue_gather(char* dst, int chunk, int wave, int lane, const int* sidx, int nrows, int ld) const {
+        int src[4];                 // the four index reads first: one LDS round trip in front of the four DMAs, not one in front of each
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = chunk * (32 * NW) + 8 * (wave + NW * i) + (lane >> 3);
+            src[i] = r < nrows ? sidx[r] : -1;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 8 * (wave + NW * i) + (lane >> 3), slot = lane & 7;
-            const int r = chunk * (32 * NW) + row;
-            const uint32_t off = r < nrows ? ((uint32_t)sidx[r] * ld + 8 * (slot ^ swz(row))) * 2 : (uint32_t)MEBT_OOB;
+            const uint32_t off = src[i] >= 0 ? ((uint32_t)src[i] * ld + 8 * (slot ^ swz(row))) * 2 : (uint32_t)MEBT_OOB;
             dma16(rsrc, lds_addr_of(dst + (wave + NW * i) * 1024), off);
         }
     }
@@ -363,6 +368,217 @@ __global__ __launch_bounds__(NW * SPLIT * 64) void attn_fwd_mfma(const AttnParam
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[e][r] = o[e][r] * a0 + mg[4 * e + r] * a1;
+        m = mn;
+    }
+    if (q < p.NQ) {
+        const float inv = 1.0f / l;
+        bf16_t* O = reinterpret_cast<bf16_t*>(p.o) + ((size_t)b * p.NQ + q) * p.ldo + h * 64;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store4<bf16_t>(O + 16 * e + 4 * g, o[e] * inv);
+        if (p.lse && g == 0) p.lse[((size_t)b * p.H + h) * p.NQ + q] = m * 0.6931471805599453f + logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, long key sets on a grid of at most one workgroup per CU: two groups of four waves in ANTI-PHASE
+// ------------------------------------------------------------------------------------------------
+// Same decomposition as attn_fwd_mfma<4, 2, 2> (64 query rows per workgroup, group s = waves 4s .. 4s+3 takes the 128-key chunks
+// s, s + 2, ... through a ring of its own, (m, l, O) merged through LDS at the end), different schedule.  There the two waves that
+// share a SIMD (wave w of each group) ran the same part of a pass at the same time — both wait for their score MFMAs, both run the
+// softmax's vector instructions, both wait for the P V MFMAs: ~6000 cycles per 128 keys for ~1700 of work per wave, with keys and
+// values resident (tools/attn_layout_experiment.py).  Here a pass is cut into a MATRIX phase (O += V(i-1) P(i-1), then S(i) = K(i) Q
+// and the row maxima of S(i): 32 MFMAs) and a VECTOR phase (softmax of S(i) to the packed P(i), rescale of O; the DMA of K(i+2) and
+// V(i+1) is issued at its start), one workgroup barrier between phases, and group 1 runs one phase behind group 0: a SIMD's matrix
+// pipe and vector ALU are each busy for one of its two waves in every phase.  P(i) is applied one pass late, so K(i) and V(i-1) are
+// what a matrix phase reads; a stage's K half is refilled with K(i+2) and the other stage's V half with V(i+1) right after it.
+__global__ __launch_bounds__(512) void attn_fwd_pp(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    constexpr int NW = 4, CROWS = 2 * TILE, CBYTES = 2 * TILE_BYTES, SBYTES = 2 * CBYTES;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave_all >> 2, wave = wave_all & 3;
+    char* smem = smem_all + half * (2 * SBYTES);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * (NW * 16) + wave * 16 + (lane & 15);
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (size_t)b * p.NQ * p.ldq + h * 64;
+    const bool gather = p.kidx != nullptr;
+    const int krows = gather ? p.kidx_rows : p.NK;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (size_t)b * krows * p.ldk + h * 64;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * krows * p.ldv + h * 64;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = frag_global(Q, q, p.NQ, p.ldq, ks, lane);
+    ChunkDma<NW> lk, lv;
+    lk.init(K, krows, p.ldk, wave, lane);
+    lv.init(V, krows, p.ldv, wave, lane);
+    int* sidx = reinterpret_cast<int*>(smem_all + 4 * SBYTES);
+    if (gather) {
+        const int32_t* gi = p.kidx + (size_t)b * p.NK;
+        for (int i = tid; i < p.NK; i += 512) sidx[i] = gi[i];
+        __syncthreads();
+    }
+    const int nchunks_all = (p.NK + CROWS - 1) / CROWS;
+    const int n = (nchunks_all - half + 1) / 2;                     // this group's chunks: half, half + 2, ...
+    const int n0 = (nchunks_all + 1) / 2, n1 = nchunks_all / 2;
+    const int nphase = max(2 * n0 + 1, 2 * n1 + 2);                // group 0: phases 0 .. 2 n0, group 1: 1 .. 2 n1 + 1
+    auto issue_k = [&](int j) {
+        if (gather) lk.issue_gather(smem + (j & 1) * SBYTES, 2 * j + half, wave, lane, sidx, p.NK, p.ldk);
+        else lk.issue(smem + (j & 1) * SBYTES, 2 * j + half, wave);
+    };
+    auto issue_v = [&](int j) {
+        if (gather) lv.issue_gather(smem + (j & 1) * SBYTES + CBYTES, 2 * j + half, wave, lane, sidx, p.NK, p.ldv);
+        else lv.issue(smem + (j & 1) * SBYTES + CBYTES, 2 * j + half, wave);
+    };
+    if (0 < n) { issue_k(0); issue_v(0); }
+    if (1 < n) issue_k(1);
+    if (n <= 0) wait_vm<0>();                   // K(0) has landed (this wave's pieces); V(0) and K(1) may stay in flight
+    else if (1 < n) wait_vm<8>();
+    else wait_vm<4>();
+    const float c = 0.125f * LOG2E;
+    const int mtiles = mebt_attn_dmask_tiles(p.NK);
+    FragOffsets fo;
+    fo.init(lane);
+    f32x4 o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f32x4{0, 0, 0, 0};
+    float m = -INFINITY, l = 0.f, tmax = -INFINITY;
+    f32x4 s[2][4];
+    bf16x8 pf[2][2];
+
+    for (int ph = 0; ph < nphase; ++ph) {
+        __builtin_amdgcn_s_barrier();
+        const int r = ph - half;
+        if (r < 0 || r > 2 * n) continue;
+        const int i = r >> 1;
+        if (!(r & 1)) {
+            // ---- matrix phase: O += V(i-1) P(i-1);  S(i) = K(i) Q and its row maxima.  All sixteen K fragments are requested first
+            // (64 registers) and the V fragments of a 32-key step while the previous step's MFMAs run: the LDS round trips overlap the
+            // matrix pipe instead of alternating with it (four reads, wait, four MFMAs was what the compiler made of the plain loop nest)
+            bf16x8 kf[2][4][2];
+            if (i < n) {
+                const char* sK = smem + (i & 1) * SBYTES;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) kf[u][kb][ks] = fo.row_frag(sK + u * TILE_BYTES, kb, ks);
+            }
+            if (i > 0) {
+                const char* sV = smem + ((i - 1) & 1) * SBYTES + CBYTES;
+                bf16x8 vf[2][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vf[0][e] = fo.col_frag(sV, e, 0);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int u = st >> 1, kk = st & 1;
+                    if (st + 1 < 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vf[(st + 1) & 1][e] = fo.col_frag(sV + ((st + 1) >> 1) * TILE_BYTES, e, (st + 1) & 1);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = MFMA(vf[st & 1][e], pf[u][kk], o[e]);
+                }
+            }
+            if (i < n) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) s[u][kb] = MFMA(kf[u][kb][0], qf[0], (f32x4{0, 0, 0, 0}));
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) s[u][kb] = MFMA(kf[u][kb][1], qf[1], s[u][kb]);
+                const int k0 = (2 * i + half) * CROWS;
+                if (k0 + CROWS > p.NK) {        // ragged end only: keys beyond NK are masked out
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr)
+                                if (k0 + 64 * u + 16 * kb + 4 * g + rr >= p.NK) s[u][kb][rr] = -INFINITY;
+                }
+                float t = -INFINITY;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) t = fmaxf(t, s[u][kb][rr]);
+                tmax = group_max(t) * c;
+            }
+        } else {
+            // ---- vector phase: refill the halves the matrix phase has just released, softmax of S(i)
+            const bool more_v = i + 1 < n, more_k = i + 2 < n;
+            if (more_v) issue_v(i + 1);
+            if (more_k) issue_k(i + 2);
+            const int k0 = (2 * i + half) * CROWS;
+            const float mn = fmaxf(m, tmax);
+            float ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) { s[u][kb][rr] = fast_exp2(fmaf(s[u][kb][rr], c, -mn)); ps += s[u][kb][rr]; }
+            ps = group_sum(ps);
+            if (__builtin_amdgcn_ballot_w64(mn != m)) {
+                const float alpha = fast_exp2(m - mn);
+                l *= alpha;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] *= alpha;
+            }
+            l += ps;
+            m = mn;
+            if (p.drop.thresh) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (k0 + 64 * u >= p.NK) break;
+                    const uint64_t dbase = (((uint64_t)b * p.H + h) * p.NQ + q) * p.NK + k0 + 64 * u;
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {
+                        const f32x4 keep = drop_keep4(p.drop, dbase + 16 * kb + 4 * g);
+                        s[u][kb] *= keep;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) bits |= (keep[rr] != 0.f ? 1u : 0u) << (4 * kb + rr);
+                    }
+                    if (p.dmask && q < p.NQ)
+                        p.dmask[((((size_t)b * p.H + h) * p.NQ + q) * mtiles + ((k0 >> 6) + u)) * 4 + g] = (uint16_t)bits;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) pf[u][kk] = pack_acc(s[u][2 * kk], s[u][2 * kk + 1]);
+            // what the next matrix phase reads — K(i+1), V(i) — is older than this phase's refills
+            if (more_v && more_k) wait_vm<8>();
+            else if (more_v || more_k) wait_vm<4>();
+            else wait_vm<0>();
+        }
+    }
+    // merge the groups: group 1 parks (m, l, O) in LDS, group 0 combines
+    __syncthreads();
+    float* mg = reinterpret_cast<float*>(smem_all) + (size_t)(wave * 64 + lane) * 18;
+    if (half == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) mg[4 * e + rr] = o[e][rr];
+        mg[16] = m; mg[17] = l;
+    }
+    __syncthreads();
+    if (half == 1) return;
+    {
+        const float m1 = mg[16], l1 = mg[17];
+        const float mn = fmaxf(m, m1);
+        const float a0 = m == mn ? 1.f : fast_exp2(m - mn), a1 = m1 == mn ? 1.f : fast_exp2(m1 - mn);
+        l = l * a0 + l1 * a1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) o[e][rr] = o[e][rr] * a0 + mg[4 * e + rr] * a1;
         m = mn;
     }
     if (q < p.NQ) {
@@ -641,6 +857,7 @@ static int check_layout(const AttnParams& p) {
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS));
         MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS));
         inited = true;
@@ -668,8 +885,10 @@ int launch_attn_fwd_mfma(const AttnParams& p_in, hipStream_t stream) {
         // short key sets: two stages of 128 keys (64 KiB: two workgroups per CU); long ones: four stages, one workgroup per CU
         static const int split_on = [] { const char* e = getenv("MEBT_ATTN_FWD_SPLIT"); return e ? atoi(e) : 1; }();
         if (p.NK <= 1024) hipLaunchKernelGGL((attn_fwd_mfma<4, 2>), grid, dim3(256), 2 * CHUNK_BYTES + xl, stream, p);
-        else if (split_on && (long)grid.x * p.H * p.B <= 256)      // one workgroup per CU at most: a second group of waves per query block
-            hipLaunchKernelGGL((attn_fwd_mfma<4, 2, 2>), grid, dim3(512), 4 * CHUNK_BYTES + xl, stream, p);
+        else if (split_on && (long)grid.x * p.H * p.B <= 256) {    // one workgroup per CU at most: a second group of waves per query block
+            if (split_on == 2) hipLaunchKernelGGL((attn_fwd_mfma<4, 2, 2>), grid, dim3(512), 4 * CHUNK_BYTES + xl, stream, p);   // both groups in phase (A/B)
+            else hipLaunchKernelGGL(attn_fwd_pp, grid, dim3(512), 4 * CHUNK_BYTES + xl, stream, p);
+        }
         else hipLaunchKernelGGL((attn_fwd_mfma<4, 4>), grid, dim3(256), 4 * CHUNK_BYTES + xl, stream, p);
     } else {
         const dim3 grid((p.NQ + BLOCK_ROWS - 1) / BLOCK_ROWS, p.H, p.B);
