@@ -492,8 +492,16 @@ def test_resume_equals_uninterrupted_training(tmp_path):
     for (k, p), (_, q) in zip(ref.state_dict().items(), b.state_dict().items()):
         # attn.key.bias has a mathematically zero gradient: AdamW normalises its rounding noise (atomic summation order)
         # into +-lr steps, so it is only bounded, not reproduced
-        tol = 6 * 1e-3 if k.endswith("attn.key.bias") else 1e-6 * (1 + p.abs().max().item())
-        assert (p - q).abs().max().item() <= tol, k
+        # elsewhere the atomically accumulated gradients (embedding rows, bias column sums) differ in the last bit between two runs
+        # and AdamW turns that into up to ~1e-6 on single elements whose gradient is near its epsilon (seen: 1.15e-6 on one
+        # tok_emb element): single elements are bounded well below one step (lr = 1e-3), the mean at rounding level — a resume
+        # that lost the moments, the step count, the warm-up position or a seed moves every element by ~lr
+        d = (p.float() - q.float()).abs()
+        if k.endswith("attn.key.bias"):
+            assert d.max().item() <= 6e-3, k
+        else:
+            assert d.max().item() <= 5e-5, (k, d.max().item())
+            assert d.mean().item() <= 1e-6 * (1 + p.abs().max().item()), (k, d.mean().item())
     for u, v in zip(loop.native.adam, lb.native.adam):
         assert (u - v).abs().max().item() <= 1e-6 * (1e-3 + u.abs().max().item())
     # a run that restarts the counters (weights only) is NOT the same: the warm-up LR and bias correction restart
