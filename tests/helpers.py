@@ -97,3 +97,16 @@ def record_measured(name, value, gate, note=""):
             f.write(f"{name}\tmeasured {float(value):.4e}\tgate {float(gate):.4e}\t{note}\n")
     except OSError:
         pass
+
+
+def assert_same_trajectory(a, b, what, lr=1e-3):
+    """Two runs of the same training steps that differ only in the order of atomically accumulated sums (embedding rows, bias
+    column sums): last-bit differences of a gradient become up to ~1e-6 on single parameters whose gradient sits near AdamW's
+    epsilon, so single elements are bounded at a twentieth of one step and the mean at rounding level — a run that dropped a
+    moment, a step count, a seed or a schedule position moves every element by ~lr."""
+    import torch
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    d = (a - b).abs()
+    scale = 1.0 + a.abs().max().item()
+    assert d.max().item() <= 0.05 * lr * scale, (what, d.max().item())
+    assert d.mean().item() <= 1e-6 * scale, (what, d.mean().item())

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.helpers import assert_same_trajectory
+
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
@@ -259,7 +261,7 @@ def test_rccl_executes_the_collective_path_with_one_rank(dtype, mode, wire, dela
     for k, v in model.state_dict().items():
         d = np.abs(v.cpu().numpy() - sd1[k]).max()
         if dtype == "f32" and not k.endswith("attn.key.bias"):
-            assert d <= 1e-6 * (1 + np.abs(sd1[k]).max()), (k, d)          # one rank: the "sum" is the gradient itself
+            assert_same_trajectory(v, sd1[k], k, lr=lr)                     # one rank: the "sum" is the gradient itself
         else:
             assert d <= 6.6 * lr, (k, d)                                      # bf16 wire: sign flips of ~0 gradients, three steps
 
