@@ -24,11 +24,12 @@ from mebt_amd.trainer import TrainLoop
 from oracle import mebt_oracle as orc
 
 DEV = "cuda"
-# The default run has to fit the driver's time limit with room to spare (617 s of 1200): of every family of
-# oracle-checked full-size cases ONE stays on by default (the benchmarked precision / the hardest shape), its siblings run with
-# MEBT_LONG_TESTS=1 (their last results: profiles/r05_gpu_suite_long.txt).
-LONG = os.environ.get("MEBT_LONG_TESTS") == "1"
-long_only = pytest.mark.skipif(not LONG, reason="MEBT_LONG_TESTS=1 runs the sibling cases of the default ones")
+# The default run has to fit the driver's time limit with room to spare (617 s of 1200).  With the oracle
+# side's CPU threads bounded (tests/conftest.py: 128 default threads ran 5 x slower than 16 on the GPU boxes) the whole suite with
+# every sibling case of the oracle-checked full-size families takes ~6 min, so they run by default again; MEBT_LONG_TESTS=0 keeps
+# ONE case per family (the benchmarked precision / the hardest shape: ~4 min), MEBT_LONG_TESTS=1 adds the ≈20-minute UCF schedule.
+LONG = os.environ.get("MEBT_LONG_TESTS", "") != "0"
+long_only = pytest.mark.skipif(not LONG, reason="MEBT_LONG_TESTS=0: only one case per full-size family")
 SITE = {"attn": 0, "proj": 1, "mlp": 2, "emb_sos": 0xFFFF0, "emb_ctx": 0xFFFF1, "emb_tgt": 0xFFFF2}
 
 # bf16 (MFMA bf16, fp32 accumulate) against the fp32 oracle at C2, B = 6.  Bounds are <= 2x what this test measured
