@@ -679,6 +679,7 @@ static int forward_impl(mebt_model* m, void* ws, int64_t ws_bytes, int32_t B, in
         } else {
             GemmParams pk = gp(a.kn, m->Wop(o.wk), a.k, Mk, 2 * d, d, d, d, 2 * d, 1, 1);
             pk.bias = m->P + o.bk;
+            pk.coarse_m = kv_layer ? 1 : 0;        // B * ND changes at every step of a sampling loop: few tuner signatures, not one per 128 rows
             set_pf(m, pk, o.wp, (int64_t)d * d);
             GemmParams p = gp(a.qn, m->Wop(o.wq), a.q, Mq, d, d, d, d, d, 1, 1);
             p.bias = m->P + o.bq;

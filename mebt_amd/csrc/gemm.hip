@@ -10,6 +10,9 @@
 #include <vector>
 #include <string>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 
 void mebt_gemm_cfg_kk(const GemmParams&, int, int, int, int, hipStream_t);
 void mebt_gemm_cfg_kr(const GemmParams&, int, int, int, int, hipStream_t);
@@ -150,6 +153,12 @@ static int launch_bf16_splitk(const GemmParams& p, int tbm, int tbn, int ring, i
 // cache) and guarded by a mutex; tuning itself runs under the same lock with the CALLER's scratch and events of its own.
 typedef std::vector<int> TuneKey;
 static int tune_bucket(int v) { return v <= 128 ? v : ((v + 127) / 128) * 128; }
+static int tune_bucket_m(const GemmParams& p) {          // GemmParams::coarse_m: next power of two above 128 rows
+    if (!p.coarse_m || p.M <= 128) return tune_bucket(p.M);
+    int b = 128;
+    while (b < p.M) b <<= 1;
+    return b;
+}
 static std::map<TuneKey, int> g_tuned;      // -> (tbm << 20) | (tbn << 8) | staging
 // the fastest few candidates of every signature tuned in this process, with their isolated (cold) times: what tools/step_tune.py
 // tries one by one IN the train step (a candidate that is second in isolation can be first between its real neighbours)
@@ -228,6 +237,12 @@ static void tune_init() {
     g_tune_log = l ? atoi(l) : 0;                     // 1: decisions, 2: every candidate
     g_tune_cache = getenv("MEBT_GEMM_TUNE_CACHE");
     if (g_tune_cache && g_tune_cache[0]) {
+        // Data-parallel ranks inherit the same variable and run this concurrently: the read / version check / restart of the file is
+        // done under an exclusive flock on a sibling lock file, a file of another version is MOVED to <cache>.v<its version> (never
+        // truncated: it may be a file the user pointed at by mistake) and the fresh file appears by rename.
+        const std::string lock_path = std::string(g_tune_cache) + ".lock";
+        const int lock_fd = open(lock_path.c_str(), O_CREAT | O_RDWR, 0644);
+        if (lock_fd >= 0) (void)flock(lock_fd, LOCK_EX);
         bool fresh = true;
         if (FILE* f = fopen(g_tune_cache, "r")) {
             std::string text;
@@ -236,18 +251,29 @@ static void tune_init() {
             while ((got = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, got);
             fclose(f);
             fresh = text.empty();
-            if (!fresh && tune_text_version(text.c_str()) != MEBT_TUNE_VERSION) {
+            const int ver = fresh ? MEBT_TUNE_VERSION : tune_text_version(text.c_str());
+            if (!fresh && ver != MEBT_TUNE_VERSION) {
                 // a cache written by a build whose variant codes meant something else (or an unversioned round-3 file): nothing of it
-                // is usable, and appending to it would only grow a file every later process ignores again — start it over
-                fprintf(stderr, "[mebt gemm autotune] %s holds a table of another version: rewritten for version %d\n", g_tune_cache, MEBT_TUNE_VERSION);
-                if (FILE* w = fopen(g_tune_cache, "w")) fclose(w);
-                fresh = true;
+                // is usable, and appending to it would only grow a file every later process ignores again — start a new one
+                const std::string keep = std::string(g_tune_cache) + ".v" + std::to_string(ver);
+                const bool moved = rename(g_tune_cache, keep.c_str()) == 0;
+                fprintf(stderr, "[mebt gemm autotune] %s holds a table of version %d: %s, new table for version %d\n", g_tune_cache, ver,
+                        moved ? ("kept as " + keep).c_str() : "could not be moved aside (left in place, not used)", MEBT_TUNE_VERSION);
+                if (!moved) g_tune_cache = nullptr;       // never truncate a file that is not ours
+                fresh = moved;
             } else {
                 tune_parse(text.c_str(), true);
             }
         }
-        if (fresh)
-            if (FILE* f = fopen(g_tune_cache, "a")) { fprintf(f, "1 -1 %d\n", MEBT_TUNE_VERSION); fclose(f); }
+        if (fresh && g_tune_cache) {
+            const std::string tmp = std::string(g_tune_cache) + ".tmp" + std::to_string((long)getpid());
+            if (FILE* f = fopen(tmp.c_str(), "w")) {
+                fprintf(f, "1 -1 %d\n", MEBT_TUNE_VERSION);
+                fclose(f);
+                if (rename(tmp.c_str(), g_tune_cache) != 0) (void)remove(tmp.c_str());
+            }
+        }
+        if (lock_fd >= 0) { (void)flock(lock_fd, LOCK_UN); close(lock_fd); }
     } else {
         g_tune_cache = nullptr;
     }
@@ -500,7 +526,7 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
             tune_init();
             const TuneKey key{p.a_kc | (p.b_kc << 1) | (p.epilogue << 2) | (p.c_f32 << 5) | ((p.bias != nullptr) << 6) | ((p.drop.thresh != 0) << 7) |
                                   ((p.C == nullptr) << 8),        // bit 8: no primary output (inference GELU product: half the store bytes)
-                              tune_bucket(p.M), p.N, tune_bucket(p.K)};
+                              tune_bucket_m(p), p.N, tune_bucket(p.K)};
             auto it = g_tuned.find(key);
             if (it == g_tuned.end() && g_autotune && idempotent && tune_scratch_of(p.scratch)) {
                 heuristic_config(p, tbm, tbn, staging);
@@ -560,7 +586,7 @@ int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipS
         std::unique_lock<std::mutex> lk(g_tune_mutex);
         tune_init();
         const TuneKey key{0x20000000 | p0.b_kc | (p0.epilogue << 2) | (p1.epilogue << 5) | ((p0.drop.thresh != 0) << 8),
-                          tune_bucket(p0.M), p0.N, tune_bucket(p0.K), tune_bucket(p1.M), p1.N, tune_bucket(p1.K)};
+                          tune_bucket_m(p0), p0.N, tune_bucket(p0.K), tune_bucket_m(p1), p1.N, tune_bucket(p1.K)};
         auto it = g_tuned.find(key);
         if (it == g_tuned.end() && g_autotune && tune_scratch_of(p0.scratch)) {
             TuneRun tr;

@@ -59,6 +59,8 @@ struct GemmParams {
     const void* pf2 = nullptr;              // a second range, 4 lines per thread: saved forward activations the NEXT kernels of the
     unsigned pf2_bytes = 0;                 // backward chain read (they were written a whole forward + half a backward ago)
     unsigned* pf_sink = nullptr;            // always null at run time: keeps the prefetch loads alive for the compiler
+    int coarse_m = 0;                       // host side only: the tuner buckets M to the next power of two instead of the next multiple of 128 (a row count that
+                                            // differs at almost every call: the re-projected rows of the key / value cache)
     int narrow_store = 0;                   // experiments (MEBT_EPI_NARROW=1): 8-byte instead of 16-byte bf16 stores in the plain epilogues
     float* rowsum_a = nullptr;              // internal (grouped weight gradients): [M] fp32 += sum_k A(m, k), added by the tiles of column 0
     unsigned long long* stamps = nullptr;   // diagnostics only (mebt_debug_gemm_stamps): [workgroup][4] s_memtime at entry / first tile landed /

@@ -140,3 +140,26 @@ class TokenData:
         return self._dataloader(False)
 
     test_dataloader = val_dataloader
+
+    @staticmethod
+    def add_data_specific_args(parent_parser):
+        """the data flags of the reference's scripts (data.py:307-327), so that their command lines parse unchanged"""
+        import argparse
+        parser = argparse.ArgumentParser(parents=[parent_parser], add_help=False)
+        parser.add_argument('--data_path', type=str, default='')
+        parser.add_argument('--sequence_length', type=int, default=16)
+        parser.add_argument('--resolution', type=int, default=128)
+        parser.add_argument('--batch_size', type=int, default=32)
+        parser.add_argument('--num_workers', type=int, default=8)
+        parser.add_argument('--image_channels', type=int, default=3)
+        parser.add_argument('--smap_cond', type=int, default=0)
+        parser.add_argument('--smap_only', action='store_true')
+        parser.add_argument('--text_cond', action='store_true')
+        parser.add_argument('--vtokens', action='store_true')
+        parser.add_argument('--vtokens_pos', action='store_true')
+        parser.add_argument('--spatial_length', type=int, default=15)
+        parser.add_argument('--sample_every_n_frames', type=int, default=1)
+        parser.add_argument('--image_folder', action='store_true')
+        parser.add_argument('--stft_data', action='store_true')
+        parser.add_argument('--preprocessed_hdf5', action='store_true')
+        return parser

@@ -364,24 +364,21 @@ class GradReducer:
         settle on different tiles for the same product — a rank with a slower pick is then the straggler of every later step
          — so in a data-parallel job ONLY rank `src` tunes in situ (`lead_tuning()` switches the others'
         tuner off) and the others replace their table with its table here.  TrainLoop calls this after optimizer steps 1, 2, 4,
-        ..., 64 and then every 64: unseen signatures (a new bucket of `t`) keep appearing for a while; between two calls a
+        ..., 256 and then every 256: unseen signatures (a new bucket of `t`) keep appearing for a while; between two calls a
         follower launches its heuristic configuration for them (same results, possibly another speed).
-        The text only travels when `src`'s table changed since the last call: first one int64 on the device (the
-        table's size in bytes, 0 = unchanged), then — only if it is non-zero — the pickled text.  With the shipped table the
-        normal case is "unchanged": one 8-byte broadcast and one host read per call.  Returns the table text (None when
-        nothing was sent)."""
+        The text only travels when some rank's table differs from the one last adopted: one int64 flag per rank,
+        MAX-reduced on the device - rank `src` raises it when its table changed since the last call, a follower when ITS table is
+        no longer the adopted one (a local `tune_table_merge` / cache import) - then, only if it is up, the pickled text from
+        `src`.  With the shipped table the normal case is "unchanged": one 8-byte all-reduce and one host read per call.
+        Returns the table text (None when nothing was sent)."""
         from . import _lib
         if not self.active:
             return _lib.tune_table_text()
-        n = 0
-        text = None
-        if self.rank == src:
-            text = _lib.tune_table_text()
-            if force or text != getattr(self, "_tune_sent", None):
-                n = len(text)
+        text = _lib.tune_table_text()
+        flag = 1 if (force or text != getattr(self, "_tune_sent", None)) else 0
         nccl = dist.get_backend(self.group) == "nccl"
-        head = torch.tensor([n], dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()) if nccl else "cpu")
-        dist.broadcast(head, src=src, group=self.group)
+        head = torch.tensor([flag], dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()) if nccl else "cpu")
+        dist.all_reduce(head, op=dist.ReduceOp.MAX, group=self.group)
         if int(head.item()) == 0:
             return None
         box = [text if self.rank == src else None]
@@ -399,8 +396,9 @@ class GradReducer:
 
     @staticmethod
     def tune_sync_due(step):
-        """optimizer steps after which the followers adopt the lead's table: 1, 2, 4, ..., 64, then every 64"""
-        return step > 0 and (((step & (step - 1)) == 0 and step <= 64) or step % 64 == 0)
+        """optimizer steps after which the followers adopt the lead's table: 1, 2, 4, ..., 256, then every 256 (each sync point is a
+        host read that drains every rank's queue: ADVICE r05 - unseen signatures appear early, so the early points are dense)"""
+        return step > 0 and (((step & (step - 1)) == 0 and step <= 256) or step % 256 == 0)
 
     def consolidate(self, native, optimizer_state=False):
         """Make the fp32 masters (and, on request, the AdamW moments) complete on every rank: after sharded steps each rank

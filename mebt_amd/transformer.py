@@ -213,6 +213,7 @@ class _KvSession:
         self.native, self.B, self.N = native, B, N
         self.cache = native.new_kv_cache(B, N)
         self.fresh = True
+        self.degraded = False
         self.prev_targets = None
         self.check = os.environ.get("MEBT_KV_CACHE_CHECK", "0") == "1"
         self.stamp = torch.full((B, N), -1, dtype=torch.long, device=native.device) if self.check else None
@@ -220,14 +221,24 @@ class _KvSession:
         self.rows_uncached = 0            # ... and what the same forwards project without the cache
 
     def forward(self, x_ids, ci, ti, dirty, logits_bf16):
-        if self.fresh or ci.shape[1] == 0:
+        # The engine takes 0 <= ND <= NC re-projected positions (its context buffers hold NC rows).  What must hold is that every
+        # position of `ci` whose token changed since its row was written is in `d`:
+        #   * nothing projected yet (`fresh`: a new session, or after a forward without contexts - a one-step draft / revise pass
+        #     re-samples every position) -> the whole context;
+        #   * the loop named the changed positions (`dirty`, a subset of ci) -> those;
+        #   * otherwise the previous forward's targets, if that many rows fit;  if they do not, the whole context is projected and
+        #     the session stays `degraded` (some changed positions outside `ci` were NOT re-projected, so no later `dirty` list can
+        #     be trusted to cover them): every further forward re-projects its whole context, like the reference.
+        NC = ci.shape[1]
+        if self.fresh or self.degraded or NC == 0:
             d = ci
         elif dirty is not None:
             d = dirty
-        else:
+        elif self.prev_targets is not None and self.prev_targets.shape[1] <= NC:
             d = self.prev_targets
-        if d is None:
+        else:
             d = ci
+            self.degraded = True
         d = d.reshape(self.B, -1)
         if self.check:
             self.stamp.scatter_(1, d, x_ids.gather(1, d))
@@ -235,7 +246,7 @@ class _KvSession:
                 stale = int((self.stamp.gather(1, ci) != x_ids.gather(1, ci)).sum())
                 assert stale == 0, f"key/value cache: {stale} context positions were projected for another token id"
         logits = self.native.forward_cached(x_ids, ci, ti, self.cache, d, logits_bf16)
-        self.fresh = False
+        self.fresh = NC == 0           # a forward without contexts projected nothing and its targets are every position it names
         self.prev_targets = ti
         self.rows_projected += self.B * d.shape[1]
         self.rows_uncached += self.B * ci.shape[1]
@@ -436,6 +447,15 @@ class Net2NetTransformer(LightningModuleShim):
         return super().state_dict(*args, **kwargs)
 
     # ---- forward ----------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_to_c(self, c):
+        """reference :696-701: the conditioning stage's (quantised, indices) pair; the only conditioning stage that exists is the
+        unconditional SOSProvider (:204-212), whose pair is the sos token twice, [B, 1]"""
+        quant_c, indices = self.cond_stage_model.encode(c, include_embeddings=True)
+        if len(indices.shape) > 2:
+            indices = indices.view(c.shape[0], -1)
+        return quant_c, indices
+
     @torch.no_grad()
     def encode_to_z(self, x):
         """reference :683-694: token grids pass through (`vtokens`); pixel videos [B,C,T,H,W] go through the first stage's

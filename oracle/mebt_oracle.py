@@ -398,6 +398,45 @@ def sample_from_logits(logits, temperature, top_k, top_p, noise):
     return ids, probs
 
 
+def inverse_cdf_order(V=16384):
+    """element order of the product's inverse-CDF draw (mebt_amd/csrc/sampler.hip: sample_fast_kernel, `draw = 1`): thread t of 512
+    owns elements 8 t + k + 4096 g (g = 0..3 major, k = 0..7), threads in order."""
+    assert V == 16384
+    return (8 * torch.arange(512).view(512, 1, 1) + torch.arange(8).view(1, 1, 8) + 4096 * torch.arange(4).view(1, 4, 1)).reshape(-1)
+
+
+def sample_inverse_cdf(logits, temperature, top_k, seed):
+    """CPU twin of the product's PRODUCTION draw (no injected noise; include/mebt_hip.h: mebt_op_sample_lp, draw = 1).  The
+    reference draws arg-max p / q, q ~ Exp(1) (mebt/transformer.py:826-841, :877) - one sample of the categorical distribution p
+    left by temperature / top-k / softmax (:859-871).  The product takes the same distribution's sample by inverse CDF from ONE
+    uniform per row: the first element, in `inverse_cdf_order`, whose running sum of p reaches u * sum(p), u = the counter-based
+    uniform of (seed, row) (oracle/closed_form.py:uniform_counter, exact twin of the kernel's hash); filtered elements (p = 0) are
+    never chosen; if rounding leaves the target above the last running sum the last positive element is taken.
+    Probabilities: this oracle's own (`sample_from_logits`: the reference's arithmetic), running sum in float64.
+    Returns (ids [R], probs [R, V], margin [R]) for logits [R, V]; margin = distance of the target from the nearer running-sum
+    boundary of the chosen element, relative to sum(p): a product id that differs is a proven tie only where the margin is within
+    fp32 rounding of the running sum (the product adds 32 elements per thread, then scans 512 thread sums, in fp32)."""
+    from oracle import closed_form as cf
+    R, V = logits.shape
+    _, probs = sample_from_logits(logits, temperature, top_k, None, torch.ones(R, V))
+    order = inverse_cdf_order(V)
+    po = probs.double()[:, order]
+    cum = po.cumsum(1)
+    tot = cum[:, -1]
+    u = torch.from_numpy(cf.uniform_counter(int(seed), R).astype(np.float64))
+    target = u * tot
+    ids = torch.empty(R, dtype=torch.long)
+    margin = torch.empty(R, dtype=torch.float64)
+    for r in range(R):
+        pos = (po[r] > 0).nonzero().flatten()
+        hit = ((cum[r] >= target[r]) & (po[r] > 0)).nonzero().flatten()
+        e = int(hit[0]) if hit.numel() else int(pos[-1])
+        ids[r] = order[e]
+        lo = float(cum[r, e] - po[r, e])
+        margin[r] = min(abs(float(target[r]) - lo), abs(float(cum[r, e]) - float(target[r]))) / float(tot[r])
+    return ids, probs, margin
+
+
 def gumbel_top_k(score, ctemp, noise):
     """mebt/mask_sampler.py:178-187 with the Exp(1) draw injected.  Returns descending order."""
     prob = score / score.sum(-1, keepdim=True)

@@ -252,6 +252,30 @@ def test_key_value_cache_of_the_sampling_loops():
         out = model.draft_and_revise(torch.randint(0, 16384, (B, 4, 16, 16), generator=g).to(DEV), None, 8, 1.0, None, None, 8, 1.0, None, None, 2, True)
         proj, unc = model._kv_last
         assert proj == B * ((N - 128) + 15 * 128) and unc == B * 16 * (N - 128), (proj, unc)
+        # a one-step draft (NC = 0, targets = every position) followed by revise passes - the draft forward projects nothing,
+        # so the first revise forward must re-project its whole context (it used to hand the engine ND = N > NC and raise)
+        out = model.draft_and_revise(x0, None, 1, 1.0, None, None, 4, 1.0, None, None, 2, False)
+        proj, unc = model._kv_last
+        assert out.shape == (B, N) and proj == B * ((N - 256) + 7 * 256) and unc == B * 8 * (N - 256), (proj, unc)
+        # ... and one-step revise passes (again NC = 0) before a longer pass
+        out = model.draft_and_revise(x0, None, 2, 1.0, None, None, 1, 1.0, None, None, 2, False)
+        out = model.revise(out.view(B, 4, 16, 16), None, 1.0, None, None, 4)
+        assert out.shape == (B, N)
+        # a caller that names no dirty positions and whose previous targets do not fit the context: whole-context projection from
+        # there on (`degraded`), never a stale row (the record is asserted inside every forward)
+        ses2 = _KvSession(nm, B, N)
+        ses2.forward(x, ci, ti, None, False)
+        big_t, small_c = perm[:, :640].contiguous(), perm[:, 640:].contiguous()          # NT = 640 > the next forward's NC = 256 ...
+        ses2.forward(x, small_c, big_t, None, False)
+        x4 = x.clone()
+        x4.scatter_(1, big_t, torch.randint(0, 16384, (B, 640), generator=g).to(DEV))
+        got4 = ses2.forward(x4, perm[:, 512:768].contiguous(), perm[:, 768:].contiguous(), None, False)
+        assert ses2.degraded
+        ref4 = model.reconstruct_mask(x4, perm[:, 512:768].contiguous(), perm[:, 768:].contiguous())[0]
+        assert (got4 - ref4).abs().max().item() < 2e-2 * ref4.abs().max().item()
+        got5 = ses2.forward(x4, ci, ti, ti[:, :0], False)            # an (empty) dirty list is ignored once degraded: positions 0..639 changed
+        ref5 = model.reconstruct_mask(x4, ci, ti)[0]
+        assert (got5 - ref5).abs().max().item() < 2e-2 * ref5.abs().max().item()
         # the script drivers on top of `sample`: bootstrap + continuation windows with a fixed context, and extrapolate(edit=True)
         from mebt_amd.sampling import bidirect_sample, extrapolate
         log = bidirect_sample(model, B, 32, 16, 8, temperature=1.0, top_k=32, top_p=None, vid_n_steps=4, vid_c_temp=2.0, bootstrap=3)

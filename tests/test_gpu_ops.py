@@ -527,30 +527,25 @@ def test_sampler_inverse_cdf_draw_is_a_sample_of_the_same_distribution():
     ld = logits.to(DEV)
     seed = 0x51ED_0000_1234
     # kernel order: thread t owns elements 8 t + k + 4096 g (g = 0 .. 3 major, k = 0 .. 7), threads in order
-    order = (8 * torch.arange(512).view(512, 1, 1) + torch.arange(8).view(1, 1, 8) + 4096 * torch.arange(4).view(1, 4, 1)).reshape(-1)
+    order = orc.inverse_cdf_order(V)
     for temp, k in ((1.0, 0), (0.8, 32), (1.0, 700)):
         ids = torch.empty(R, dtype=torch.long, device=DEV)
         score = torch.empty(R, device=DEV)
         check(lib().mebt_op_sample_lp(ptr(ld), 0, None, seed, temp, k, ptr(ids), ptr(score), None, None, 1, R, R, V, 1, cur_stream()))
         torch.cuda.synchronize()
         ids, score = ids.cpu(), score.cpu()
-        _, probs = orc.sample_from_logits(logits, temp, k or None, None, torch.ones(R, V))
-        u = torch.from_numpy(cf.uniform_counter(seed, R)).double()
+        # the oracle's twin of the draw (oracle/mebt_oracle.py:sample_inverse_cdf: same uniform, same element order, the oracle's own
+        # post-top-k probabilities, float64 running sum): the same element, or - where fp32 rounding of the running sum can move the
+        # crossing (margin = distance of u * sum(p) from the chosen element's boundaries) - its neighbour among the positive elements
+        oid, probs, margin = orc.sample_inverse_cdf(logits, temp, k or None, seed)
         po = probs.double()[:, order]
-        cum = po.cumsum(1)
-        target = u * cum[:, -1]
-        for r in range(R):
+        for r in (ids != oid).nonzero().flatten().tolist():
             pos_idx = (po[r] > 0).nonzero().flatten()
-            exact = int((cum[r] >= target[r]).nonzero().flatten()[0]) if bool((cum[r] >= target[r]).any()) else int(pos_idx[-1])
-            while po[r, exact] == 0:                                        # the crossing element has p > 0 by construction
-                exact += 1
-            got = int((order == ids[r]).nonzero().flatten()[0])
+            got, exact = int((order == ids[r]).nonzero().flatten()[0]), int((order == oid[r]).nonzero().flatten()[0])
             assert po[r, got] > 0, (temp, k, r)
             a, b = int((pos_idx == exact).nonzero().flatten()[0]), int((pos_idx == got).nonzero().flatten()[0])
-            assert abs(a - b) <= 1, (temp, k, r, exact, got)
-            if a != b:                                                      # a neighbour only where the running sum is within rounding of the target
-                lo = min(exact, got)
-                assert abs(float(cum[r, lo] - target[r])) < 2e-5 * float(cum[r, -1]), (temp, k, r)
+            assert abs(a - b) == 1 and float(margin[r]) < 2e-5, (temp, k, r, exact, got, float(margin[r]))
+        assert int((ids != oid).sum()) <= 2, (temp, k)
         np.testing.assert_allclose(score.numpy(), probs.gather(1, ids.view(R, 1)).squeeze(1).numpy(), rtol=3e-5, atol=1e-12)
         assert int(ids[5]) == 777
         ids2 = torch.empty(R, dtype=torch.long, device=DEV)

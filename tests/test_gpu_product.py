@@ -228,6 +228,58 @@ def test_script_drivers_bit_exact():
     np.testing.assert_allclose(log["score"].cpu().numpy(), score.numpy(), rtol=1e-4)
 
 
+def test_sampling_command_lines_micro_golden(tmp_path, monkeypatch):
+    """`python -m mebt_amd.sample` then `python -m mebt_amd.draft_and_revise --np_draft <its codemap>` (the two stages of the shipped
+    pipelines, reference sample_vqgan_transformer_videos.py:160-297 / draft_and_revise_videos.py:64-198) on a Lightning-format
+    checkpoint of the micro model: the code map file of the first equals the reference script's own output
+    (tests/golden/script_drivers.npz), the second equals the oracle's draft_and_revise(skip_draft=True) on that draft."""
+    from mebt_amd import sample as sample_cli, draft_and_revise as dnr_cli, scripts_common
+    g = load_golden("script_drivers")
+    model = build_product("micro", "f32", schedule="linear", device="cpu")
+    ckpt = str(tmp_path / "micro.ckpt")
+    torch.save({"state_dict": model.state_dict(), "hyper_parameters": model.hparams, "global_step": 11, "epoch": 0}, ckpt)
+    monkeypatch.chdir(tmp_path)
+    real_load = scripts_common.load_model
+    hooks = []
+
+    def load_with_noise(args):
+        m = real_load(args)
+        hook, state = closed_form_hook()
+        m.noise_hook = hook
+        hooks.append(state)
+        return m
+
+    monkeypatch.setattr(sample_cli, "load_model", load_with_noise)
+    monkeypatch.setattr(dnr_cli, "load_model", load_with_noise)
+    out = sample_cli.main(f"--gpt_ckpt {ckpt} --exp_name micro --dtype f32 --batch_size 2 --n_sample 1 --total_length 8 --step_size 8 --context_size 4 "
+                          "--temp 1.0 --vid_n_steps 4 --vid_c_temp 3.0 --bootstrap 3 --no_phase --save_codemap --no_np --dataset stl -v".split())
+    assert out == "results/micro/numpy_files_8/stl/VID_n_steps4_temp1.0_ctemp3.0linear_maskgit_cosine_no_phase_run0"
+    code = np.load(out + "_codemap.npy")
+    assert code.shape == (1, 2, 4, 4) and hooks[0]["k"] == int(g["bi_ndraws"])          # --n_sample 1 of the batch of 2 (:279)
+    assert (code == g["bi_code_maps"][:1]).all()
+    full = str(tmp_path / "VID_n_steps4_maskgit_cosine_ctemp3.0_draft_codemap.npy")
+    np.save(full, g["bi_code_maps"])
+    out2 = dnr_cli.main(f"--gpt_ckpt {ckpt} --exp_name micro --dtype f32 --batch_size 2 --n_sample 2 --total_length 8 --step_size 8 --context_size 8 "
+                        f"--n_revise 2 --M 2 --revise_t 0.8 --np_draft {full} --save_codemap --dataset stl --no_phase".split())
+    assert out2 == "results/micro/numpy_files_8/stl/VID_dnr_nd4_dt0.0_nr2_rt0.8_M2_ctemp3.0_run0"
+    assert open(out2 + ".txt").read() == full
+    code2 = np.load(out2 + "_codemap.npy")
+    noise_fn, perm_fn, _ = mg.oracle_noise_fns()
+    cfg = mg.oracle_cfg("micro")
+    with torch.no_grad():
+        ref = orc.draft_and_revise(orc.closed_form_params(cfg), cfg, torch.from_numpy(g["bi_code_maps"]), 4, 0.0, None, None, 2, 0.8, None, None, 2, True,
+                                   perm_fn, noise_fn)
+    assert code2.shape == (2, 2, 4, 4) and (code2.reshape(2, -1) == ref.numpy()).all()
+
+
+def test_encode_to_c_is_the_sos_pair():
+    """reference transformer.py:696-701 with the only conditioning stage there is (SOSProvider, :204-212)"""
+    model = build_product("micro", "f32").eval()
+    x = torch.zeros(3, 2, 4, 4, dtype=torch.long, device=DEV)
+    q, idx = model.encode_to_c(x)
+    assert q.shape == (3, 1) and idx.shape == (3, 1) and q.dtype == torch.long and int(idx.abs().sum()) == 0 and idx.device == x.device
+
+
 def test_sample_debug_tuple_and_gpt_forward_boundary():
     model = build_product("micro", "f32", schedule="cosine").eval()
     hook, _ = closed_form_hook()

@@ -51,6 +51,27 @@ def test_shipped_tune_table_matches_this_build():
     assert out.stdout.split()[0] == "1", out.stdout
 
 
+def test_tune_cache_of_another_version_is_moved_aside_not_truncated(tmp_path):
+    """MEBT_GEMM_TUNE_CACHE pointing at a table of another MEBT_TUNE_VERSION (or at a file that is no table at all): the file is kept
+    as <cache>.v<its version>, a fresh versioned table starts by rename, under a lock several ranks take (the old code
+    truncated the user's file in place, without a lock)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cache = tmp_path / "tune.txt"
+    old = "4 3 1536 1024 1024 5\n4 3 3072 1024 1024 7\n"                       # unversioned: reads as version 1
+    cache.write_text(old)
+    code = "from mebt_amd import _lib; print(_lib.tune_table_text().splitlines()[0])"
+    env = dict(os.environ, MEBT_GEMM_TUNE_CACHE=str(cache), MEBT_GEMM_TUNE_SHIPPED="0")
+    procs = [subprocess.Popen([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(3)]
+    outs = [p_.communicate(timeout=300) for p_ in procs]
+    assert all(p_.returncode == 0 for p_ in procs), [o[1][-500:] for o in outs]
+    version = outs[0][0].strip()
+    assert version.startswith("1 -1 ") and all(o[0].strip() == version for o in outs)
+    assert (tmp_path / "tune.txt.v1").read_text() == old                      # nothing of the user's file was lost
+    assert cache.read_text().splitlines() == [version]                        # one version line, however many processes raced
+    assert sum("kept as" in o[1] for o in outs) == 1
+
+
 def test_product_fails_loudly_without_gpu():
     """no CPU fallback: a forward on a CPU-resident model must raise, not silently compute"""
     from tests.helpers import build_product
@@ -197,8 +218,14 @@ def _dp_worker(rank, world, port, ret):
             assert _lib.tune_table_merge(f"{version}\n4 3 2048 1024 1024 100673539\n", overwrite=True) == 1
         text2 = red.sync_tune_table()
         assert text2 == _lib.tune_table_text() and "4 3 2048 1024 1024 100673539" in text2
-        assert [red.tune_sync_due(k) for k in (16, 32, 64, 96, 128, 192)] == [True, True, True, False, True, True]
-        assert [red.tune_sync_due(k) for k in (0, 1, 2, 3, 4, 5, 8, 255, 256, 257, 512)] == [False, True, True, False, True, False, True, False, True, False, True]
+        # a FOLLOWER whose table was changed locally is re-synced too, and only then
+        if rank == 1:
+            assert _lib.tune_table_merge(f"{version}\n4 3 4096 1024 1024 100673540\n", overwrite=True) == 1
+        text3 = red.sync_tune_table()
+        assert text3 == text2 == _lib.tune_table_text() and "4096 1024 1024 100673540" not in _lib.tune_table_text()
+        assert red.sync_tune_table() is None
+        assert [red.tune_sync_due(k) for k in (16, 32, 64, 96, 128, 192)] == [True, True, True, False, True, False]
+        assert [red.tune_sync_due(k) for k in (0, 1, 2, 3, 4, 5, 8, 255, 256, 257, 512, 640, 768)] == [False, True, True, False, True, False, True, False, True, False, True, False, True]
         if rank == 0:
             ret.put(({k: v.detach().numpy().copy() for k, v in st.P.items()}, float(t)))   # numpy: pickled by value
         dist.barrier()
@@ -729,3 +756,38 @@ def test_host_layer_under_asan_ubsan():
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "asan_host_driver.py"), os.path.join(root, "mebt_amd", "lib", "libmebt_hip_asan.so"), root],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "no sanitizer finding" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_sampling_command_lines_parse_the_shipped_scripts_flags(tmp_path):
+    """`python -m mebt_amd.sample` / `python -m mebt_amd.draft_and_revise` take the flags of the reference's two scripts
+    (sample_vqgan_transformer_videos.py:160-193, draft_and_revise_videos.py:64-96) and name their outputs like them: the command
+    lines of scripts/valid_dnr_config_ckpt_exp_ucf_128f.sh:10-15,30-35 parse unchanged, and the file names are the ones that script's
+    next stage (`--np_draft ...`, `measure_fvd_with_numpy.py --np_file ...`) expects."""
+    from mebt_amd import sample, draft_and_revise
+    from mebt_amd.scripts_common import resolve_checkpoint
+    line = ("--base cfg.yaml --gpt_ckpt g.ckpt --exp_name EXP --vid_c_temp 2.0 --total_length 128 --vid_n_steps 32 --context_size 128 --step_size 128 "
+            "--verbose --dataset ucf101 --no_phase --n_sample 512 --run 3 --batch_size 4 --save_videos --decoding_strategy maskgit --top_k 32 "
+            "--save_codemap --bootstrap 64 --save_n 20")
+    a, unknown = sample.build_parser().parse_known_args(line.split())
+    assert not unknown and a.bootstrap == 64 and a.top_k == 32 and a.temp == 1.0 and a.schedule == "cosine" and a.batch_size == 4
+    assert resolve_checkpoint(a) == "g.ckpt" and a.save == "results/EXP"
+    save_dir, save_np = sample.output_names(a)
+    assert save_np == "results/EXP/numpy_files_128/ucf101/VID_n_steps32_k32_temp1.0_ctemp2.0linear_maskgit_cosine_no_phase_run3"
+    assert save_dir == "results/EXP/videos_128/ucf101/VID_n_steps32_k32_temp1.0_ctemp2.0linear_maskgit_cosine_no_phase_run3"
+    a.no_phase = False
+    with pytest.raises(AssertionError):                       # the reference asserts --no_phase (:235)
+        sample.output_names(a)
+    draft_file = tmp_path / "VID_n_steps32_k32_temp1.0_ctemp2.0linear_maskgit_cosine_no_phase_run3_codemap.npy"
+    np.save(str(draft_file), np.zeros((4, 32, 16, 16), dtype=np.int64))
+    line = (f"--base cfg.yaml --gpt_ckpt g.ckpt --exp_name EXP --total_length 128 --n_revise 32 --M 2 --revise_t 0.1 --np_draft {draft_file} "
+            "--context_size 128 --step_size 128 --verbose --dataset ucf101 --no_phase --n_sample 512 --run 3 --batch_size 4 --save_videos --save_n 20")
+    b, unknown = draft_and_revise.build_parser().parse_known_args(line.split())
+    assert unknown == ["--no_phase"]                          # the shipped script passes it; the reference's parser leaves it to OmegaConf's dotlist too
+    resolve_checkpoint(b)
+    draft, postfix = draft_and_revise.apply_np_draft(b)
+    assert draft.shape == (4, 32, 16, 16) and b.n_draft == 32 and b.draft_t == 0.0 and postfix == "_ctemp2.0"
+    _, save_np = draft_and_revise.output_names(b, postfix)
+    assert save_np == "results/EXP/numpy_files_128/ucf101/VID_dnr_nd32_dt0.0_nr32_rt0.1_M2_ctemp2.0_run3"      # the --np_file of the script's FVD stage (:37)
+    b.exp_name, b.gpt_ckpt = "nope", ""
+    with pytest.raises(FileNotFoundError):
+        resolve_checkpoint(b)
