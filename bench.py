@@ -710,6 +710,8 @@ def main():
         model._reducer = reducer
         loop.native.enable_wire_grads(loop.wire_grads)       # the one-rank loops above unbound it
         dp = {"dp_mode": reducer.mode, "wire": reducer.wire if reducer.mode == "sharded" else "fp32",
+              "gradient_sum": ("fp32 at the owning rank (bf16 all-to-all of the shards, mebt_adamw_slice_pieces)" if (reducer.mode == "sharded" and reducer.wire == "bf16" and reducer.exchange == "a2a")
+                               else "bf16 inside RCCL's reduce-scatter" if (reducer.mode == "sharded" and reducer.wire == "bf16") else "fp32 inside RCCL"),
               "rccl_ranks": int(ones.item()), "backend": backend, "dp_fallback": dp_fallback,
               "deferred_gathers": bool(reducer.defer), "buckets": reducer.bucket_plan(loop.native.n_layer),
               "bytes_on_wire_per_step": int(wire_bytes_per_step),
@@ -742,7 +744,7 @@ def main():
                              "note": "amdgpu sysfs (current sclk / mclk / fclk level, power cap / average, temperature), read outside the timed region"},
                "config": {"workload": "Sky-Timelapse 16f MeBT train step: 24L/1024d/16h, 1024 VQ tokens + 256 latents, "
                                       f"batch {args.batch}/GPU, t={args.t} (NC=NT={n_targets // args.batch}), "
-                                      "fwd + masked CE + bwd + AdamW" + ((f" + reduce-scatter / sharded AdamW / all-gather ({reducer.wire} wire)" if reducer.mode == "sharded" else " + bucketed fp32 all-reduce") if reducer.active else ""),
+                                      "fwd + masked CE + bwd + AdamW" + ((f" + {'all-to-all (fp32 sum at the owner)' if (reducer.wire == 'bf16' and reducer.exchange == 'a2a') else 'reduce-scatter'} / sharded AdamW / all-gather ({reducer.wire} wire)" if reducer.mode == "sharded" else " + bucketed fp32 all-reduce") if reducer.active else ""),
                           "global_batch": args.batch * world, "parallelism": f"dp{world}", "dropout": args.dropout,
                           "optimizer": "in-backward (fused into the weight-gradient launches)" if loop.fused_optimizer else
                                        ("sharded over ranks" if reducer.active and reducer.mode == "sharded" else

@@ -152,6 +152,14 @@ int mebt_adamw_slice(mebt_model* m, int32_t which, int64_t off, int64_t n, const
                      float* vW, float* mP, float* vP, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int32_t step, float grad_scale, mebt_stream_t stream);
 
+/* The same update with the slice's gradient given as `pieces` bf16 copies of it, piece j at grad_pieces + j * n elements: rank j's
+ * contribution to this rank's shard as an all-to-all delivers them.  The kernel adds the pieces in fp32, in piece order, then
+ * applies AdamW to the sum: 2 B per parameter on the wire like a bf16 reduce-scatter, but the cross-rank sum is taken in fp32 as
+ * the reference's DDP all-reduce takes it (train_transformer.py:39-41) instead of in bf16 inside RCCL. */
+int mebt_adamw_slice_pieces(mebt_model* m, int32_t which, int64_t off, int64_t n, const void* grad_pieces, int32_t pieces, float* mW,
+                            float* vW, float* mP, float* vP, float lr, float beta1, float beta2, float eps, float weight_decay,
+                            int32_t step, float grad_scale, mebt_stream_t stream);
+
 /* Optimizer-in-backward (single-process training): armed with step >= 1, the next mebt_backward_layers applies
  * AdamW to every block's Linear weights INSIDE the weight-gradient launch (the gradient tile is consumed from
  * registers; it is not stored in gW, and W / the bf16 mirror / mW / vW are updated in place), which removes

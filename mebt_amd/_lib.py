@@ -52,6 +52,7 @@ PROTOTYPES = {
     "mebt_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp]),
     "mebt_adamw_range": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_i32, c_i32, c_i32, c_vp]),
     "mebt_adamw_slice": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp]),
+    "mebt_adamw_slice_pieces": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp]),
     "mebt_model_set_fused_adamw": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32]),
     "mebt_model_set_grad_accumulate": (c_i32, [c_vp, c_i32]),
     "mebt_model_bind_wire_grads": (c_i32, [c_vp, c_vp]),

@@ -681,7 +681,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWParams a) {
     const AdamWHyper h = {a.lr, a.beta1, a.beta2, a.eps, a.weight_decay, a.bc1, a.bc2, a.grad_scale};
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (size_t)gridDim.x * 1024) {
         f32x4 p = *reinterpret_cast<const f32x4*>(a.p + i);
-        const f32x4 g = load4<TG>(reinterpret_cast<const TG*>(a.g) + i);
+        f32x4 g = load4<TG>(reinterpret_cast<const TG*>(a.g) + i);
+        if constexpr (sizeof(TG) == 2)       // gradient exchanged by all-to-all: the ranks' bf16 contributions are added here, in fp32, in rank order
+            for (int j = 1; j < a.g_pieces; ++j) g += load4<TG>(reinterpret_cast<const TG*>(a.g) + (size_t)j * a.g_stride + i);
         f32x4 m = *reinterpret_cast<const f32x4*>(a.m + i);
         f32x4 v = *reinterpret_cast<const f32x4*>(a.v + i);
         adamw_update4(p, g, m, v, h);

@@ -1288,16 +1288,18 @@ extern "C" int mebt_adamw_range(mebt_model* m, float* mW, float* vW, float* mP, 
 // grad_bf16).  This is the update a data-parallel rank applies to ITS shard of a gradient bucket after the
 // reduce-scatter (ZeRO-1 style: m, v and the fp32 master are only ever touched on the owning rank).  Elements of blocks
 // the loss cannot reach are skipped, exactly like mebt_adamw_range.
-extern "C" int mebt_adamw_slice(mebt_model* m, int32_t which, int64_t off, int64_t n, const void* grad, int32_t grad_bf16, float* mW,
-                                float* vW, float* mP, float* vP, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                int32_t step, float grad_scale, mebt_stream_t stream) {
+static int adamw_slice_impl(mebt_model* m, int32_t which, int64_t off, int64_t n, const void* grad, int32_t grad_bf16, int32_t pieces, float* mW,
+                            float* vW, float* mP, float* vP, float lr, float beta1, float beta2, float eps, float weight_decay,
+                            int32_t step, float grad_scale, mebt_stream_t stream) {
     if (!m || !m->W || !grad) { mebt_set_error("adamw_slice: model not bound / null gradient"); return MEBT_EINVAL; }
+    if (pieces < 1 || (pieces > 1 && !grad_bf16)) { mebt_set_error("adamw_slice: pieces >= 1, several pieces only of bf16 gradients"); return MEBT_EINVAL; }
     if (step < 1) { mebt_set_error("adamw: step must be >= 1"); return MEBT_EINVAL; }
     const int64_t total = which == 0 ? m->n_w : m->n_p;
     if (off < 0 || n < 0 || off + n > total || (off % 4) || (n % 4)) { mebt_set_error("adamw_slice: bad range (multiples of 4 inside the buffer)"); return MEBT_EINVAL; }
     hipStream_t st = S(stream);
     AdamWParams a;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.grad_scale = grad_scale; a.g_bf16 = grad_bf16 ? 1 : 0;
+    a.g_pieces = pieces; a.g_stride = (size_t)n;      // piece j of the gradient starts n elements behind piece j - 1
     a.bc1 = (float)(1.0 - pow((double)beta1, step)); a.bc2 = (float)(1.0 - pow((double)beta2, step));
     a.weight_decay = which == 0 ? weight_decay : 0.f;
     const int d = m->d.n_embd;
@@ -1319,6 +1321,21 @@ extern "C" int mebt_adamw_slice(mebt_model* m, int32_t which, int64_t off, int64
     if (which == 0) RC(run(m->head_w, m->n_w));
     else RC(run(m->lnf_w, m->tok_live ? m->n_p : m->tok_emb));
     return MEBT_OK;
+}
+extern "C" int mebt_adamw_slice(mebt_model* m, int32_t which, int64_t off, int64_t n, const void* grad, int32_t grad_bf16, float* mW,
+                                float* vW, float* mP, float* vP, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int32_t step, float grad_scale, mebt_stream_t stream) {
+    return adamw_slice_impl(m, which, off, n, grad, grad_bf16, 1, mW, vW, mP, vP, lr, beta1, beta2, eps, weight_decay, step, grad_scale, stream);
+}
+// The gradient of the slice arrives as `pieces` bf16 copies of it (piece j = rank j's contribution to this rank's shard, received by
+// an all-to-all; piece j at grad + j * n elements): the kernel adds them up in fp32, in piece order, and applies AdamW to the sum —
+// the reference's DDP sums fp32 gradients (train_transformer.py:39-41); a bf16 reduce-scatter lets RCCL add in bf16 (one rounding
+// per ring hop), this keeps 2 B per parameter on the wire and the sum in fp32 (one rounding per RANK, where each rank rounded its
+// own fp32 accumulators once).
+extern "C" int mebt_adamw_slice_pieces(mebt_model* m, int32_t which, int64_t off, int64_t n, const void* grad_pieces, int32_t pieces, float* mW,
+                                       float* vW, float* mP, float* vP, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                       int32_t step, float grad_scale, mebt_stream_t stream) {
+    return adamw_slice_impl(m, which, off, n, grad_pieces, 1, pieces, mW, vW, mP, vP, lr, beta1, beta2, eps, weight_decay, step, grad_scale, stream);
 }
 
 // bf16 wire-format gradients for the data-parallel path: with a buffer bound (bf16 compute mode, no accumulation, no fused

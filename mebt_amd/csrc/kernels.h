@@ -206,6 +206,8 @@ struct AdamWParams {
     float* p; const float* g; float* m; float* v; void* p_bf16;   // p_bf16 may be null
     size_t n; float lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale;
     int g_bf16 = 0;    // g points at bf16 gradients (the reduce-scattered wire format of the data-parallel path)
+    int g_pieces = 1;  // bf16 only: the gradient is the fp32 sum of g_pieces bf16 copies, copy j at g + j * g_stride elements (all-to-all exchange)
+    size_t g_stride = 0;
 };
 int launch_adamw(const AdamWParams& p, hipStream_t stream);
 int launch_cast_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t stream);

@@ -276,9 +276,16 @@ class NativeModel:
                                         float(eps), float(weight_decay), int(step), float(grad_scale), k, int(hi or 0), int(lo or 0),
                                         stream if stream is not None else cur_stream()))
 
-    def adamw_slice(self, which, off, n, grad, lr, weight_decay, step, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0, stream=None):
-        """AdamW on elements [off, off+n) of W (which = 0) or P (1) with `grad` (fp32 or bf16, n elements) as gradient"""
+    def adamw_slice(self, which, off, n, grad, lr, weight_decay, step, betas=(0.9, 0.95), eps=1e-8, grad_scale=1.0, stream=None, pieces=1):
+        """AdamW on elements [off, off+n) of W (which = 0) or P (1) with `grad` (fp32 or bf16, n elements) as gradient; `pieces` > 1:
+        `grad` holds that many bf16 copies of the slice's gradient back to back (an all-to-all's receive buffer), summed in fp32"""
         mW, vW, mP, vP = self._adam_state()
+        if pieces > 1:
+            assert grad.dtype == torch.bfloat16 and grad.numel() == pieces * n
+            check(self.lib.mebt_adamw_slice_pieces(self.h, int(which), int(off), int(n), ptr(grad), int(pieces),
+                                                   ptr(mW), ptr(vW), ptr(mP), ptr(vP), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                                   float(weight_decay), int(step), float(grad_scale), stream if stream is not None else cur_stream()))
+            return
         check(self.lib.mebt_adamw_slice(self.h, int(which), int(off), int(n), ptr(grad), 1 if grad.dtype == torch.bfloat16 else 0,
                                         ptr(mW), ptr(vW), ptr(mP), ptr(vP), float(lr), float(betas[0]), float(betas[1]), float(eps),
                                         float(weight_decay), int(step), float(grad_scale), stream if stream is not None else cur_stream()))

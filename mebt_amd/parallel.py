@@ -9,8 +9,11 @@ contiguous slice — no flatten / unflatten copies.  The HIP backward is split a
   mode "sharded" (default):   bf16 wire buffer                         (Linear weight gradients: stored as bf16 by the
                                                                         weight-gradient launches themselves; the small
                                                                         non-Linear tail: cast kernel on the compute stream)
-                              reduce-scatter(sum) of the bf16 bucket   (RCCL, its own stream)     -> rank r holds shard r
-                              AdamW on shard r only                    (mebt_adamw_slice, optimizer stream; fp32 master,
+                              all-to-all of the bucket's shards        (RCCL, its own stream)     -> rank r holds every rank's
+                                                                        bf16 copy of shard r; summed in fp32 inside the AdamW
+                                                                        launch (mebt_adamw_slice_pieces).  MEBT_DP_EXCHANGE=rs:
+                                                                        reduce-scatter(sum), RCCL adds in bf16
+                              AdamW on shard r only                    (mebt_adamw_slice[_pieces], optimizer stream; fp32 master,
                                                                         m, v are touched by the owner alone: 1/N of the
                                                                         10 GB the replicated optimizer streams per step)
                               all-gather of the updated shard          (RCCL): the bf16 weight mirror for the Linear
@@ -18,8 +21,9 @@ contiguous slice — no flatten / unflatten copies.  The HIP backward is split a
   mode "allreduce" (legacy):  all-reduce(sum) of the fp32 bucket, replicated bucket-wise AdamW (mebt_adamw_range)
 
 Everything after the cast overlaps the rest of backward; only the last bucket is exposed.  On the wire a step moves
-2 x 2 B per parameter (reduce-scatter + all-gather in bf16) instead of 2 x 4 B for the fp32 all-reduce; the gradient
-sum itself is taken in bf16 by RCCL (each rank's bucket was accumulated in fp32 locally and rounded once).  The
+2 x 2 B per parameter (all-to-all / reduce-scatter + all-gather in bf16) instead of 2 x 4 B for the fp32 all-reduce; each rank's
+bucket was accumulated in fp32 locally and rounded once, the sum across ranks is taken in fp32 (all-to-all; in bf16 by RCCL with
+MEBT_DP_EXCHANGE=rs).  The
 1/world_size factor is folded into AdamW (`grad_scale`).  All ranks draw the same `t` (same python seed,
 train_transformer.py:11), hence identical NC/NT and no stragglers.
 
@@ -88,7 +92,7 @@ class _Done:
 
 
 class GradReducer:
-    def __init__(self, world_size=None, group=None, layers_per_bucket=4, mode=None, wire=None, force=None):
+    def __init__(self, world_size=None, group=None, layers_per_bucket=4, mode=None, wire=None, force=None, exchange=None):
         self.group = group
         self.world_size = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.rank = dist.get_rank(group) if (self.world_size > 1 and dist.is_initialized()) else 0
@@ -110,7 +114,11 @@ class GradReducer:
         self._test_delay = int(os.environ.get("MEBT_DP_TEST_DELAY_CYCLES", "0"))
         self.mode = mode or os.environ.get("MEBT_DP_MODE", "sharded")
         self.wire = wire or os.environ.get("MEBT_DP_WIRE", "bf16")
-        assert self.mode in ("sharded", "allreduce") and self.wire in ("bf16", "fp32")
+        # how the bf16 buckets are summed across ranks: "a2a" = all-to-all of the shards, the N received copies added in fp32 inside
+        # the owner's AdamW launch (the reference's DDP sums fp32, train_transformer.py:39-41; on xGMI's full mesh every link
+        # carries one shard at once); "rs" = RCCL reduce-scatter, which adds in bf16 (one rounding per hop).  fp32 wire: always "rs".
+        self.exchange = exchange or os.environ.get("MEBT_DP_EXCHANGE", "a2a")
+        assert self.mode in ("sharded", "allreduce") and self.wire in ("bf16", "fp32") and self.exchange in ("a2a", "rs")
         # `elide` (bench.py, measurement only): every collective of the step becomes a local no-op / copy with the same
         # buffers, kernels and stream hand-offs — the step time with it set is the compute side of the data-parallel step,
         # the difference to the real step is communication that was not hidden (plus RCCL's kernels competing for CUs)
@@ -141,6 +149,19 @@ class GradReducer:
             out.copy_(ho)
             return _Done()
         return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _all_to_all(self, recv, send):
+        """recv[j * shard : (j + 1) * shard] = rank j's send[rank * shard : (rank + 1) * shard]"""
+        if self.elide:               # measurement only: N copies of this rank's own shard stand in for the ranks' contributions
+            n = recv.numel() // self.world_size
+            recv.view(self.world_size, n).copy_(send[self.rank * n:(self.rank + 1) * n].unsqueeze(0).expand(self.world_size, n))
+            return _Done()
+        if self._staged(send):
+            hr = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(hr, send.cpu(), group=self.group)
+            recv.copy_(hr)
+            return _Done()
+        return dist.all_to_all_single(recv, send, group=self.group, async_op=True)
 
     def _all_gather(self, full, mine):
         if self.elide:
@@ -256,15 +277,18 @@ class GradReducer:
                 native.cast_bf16(g, wire)                                       # compute stream
             else:
                 wire = g
-            out = self._buf(self._rs_out, (which, a, b), shard, wire.dtype, g.device)
-            w = self._reduce_scatter(out, wire)
+            a2a = self.wire == "bf16" and self.exchange == "a2a"
+            pieces = world if a2a else 1
+            out = self._buf(self._rs_out, (which, a, b), shard * pieces, wire.dtype, g.device)
+            w = self._all_to_all(out, wire) if a2a else self._reduce_scatter(out, wire)
             self.bytes_on_wire += n * wire.element_size()
             lowp = native.Wlp if which == 0 else None
 
-            def tail(w=w, which=which, a=a, b=b, sa=sa, shard=shard, out=out, lowp=lowp, key=key):
-                w.wait()                                                       # the optimizer stream waits for the reduce-scatter
+            def tail(w=w, which=which, a=a, b=b, sa=sa, shard=shard, out=out, lowp=lowp, key=key, pieces=pieces):
+                w.wait()                                                       # the optimizer stream waits for the exchange
+                kw = {"pieces": pieces} if pieces > 1 else {}                  # a2a: the ranks' bf16 contributions are summed in fp32 by the AdamW launch
                 native.adamw_slice(which, sa, shard, out, lr, weight_decay, step, betas=betas, eps=eps, grad_scale=self.grad_scale,
-                                   stream=self._sid(opt_stream))
+                                   stream=self._sid(opt_stream), **kw)
                 full_t = lowp if lowp is not None else (native.W if which == 0 else native.P)
                 full, mine = full_t[a:b], full_t[sa:sa + shard]
                 if self.defer:

