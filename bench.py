@@ -143,6 +143,55 @@ def gpu_state(index=0):
     return st
 
 
+class ClockSampler:
+    """sclk / average power sampled from sysfs every 25 ms on a host thread while the timed windows run (the values before / after
+    the windows are idle readings: the GPU clocks down within milliseconds).  Reads files only - nothing touches the GPU queue."""
+
+    def __init__(self, index=0, period=0.025):
+        import glob
+        import threading
+        cards = sorted(c for c in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(c, "pp_dpm_sclk")))
+        self.dev = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        hw = glob.glob(os.path.join(self.dev, "hwmon", "hwmon*")) if self.dev else []
+        self.power = next((os.path.join(h, f) for h in hw for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, f))), None)
+        self.period, self.sclk, self.watts = period, [], []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                with open(os.path.join(self.dev, "pp_dpm_sclk")) as f:
+                    cur = [ln for ln in f.read().splitlines() if ln.rstrip().endswith("*")]
+                if cur:
+                    self.sclk.append(int("".join(ch for ch in cur[0].split(":", 1)[1] if ch.isdigit())))
+                if self.power:
+                    with open(self.power) as f:
+                        self.watts.append(int(f.read().strip()) * 1e-6)
+            except (OSError, ValueError, IndexError):
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.dev:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.dev:
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.sclk:
+            return None
+        s_ = sorted(self.sclk)
+        out = {"samples": len(s_), "sclk_mhz": {"min": s_[0], "median": s_[len(s_) // 2], "max": s_[-1]}}
+        if self.watts:
+            out["power_w"] = {"mean": round(sum(self.watts) / len(self.watts), 1), "max": round(max(self.watts), 1)}
+        return out
+
+
 def timed(fn, n, sync):
     sync()
     t0 = time.perf_counter()
@@ -590,12 +639,17 @@ def main():
             el = float(tt.item())
         return el, st_
 
+    sampler = ClockSampler(local_rank) if rank == 0 else None
+    if sampler is not None:
+        sampler.__enter__()
     elapsed, stats = window()            # THE timed region: `value` / `ms_per_step` come from this window alone
     wire1 = reducer.bytes_on_wire
-    gpu_after = gpu_state(local_rank) if rank == 0 else None
     # ... and more windows of the same length behind it (outside the judged region): their spread says how much of a difference
     # between two runs of this line is the box and how much the code
     extra = [window()[0] for _ in range(max(0, args.windows - 1))]
+    if sampler is not None:
+        sampler.__exit__()
+    gpu_after = gpu_state(local_rank) if rank == 0 else None
     win_ms = [round(1e3 * e / args.steps, 3) for e in [elapsed] + extra]
     stats = stats.cpu()
     n_targets = int(stats[3])                                  # masked tokens scored per rank per step
@@ -740,8 +794,9 @@ def main():
                "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
                "windows": {"ms_per_step": win_ms, "median": sorted(win_ms)[len(win_ms) // 2], "min": min(win_ms), "max": max(win_ms),
                            "note": f"{len(win_ms)} back-to-back windows of {args.steps} steps, each barrier + synchronize bracketed; `value` is the FIRST"},
-               "gpu_state": {"before": gpu_before, "after": gpu_after,
-                             "note": "amdgpu sysfs (current sclk / mclk / fclk level, power cap / average, temperature), read outside the timed region"},
+               "gpu_state": {"before": gpu_before, "after": gpu_after, "during_windows": sampler.summary() if sampler is not None else None,
+                             "note": "amdgpu sysfs: current sclk / mclk / fclk level, power cap / average before and after the windows (idle readings), "
+                                     "and sclk / power sampled every 25 ms by a host thread while they run"},
                "config": {"workload": "Sky-Timelapse 16f MeBT train step: 24L/1024d/16h, 1024 VQ tokens + 256 latents, "
                                       f"batch {args.batch}/GPU, t={args.t} (NC=NT={n_targets // args.batch}), "
                                       "fwd + masked CE + bwd + AdamW" + ((f" + {'all-to-all (fp32 sum at the owner)' if (reducer.wire == 'bf16' and reducer.exchange == 'a2a') else 'reduce-scatter'} / sharded AdamW / all-gather ({reducer.wire} wire)" if reducer.mode == "sharded" else " + bucketed fp32 all-reduce") if reducer.active else ""),

@@ -353,6 +353,9 @@ void mebt_debug_gemm_scratch(void* buf, int64_t bytes);
 /* Diagnostics only: with a device buffer of 4 x 8 bytes per workgroup installed, wave 0 of every workgroup of the plain bf16
  * GEMM kernels stamps s_memtime at entry / first k-tile landed / main loop done / epilogue stores retired (NULL: off). */
 void mebt_debug_gemm_stamps(unsigned long long* buf);
+/* Diagnostics (tools/wgrad_bench.py): every grouped weight-gradient launch uses this tile (128 or 64 each way) and LDS ring depth
+ * (2-4) instead of the tuned / shipped choice; tbm = 0 switches the override off. */
+void mebt_debug_grouped_config(int32_t tbm, int32_t tbn, int32_t ring);
 /* Benchmarking only: LDS-DMA ring depth (2 or 3) of the grouped weight-gradient GEMM. */
 void mebt_debug_grouped_stages(int32_t n);
 

@@ -87,6 +87,7 @@ PROTOTYPES = {
     "mebt_debug_grouped_stages": (None, [c_i32]),
     "mebt_debug_gemm_scratch": (None, [c_vp, c_i64]),
     "mebt_debug_gemm_stamps": (None, [c_vp]),
+    "mebt_debug_grouped_config": (None, [c_i32, c_i32, c_i32]),
     "mebt_gemm_autotune": (None, [c_i32]),
     "mebt_gemm_autotune_enabled": (c_i32, []),
     "mebt_gemm_tune_export": (c_i64, [C.c_char_p, c_i64]),

@@ -103,6 +103,11 @@ struct mebt_model {
     // to W (AdamW) inside the weight-gradient launch instead of being stored in gW
     bool fused_on = false;
     bool grad_acc = false;     // mebt_model_set_grad_accumulate: backward adds to gW / gP instead of overwriting them
+    // Weight gradients of TWO consecutive blocks in one grouped launch (MEBT_WGRAD_PAIR, bf16, no side stream): the first block of a
+    // pair parks its items here; its operands live in scratch set (i & 1) and in saved activations, which nothing touches before the
+    // next block's flush point (backward_layer).  A launch of 1536 tiles of 128 x 128 fills the chip in whole rounds, 768 do not.
+    GroupedWgrad pend_w;
+    bool pend = false;
     float *fused_mW = nullptr, *fused_vW = nullptr;
     AdamWHyper fused_h = {0, 0, 0, 0, 0, 1, 1, 1};
     bool wire() const { return gWb && d.dtype == MEBT_BF16 && !grad_acc && !fused_on; }
@@ -1020,6 +1025,28 @@ static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd, bool with_col
     return MEBT_OK;
 }
 
+// The flush point of a block's weight gradients.  MEBT_WGRAD_PAIR=1 (bf16 engine, leaves on the main stream): every other block
+// parks its items and the next block launches both blocks' products together (see mebt_model::pend_w).
+static int flush_or_park(mebt_model* m, Leaves& lv, hipStream_t sd, bool side) {
+    static const bool pair_on = [] { const char* e = getenv("MEBT_WGRAD_PAIR"); return e && e[0] == '1'; }();
+    if (!pair_on || side || m->d.dtype != MEBT_BF16 || lv.w.n > MEBT_MAX_GROUP / 2) return flush_leaves(m, lv, sd);
+    if (!m->pend) {
+        m->pend_w = lv.w;
+        m->pend = true;
+        return MEBT_OK;
+    }
+    for (int k = 0; k < m->pend_w.n && lv.w.n < MEBT_MAX_GROUP; ++k) lv.w.g[lv.w.n++] = m->pend_w.g[k];
+    m->pend = false;
+    return flush_leaves(m, lv, sd);
+}
+static int flush_parked(mebt_model* m, hipStream_t sd) {
+    if (!m->pend) return MEBT_OK;
+    Leaves lv;
+    lv.w = m->pend_w;
+    m->pend = false;
+    return flush_leaves(m, lv, sd);
+}
+
 static int backward_layer(mebt_model* m, int i, hipStream_t st) {
     FwdCtx& x = m->ctx;
     LayerAct& a = x.L[i];
@@ -1107,7 +1134,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
         RC(dgrad(m, sc.dqkv_q, 3 * d, o.wq, sc.dqn, Mq, 3 * d, d, EPI_RESID, sc.dx, d, st, i > 0 ? m->lo[i - 1].w2 : -1, 4 * dd,
                  i > 0 ? &x.L[i - 1] : nullptr, 1));   // + dx (residual on qn)
         if (side) RC(fork_side(m, st));
-        RC(flush_leaves(m, lv, sd));
+        RC(flush_or_park(m, lv, sd, side));
         if (ismg) {      // LN1 rows [0,NC) of each sample came from the contexts stream, the rest from the targets stream
             const int NC = x.NC;
             ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_C, 1, 0, B * NC, NC, NC + NT, 0);
@@ -1131,7 +1158,7 @@ static int backward_layer(mebt_model* m, int i, hipStream_t st) {
             if (Mk > 0) RC(gemm_pair(m, pk, pq, st)); else RC(gemm(m, pq, st));
         }
         if (side) RC(fork_side(m, st));
-        RC(flush_leaves(m, lv, sd));
+        RC(flush_or_park(m, lv, sd, side));
         if (mode == MEBT_MODE_LATENT_ENC) {
             ln1(a.q_in, sc.dqn, nullptr, a.mean1q, a.rstd1q, x.g_S, 0, 0, Mq, 0, 0, 0);
             if (Mk > 0) {   // contexts feed every latent_enc block: accumulate in fp32
@@ -1172,7 +1199,9 @@ extern "C" int mebt_backward_layers(mebt_model* m, void* ws, int32_t layer_hi, i
     if (!m || !m->ctx.valid || m->ctx.ws != ws) { mebt_set_error("backward: no training-mode forward on this workspace"); return MEBT_EINVAL; }
     if (layer_hi >= m->d.n_layer || layer_lo < 0 || layer_lo > layer_hi) { mebt_set_error("backward_layers: bad layer range"); return MEBT_EINVAL; }
     if (m->ctx.last_bwd_lo != layer_hi + 1) m->ctx.doutm_ready = -1;     // not the block right below the previous call's range
+    m->pend = false;
     for (int i = layer_hi; i >= layer_lo; --i) RC(backward_layer(m, i, S(stream)));
+    RC(flush_parked(m, S(stream)));            // an odd block count, or the last block of a gradient bucket
     m->ctx.last_bwd_lo = layer_lo;
     return join_side(m, S(stream));          // the caller may all-reduce these gradients next
 }

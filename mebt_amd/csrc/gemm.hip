@@ -56,6 +56,8 @@ static int g_gemm_force_split = 0;
 static int g_gemm_force_tile = 0;     // (BM << 12) | BN, tests / tools only
 static int g_grouped_stages = 2;
 extern "C" void mebt_debug_grouped_stages(int n) { g_grouped_stages = n; }
+static int g_grouped_force = 0;       // (tbm << 20) | (tbn << 8) | ring: tools/wgrad_bench.py times tile shapes the table does not hold
+extern "C" void mebt_debug_grouped_config(int32_t tbm, int32_t tbn, int32_t ring) { g_grouped_force = (tbm && tbn) ? ((tbm << 20) | (tbn << 8) | ring) : 0; }
 static int g_gemm_dma = -1;           // -1 autotune / heuristic; forced (tests, tools): 0 register-staged, 2..5 LDS-DMA ring depth, 16+r two pipelines, 32+r / 64+r split-K 2 / 4
 static int g_gemm_nostore = 0;        // experiments only (variant >= 100): skip the C store of plain epilogues
 extern "C" void mebt_debug_gemm_variant(int dma) { g_gemm_nostore = dma >= 100; g_gemm_dma = dma >= 100 ? (dma == 199 ? -1 : dma - 100) : dma; }
@@ -679,6 +681,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
         }
         if (it != g_tuned.end()) { tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; stages = it->second & 255; }
     }
+    if (g_grouped_force) { tbm = g_grouped_force >> 20; tbn = (g_grouped_force >> 8) & 0xFFF; stages = g_grouped_force & 255; }
     launch_grouped_config(c, tbm, tbn, stages, stream);
     MEBT_HIP_CHECK(hipGetLastError());
     return MEBT_OK;

@@ -1083,12 +1083,13 @@ __global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmPair g) {
 template <int TBM, int TBN, int NSTAGE>
 __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile = blockIdx.x;
     int g = 0;
 #pragma unroll
     for (int i = 1; i < MEBT_MAX_GROUP; ++i)
-        if (i < w.n && (int)blockIdx.x >= w.tile_start[i]) g = i;
+        if (i < w.n && tile >= w.tile_start[i]) g = i;
     const GroupedWgrad::Item& it = w.g[g];
-    const int t = blockIdx.x - w.tile_start[g];
+    const int t = tile - w.tile_start[g];
     GemmParams p;
     p.A = it.A; p.B = it.B; p.C = it.C; p.C2 = nullptr; p.bias = nullptr; p.aux = nullptr;
     p.M = it.M; p.N = it.N; p.K = it.K; p.lda = it.lda; p.ldb = it.ldb; p.ldc = it.ldc; p.ld_aux = 0;

@@ -71,9 +71,9 @@ int launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 // block, forward and dgrad): one kernel boundary less and a fuller grid than either product alone
 int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int dtype, hipStream_t stream);
 struct GemmPair { GemmParams p[2]; int tiles0; int ntx[2]; };     // kernel argument of the pair launch
-// Up to 8 independent weight-gradient products dW_g = dY_g^T X_g (both operands row-contiguous, fp32
+// Up to MEBT_MAX_GROUP independent weight-gradient products dW_g = dY_g^T X_g (both operands row-contiguous, fp32
 // result) in ONE launch: at batch 6 a single dW has 64-256 tiles, a layer's worth fills the chip.
-#define MEBT_MAX_GROUP 8
+#define MEBT_MAX_GROUP 12      // two blocks' worth of weight gradients (2 x (q, k|v, proj, fc1, fc2) + spare)
 struct GroupedWgrad {
     int n;
     int tile_start[MEBT_MAX_GROUP + 1];

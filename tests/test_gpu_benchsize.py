@@ -399,15 +399,14 @@ def test_c4_bf16_draft_and_revise_every_forward_vs_oracle(ucf):
     ocfg = oracle_cfg_of(cfg)
     B, N = 1, 8192
     n_draft, n_revise, M = 2, 8, 1
-    base = torch.empty(8192, 2048).exponential_(generator=torch.Generator().manual_seed(55001))
 
     def stream(k, kind, shape):
+        # fresh Exp(1) draws for every [1, NT, 16384] tensor (335 M values over the loop, ~3 s): the rolled-table noise of the fp32 tests
+        # repeats every value 8 times per row, and bf16 logits repeat too (8 significant bits) - equal p with equal q is an EXACT key tie,
+        # which the reference's unstable descending sort and the kernel (lowest index) break differently (first GPU run: 40 of 20 480 draws)
         g = torch.Generator().manual_seed(515100 + k)
         if kind == "perm":
             return torch.randperm(int(shape[0]), generator=g)
-        if len(shape) == 3 and shape[-1] == 16384:
-            rows = base.roll(shifts=37 * k, dims=0)[:shape[1]]
-            return torch.cat([rows.roll(shifts=k * 131 + 17 * i, dims=1) for i in range(8)], dim=1).reshape(shape)
         return torch.empty(tuple(shape), dtype=torch.float32).exponential_(generator=g)
 
     m = presets.build_model(cfg, compute_dtype="bf16")

@@ -41,6 +41,7 @@ struct Args {
     unsigned long long* stamps;  // [grid][2 * rounds * 2]
     unsigned* census;            // [grid]: (xcc << 16) | hw id bits
     unsigned* sink;
+    unsigned long long* clocks;  // [4]: s_memtime (shader clock) and s_memrealtime (100 MHz) at entry and exit of workgroup 0
 };
 
 __device__ __forceinline__ void fill_phase(const Args& a, char* smem, int xcc, int wg_in_xcd, int round, int wave, int lane) {
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256) void probe(const Args a) {
     else if (a.mode == 5) grp = xcc & 1;
     else if (a.mode == 6) grp = se & 1;
     unsigned long long* st = a.stamps + (size_t)blockIdx.x * (4 * a.rounds);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.clocks[0] = __builtin_amdgcn_s_memtime(); a.clocks[1] = __builtin_amdgcn_s_memrealtime(); }
     for (int r = 0; r < a.rounds; ++r) {
         const bool do_fill = a.mode != 1, do_stream = a.mode != 0;
         unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1, t2;
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void probe(const Args a) {
             if (threadIdx.x == 0) { st[4 * r] = t1; st[4 * r + 1] = t2; st[4 * r + 2] = t0; st[4 * r + 3] = t1; }
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.clocks[2] = __builtin_amdgcn_s_memtime(); a.clocks[3] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 }  // namespace
@@ -152,7 +155,8 @@ int main(int argc, char** argv) {
     float *p, *m, *v; unsigned short* lp;
     CK(hipMalloc(&p, per * 4 * pool)); CK(hipMalloc(&m, per * 4 * pool)); CK(hipMalloc(&v, per * 4 * pool)); CK(hipMalloc(&lp, per * 2 * pool));
     CK(hipMemset(p, 0, per * 4 * pool)); CK(hipMemset(m, 0, per * 4 * pool)); CK(hipMemset(v, 0, per * 4 * pool));
-    unsigned* slots; unsigned long long* stamps; unsigned* census;
+    unsigned* slots; unsigned long long* stamps; unsigned* census; unsigned long long* clocks;
+    CK(hipMalloc(&clocks, 4 * 8));
     CK(hipMalloc(&slots, 8 * 8 * 2 * 16 * 4));
     CK(hipMalloc(&stamps, (size_t)grid * 4 * rounds * 8));
     CK(hipMalloc(&census, grid * 4));
@@ -171,7 +175,7 @@ int main(int argc, char** argv) {
             a.fill = fill; a.region = region;
             const size_t o = (size_t)(it % pool) * per;
             a.p = p + o; a.m = m + o; a.v = v + o; a.lp = lp + o;
-            a.rounds = rounds; a.ktiles = ktiles; a.mode = mode; a.cu_slots = slots; a.stamps = stamps; a.census = census; a.sink = nullptr;
+            a.rounds = rounds; a.ktiles = ktiles; a.mode = mode; a.cu_slots = slots; a.stamps = stamps; a.census = census; a.sink = nullptr; a.clocks = clocks;
             CK(hipMemsetAsync(slots, 0, 8 * 8 * 2 * 16 * 4, 0));
             CK(hipEventRecord(e0, 0));
             hipLaunchKernelGGL(probe, dim3(grid), dim3(256), RING * KT_BYTES, 0, a);
@@ -193,10 +197,13 @@ int main(int argc, char** argv) {
                 f += (double)(hs[(size_t)w * 4 * rounds + 4 * r + 1] - hs[(size_t)w * 4 * rounds + 4 * r]);
                 s += (double)(hs[(size_t)w * 4 * rounds + 4 * r + 3] - hs[(size_t)w * 4 * rounds + 4 * r + 2]);
             }
-        f /= (double)grid * rounds * 100.0; s /= (double)grid * rounds * 100.0;       // s_memtime ticks at 100 MHz -> us
+        unsigned long long hk[4];
+        CK(hipMemcpy(hk, clocks, sizeof hk, hipMemcpyDeviceToHost));
+        const double ghz = (double)(hk[2] - hk[0]) / (double)(hk[3] - hk[1]) * 0.1;     // shader-clock ticks per 100 MHz reference tick
+        f /= (double)grid * rounds * ghz * 1e3; s /= (double)grid * rounds * ghz * 1e3;   // s_memtime ticks -> us at the measured clock
         if (mode < 2) base[mode] = sum / reps;
-        printf("mode %d  %-36s  %7.1f us avg  %7.1f us best   per workgroup and round: fill phase %6.1f us, stream phase %6.1f us   (%d CUs used, %d with 3 workgroups)\n",
-               mode, names[mode], sum / reps * 1e3, best * 1e3, f, s, cus, full);
+        printf("mode %d  %-36s  %7.1f us avg  %7.1f us best   per workgroup and round: fill phase %6.1f us, stream phase %6.1f us   shader clock during the last launch %.2f GHz   (%d CUs used, %d with 3 workgroups)\n",
+               mode, names[mode], sum / reps * 1e3, best * 1e3, f, s, ghz, cus, full);
     }
     printf("# sum of the halves %.1f us, max %.1f us\n", (base[0] + base[1]) * 1e3, std::max(base[0], base[1]) * 1e3);
     return 0;
