@@ -103,7 +103,7 @@ struct mebt_model {
     // to W (AdamW) inside the weight-gradient launch instead of being stored in gW
     bool fused_on = false;
     bool grad_acc = false;     // mebt_model_set_grad_accumulate: backward adds to gW / gP instead of overwriting them
-    // Weight gradients of TWO consecutive blocks in one grouped launch (MEBT_WGRAD_PAIR, bf16, no side stream): the first block of a
+    // Weight gradients of TWO consecutive blocks in one grouped launch (bf16, no side stream; MEBT_WGRAD_PAIR=0: off): the first block of a
     // pair parks its items here; its operands live in scratch set (i & 1) and in saved activations, which nothing touches before the
     // next block's flush point (backward_layer).  A launch of 1536 tiles of 128 x 128 fills the chip in whole rounds, 768 do not.
     GroupedWgrad pend_w;
@@ -1025,10 +1025,11 @@ static int flush_leaves(mebt_model* m, Leaves& lv, hipStream_t sd, bool with_col
     return MEBT_OK;
 }
 
-// The flush point of a block's weight gradients.  MEBT_WGRAD_PAIR=1 (bf16 engine, leaves on the main stream): every other block
-// parks its items and the next block launches both blocks' products together (see mebt_model::pend_w).
+// The flush point of a block's weight gradients.  bf16 engine, leaves on the main stream (MEBT_WGRAD_PAIR=0 switches it off): every
+// other block parks its items and the next block launches both blocks' products together (see mebt_model::pend_w) - round 6, one
+// MI355X, three alternating runs: 10.43 -> 10.07 ms per Sky-16f step, GEMM family 8.25 -> 7.86 ms (profiles/r06_wgrad_pair_ab.txt).
 static int flush_or_park(mebt_model* m, Leaves& lv, hipStream_t sd, bool side) {
-    static const bool pair_on = [] { const char* e = getenv("MEBT_WGRAD_PAIR"); return e && e[0] == '1'; }();
+    static const bool pair_on = [] { const char* e = getenv("MEBT_WGRAD_PAIR"); return !(e && e[0] == '0'); }();
     if (!pair_on || side || m->d.dtype != MEBT_BF16 || lv.w.n > MEBT_MAX_GROUP / 2) return flush_leaves(m, lv, sd);
     if (!m->pend) {
         m->pend_w = lv.w;

@@ -149,7 +149,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank_double_batch(dtype, mode, wire, def
 WIRE_BF16_VS_FP32_M_RELL2 = {4: 1e-2, 8: 1.6e-2}      # MEBT_DP_EXCHANGE=rs, 8 ranks: 7 roundings on the wire per element; gate = 2 x measured (see profiles/r04_parity_measured.txt)
 # default exchange (all-to-all + fp32 sum of the ranks' bf16 copies inside the owner's AdamW launch): what is left is
 # each rank's ONE rounding of its own contribution; gate = 2 x measured on MI355X (profiles/r06_parity_measured.txt)
-A2A_VS_FP32_M_RELL2 = {4: 6e-3, 8: 8e-3}
+A2A_VS_FP32_M_RELL2 = {4: 6e-3, 8: 4.5e-3}          # measured 2.93e-3 / 2.19e-3 (reduce-scatter: 5.11e-3 / 8.25e-3)
 
 
 @pytest.mark.parametrize("ranks", [4, pytest.param(8, marks=pytest.mark.skipif(os.environ.get("MEBT_LONG_TESTS") == "0", reason="MEBT_LONG_TESTS=0: without the 8-rank case"))])

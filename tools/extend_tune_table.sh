@@ -10,6 +10,9 @@ rm -f $MEBT_GEMM_TUNE_CACHE
 python3 bench.py --no-cpu-baseline > gpurun_out/tune/ext_full.json 2> gpurun_out/tune/ext_full.err
 python3 bench.py --secondary c5 --c5-batch 4 --no-cpu-baseline > gpurun_out/tune/ext_c5b4.json 2>> gpurun_out/tune/ext_full.err
 MEBT_SAMPLE_BF16_LOGITS=0 python3 bench.py --secondary c4 --c4-legs revise,sample,bootstrap --no-cpu-baseline > gpurun_out/tune/ext_c4_f32logits.json 2>> gpurun_out/tune/ext_full.err
+# the data-parallel step (weight gradients stored as bf16 / fp32 instead of consumed by the fused AdamW epilogue: other grouped signatures)
+MEBT_DP_FORCE=1 python3 bench.py --secondary none --no-cpu-baseline --steps 5 > gpurun_out/tune/ext_dp.json 2>> gpurun_out/tune/ext_full.err
+MEBT_DP_FORCE=1 MEBT_DP_MODE=allreduce python3 bench.py --secondary none --no-cpu-baseline --steps 5 > gpurun_out/tune/ext_dp_ar.json 2>> gpurun_out/tune/ext_full.err
 python3 - <<'PY'
 import os
 root = os.environ.get("GRAFT_REPO_ROOT", ".")
