@@ -646,7 +646,27 @@ def main():
     wire1 = reducer.bytes_on_wire
     # ... and more windows of the same length behind it (outside the judged region): their spread says how much of a difference
     # between two runs of this line is the box and how much the code
-    extra = [window()[0] for _ in range(max(0, args.windows - 1))]
+    # the extra windows also carry a one-wave clock probe on a second stream (mebt_debug_clock_probe: shader-clock ticks per 100 MHz
+    # reference tick over ~70 % of the window): the clock the chip really runs this step at - the judged window stays untouched
+    extra, clock_ghz = [], []
+    probe_stream = None
+    if rank == 0:       # a stream on ANOTHER hardware queue than the compute stream (two streams of one queue run in submission order: the steps
+        from mebt_amd.parallel import pick_concurrent_stream, streams_serialised     # would wait for the sleeping probe)
+        probe_stream = pick_concurrent_stream(torch.cuda.current_stream(), device=device)
+        if streams_serialised(probe_stream, torch.cuda.current_stream()):
+            probe_stream = None
+    for _ in range(max(0, args.windows - 1)):
+        buf = None
+        if probe_stream is not None:
+            buf = torch.zeros(4, dtype=torch.int64, device=device)
+            torch.cuda.synchronize()
+            _lib.check(_lib.load().mebt_debug_clock_probe(_lib.ptr(buf), int(0.7 * elapsed * 1e8), probe_stream.cuda_stream))
+        extra.append(window()[0])
+        if buf is not None:
+            torch.cuda.synchronize()
+            t0_, r0_, t1_, r1_ = (int(v) for v in buf.cpu().tolist())
+            if r1_ > r0_:
+                clock_ghz.append(round((t1_ - t0_) / (r1_ - r0_) * 0.1, 3))
     if sampler is not None:
         sampler.__exit__()
     gpu_after = gpu_state(local_rank) if rank == 0 else None
@@ -795,8 +815,11 @@ def main():
                "windows": {"ms_per_step": win_ms, "median": sorted(win_ms)[len(win_ms) // 2], "min": min(win_ms), "max": max(win_ms),
                            "note": f"{len(win_ms)} back-to-back windows of {args.steps} steps, each barrier + synchronize bracketed; `value` is the FIRST"},
                "gpu_state": {"before": gpu_before, "after": gpu_after, "during_windows": sampler.summary() if sampler is not None else None,
+                             "shader_clock_ghz_in_extra_windows": clock_ghz,
                              "note": "amdgpu sysfs: current sclk / mclk / fclk level, power cap / average before and after the windows (idle readings), "
-                                     "and sclk / power sampled every 25 ms by a host thread while they run"},
+                                     "and sclk / power sampled every 25 ms by a host thread while they run (on this pool the sysfs sclk does not follow the load: "
+                                     "`shader_clock_ghz_in_extra_windows` is measured in a kernel, s_memtime against the 100 MHz s_memrealtime, beside the steps of the "
+                                     "windows behind the judged one)"},
                "config": {"workload": "Sky-Timelapse 16f MeBT train step: 24L/1024d/16h, 1024 VQ tokens + 256 latents, "
                                       f"batch {args.batch}/GPU, t={args.t} (NC=NT={n_targets // args.batch}), "
                                       "fwd + masked CE + bwd + AdamW" + ((f" + {'all-to-all (fp32 sum at the owner)' if (reducer.wire == 'bf16' and reducer.exchange == 'a2a') else 'reduce-scatter'} / sharded AdamW / all-gather ({reducer.wire} wire)" if reducer.mode == "sharded" else " + bucketed fp32 all-reduce") if reducer.active else ""),

@@ -338,6 +338,10 @@ int32_t mebt_profile_read_waits(int32_t cap, int32_t* layer, double* ms);
  * of site `site` under `seed` — fill `out` with ones to read the mask the kernels use.  Site ids: 16*layer
  * + {0 attention probabilities, 1 proj output, 2 MLP output}; 0xFFFF0/1/2 = embedded sos/contexts/targets. */
 int mebt_debug_dropout_mask(uint64_t seed, uint32_t site, float p, int64_t n, float* out, mebt_stream_t stream);
+/* Diagnostics (bench.py): one wave on `stream` writes {s_memtime, s_memrealtime} at its start and again after `ref_ticks_100mhz`
+ * ticks of the constant 100 MHz reference counter (<= 1 s) into out4[0..3]: (out4[2] - out4[0]) / (out4[3] - out4[1]) x 100 MHz is the
+ * shader clock the GPU ran at in between, under whatever load the other streams put on it. */
+int mebt_debug_clock_probe(unsigned long long* out4, uint64_t ref_ticks_100mhz, mebt_stream_t stream);
 /* Benchmarking / tests only: 0 = keep every launch on the caller's stream (no side stream for gradient leaves). */
 void mebt_debug_side_stream(mebt_model* m, int32_t on);
 /* experiment: run that second stream's work on a caller-owned stream instead (NULL: back to the internal one) */

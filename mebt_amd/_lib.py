@@ -80,6 +80,7 @@ PROTOTYPES = {
     "mebt_op_embedding_rows": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "mebt_op_cast_f16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "mebt_debug_dropout_mask": (c_i32, [C.c_uint64, C.c_uint32, c_f32, c_i64, c_vp, c_vp]),
+    "mebt_debug_clock_probe": (c_i32, [c_vp, C.c_uint64, c_vp]),
     "mebt_debug_side_stream": (None, [c_vp, c_i32]),
     "mebt_debug_set_side_stream": (None, [c_vp, c_vp]),
     "mebt_debug_gemm_tile": (None, [c_i32, c_i32]),

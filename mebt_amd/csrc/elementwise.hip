@@ -1005,3 +1005,21 @@ int launch_cast_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s
     CHECK_LAUNCH();
     return MEBT_OK;
 }
+
+// Diagnostics (bench.py): ONE wave records the shader clock counter (s_memtime) and the constant 100 MHz reference (s_memrealtime),
+// sleeps until `ref_ticks` reference ticks have passed and records both again: (d memtime / d realtime) x 100 MHz is the shader clock
+// the chip really ran at in between - while whatever else is on the GPU runs (the sysfs sclk reading of these boxes does not move).
+namespace {
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, unsigned long long ref_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - r0 < ref_ticks) __builtin_amdgcn_s_sleep(127);
+    out[0] = t0; out[1] = r0; out[2] = __builtin_amdgcn_s_memtime(); out[3] = __builtin_amdgcn_s_memrealtime();
+}
+}  // namespace
+extern "C" int mebt_debug_clock_probe(unsigned long long* out4, uint64_t ref_ticks_100mhz, void* stream) {
+    if (!out4 || ref_ticks_100mhz > 100000000ull) { mebt_set_error("clock_probe: null output or more than one second"); return MEBT_EINVAL; }
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), out4, (unsigned long long)ref_ticks_100mhz);
+    CHECK_LAUNCH();
+    return MEBT_OK;
+}

@@ -654,7 +654,7 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
         if (it == g_tuned.end() && g_autotune && !c.beta && tune_scratch_of(w.scratch)) {
             TuneRun tr;
             if (int rc = tr.begin(scratch_of(w.scratch))) return rc;
-            static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+            static const int tiles[5][2] = {{256, 128}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
             float best = 1e30f;
             // candidates are timed in the mode that will run; a fused launch is not idempotent, so its candidates
             // run with a zero learning rate, zero decay and beta1 = beta2 = 1 (p, m, v are rewritten unchanged)
@@ -662,8 +662,9 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
             for (int i = 0; i < n; ++i) tc.g[i].bias = nullptr;      // the bias row sums are atomic adds: not in the repeated candidate runs
             if (tc.fused) { tc.opt.lr = 0.f; tc.opt.weight_decay = 0.f; tc.opt.beta1 = 1.f; tc.opt.beta2 = 1.f; }
             std::vector<std::pair<int, float>> alts;
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 5; ++t)
                 for (int st = 2; st <= 4; ++st) {
+                    if (tiles[t][0] == 256 && st > 3) continue;            // 8-wave 256 x 128: ring 2 or 3 (4 x 48 KiB does not fit the 160 KiB LDS)
                     float ms = 0.f;
                     if (int rc = time_cold([&] { launch_grouped_config(tc, tiles[t][0], tiles[t][1], st, stream); }, stream, tr, ms)) return rc;
                     alts.emplace_back((tiles[t][0] << 20) | (tiles[t][1] << 8) | st, ms);
@@ -680,6 +681,14 @@ int launch_wgrad_grouped(GroupedWgrad& w, int dtype, hipStream_t stream) {
             tune_remember(key, it->second);
         }
         if (it != g_tuned.end()) { tbm = it->second >> 20; tbn = (it->second >> 8) & 0xFFF; stages = it->second & 255; }
+    }
+    {   // experiments (tools/env_ab_cached.sh): MEBT_GROUPED_FORCE=256x128x2 = that tile / ring for every grouped launch
+        static const int env_force = [] {
+            const char* e = getenv("MEBT_GROUPED_FORCE");
+            int a = 0, b = 0, r = 0;
+            return (e && sscanf(e, "%dx%dx%d", &a, &b, &r) == 3 && a && b) ? ((a << 20) | (b << 8) | r) : 0;
+        }();
+        if (env_force && !g_grouped_force) { tbm = env_force >> 20; tbn = (env_force >> 8) & 0xFFF; stages = env_force & 255; }
     }
     if (g_grouped_force) { tbm = g_grouped_force >> 20; tbn = (g_grouped_force >> 8) & 0xFFF; stages = g_grouped_force & 255; }
     launch_grouped_config(c, tbm, tbn, stages, stream);

@@ -540,15 +540,19 @@ struct DmaLoader {
 // For outputs of a chip's worth of tiles or less and a deep reduction (the MLP down-projection and its dgrad:
 // 256 tiles x 64 k-tiles) a single 4-wave workgroup per CU is bound by the latency of one k-step (barrier, LDS
 // read, 12-24 dependent MFMAs); the second pipeline fills exactly those bubbles.
-template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE, int KS = 1, bool ROWSUM = false>
+// NW = 8 (KS = 1 only): ONE pipeline of eight waves, 4 (M) x 2 (N), on a tile twice as tall (256 x 128: the wave tile stays 64 x 64) -
+// per k-tile 48 KiB for 4.2 MFLOP, a quarter less L2 -> LDS traffic per output than 128 x 128 (grouped weight gradients of a block pair:
+// 768 tiles = three whole rounds of one workgroup per CU).
+template <bool A_KC, bool B_KC, int TBM, int TBN, int NSTAGE, int KS = 1, bool ROWSUM = false, int NW = 4>
 __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n0, int kt0, int kt1, char* smem, bool atomic, bool add_bias) {
+    static_assert(NW == 4 || (NW == 8 && KS == 1), "eight waves run as one pipeline");
     constexpr int STAGE = (TBM + TBN) * BK * 2;
-    constexpr int TM = TBM / 32, TN = TBN / 32;
-    constexpr int LPT = (TBM + TBN) / 32;              // DMA instructions per wave per tile
+    constexpr int TM = TBM / (8 * NW), TN = TBN / 32;  // waves (NW / 2) x 2
+    constexpr int LPT = (TBM + TBN) / (8 * NW);        // DMA instructions per wave per tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = KS == 2 ? wave8 >> 2 : 0;          // pipeline of this wave
-    const int wave = wave8 & 3;
+    const int wave = NW == 8 ? wave8 : (wave8 & 3);
     const int wm = wave >> 1, wn = wave & 1;
     const int nk = (kt1 - kt0) / KS;                    // k-tiles per pipeline (the launcher guarantees divisibility)
     char* ring = smem + grp * (NSTAGE * STAGE);
@@ -559,8 +563,8 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
         stamp = p.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
         stamp[0] = __builtin_amdgcn_s_memtime();
     }
-    DmaLoader<A_KC, TBM> la;
-    DmaLoader<B_KC, TBN> lb;
+    DmaLoader<A_KC, TBM, NW> la;
+    DmaLoader<B_KC, TBN, NW> lb;
     la.init(p.A, p.M, p.K, p.lda, m0, wave, lane);
     lb.init(p.B, p.N, p.K, p.ldb, n0, wave, lane);
 
@@ -629,7 +633,7 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
     if (ROWSUM && do_rs && (lane >> 4) == 0) {          // every column of rs[i] holds the sum of row (lane & 15) of fragment i
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * (TBM / 2) + i * 16 + (lane & 15);
+            const int m = m0 + wm * (TM * 16) + i * 16 + (lane & 15);
             if (m < p.M) atomicAdd(p.rowsum_a + m, rs[i][0]);
         }
     }
@@ -651,9 +655,9 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, int m0, int n
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] += red[(i * TN + j) * 64];
-        epilogue_via_lds<TM, TN, false>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
+        epilogue_via_lds<TM, TN, false>(p, acc, smem, wave, lane, m0 + wm * (TM * 16), n0 + wn * (TBN / 2), add_bias, atomic);
     } else {
-        epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TBM / 2), n0 + wn * (TBN / 2), add_bias, atomic);
+        epilogue_via_lds<TM, TN>(p, acc, smem, wave, lane, m0 + wm * (TM * 16), n0 + wn * (TBN / 2), add_bias, atomic);
     }
     if (stamp) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's own stores have left
@@ -1080,8 +1084,8 @@ __global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmPair g) {
 }
 
 // grouped weight gradients: blockIdx.x enumerates the tiles of all groups (RC x RC, fp32 result)
-template <int TBM, int TBN, int NSTAGE>
-__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w) {
+template <int TBM, int TBN, int NSTAGE, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void wgrad_grouped_kernel(const GroupedWgrad w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x;
     int g = 0;
@@ -1105,7 +1109,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const GroupedWgrad w
     int tr, tc;
     xcd_tile(t, it.ntx, (it.M + TBM - 1) / TBM, it.M, it.N, tr, tc);
     const int m0 = tr * TBM, n0 = tc * TBN;
-    gemm_tile_dma<false, false, TBM, TBN, NSTAGE, 1, true>(p, m0, n0, 0, (it.K + BK - 1) / BK, smem, false, false);
+    gemm_tile_dma<false, false, TBM, TBN, NSTAGE, 1, true, NW>(p, m0, n0, 0, (it.K + BK - 1) / BK, smem, false, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1380,7 +1384,11 @@ static void layout_launch_grouped(GroupedWgrad& c, int tbm, int tbn, int stages,
         else if (stages == 3) hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 3>), dim3(tiles), dim3(256), 3 * (TM_ + TN_) * BK * 2, stream, c); \
         else hipLaunchKernelGGL((wgrad_grouped_kernel<TM_, TN_, 2>), dim3(tiles), dim3(256), 2 * (TM_ + TN_) * BK * 2, stream, c);                 \
     } while (0)
-    if (tbm == 128 && tbn == 128) LAUNCH_G(128, 128);
+    if (tbm == 256 && tbn == 128) {          // eight waves, one workgroup per CU (ring 2: 96 KiB, ring 3: 144 KiB)
+        if (stages >= 3) hipLaunchKernelGGL((wgrad_grouped_kernel<256, 128, 3, 8>), dim3(tiles), dim3(512), 3 * 384 * BK * 2, stream, c);
+        else hipLaunchKernelGGL((wgrad_grouped_kernel<256, 128, 2, 8>), dim3(tiles), dim3(512), 2 * 384 * BK * 2, stream, c);
+    }
+    else if (tbm == 128 && tbn == 128) LAUNCH_G(128, 128);
     else if (tbm == 128 && tbn == 64) LAUNCH_G(128, 64);
     else if (tbm == 64 && tbn == 128) LAUNCH_G(64, 128);
     else LAUNCH_G(64, 64);
@@ -1462,5 +1470,7 @@ static int layout_set_grouped_attrs() {
     } while (0)
     SET_G(128, 128); SET_G(128, 64); SET_G(64, 128); SET_G(64, 64);
 #undef SET_G
+    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<256, 128, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * BK * 2));
+    MEBT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_kernel<256, 128, 3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 384 * BK * 2));
     return MEBT_OK;
 }

@@ -717,13 +717,26 @@ def _grouped_call(items, fused, step=1, lr=1e-3, wd=0.05, with_bias=True, seed=0
     return gW, biases, W, mW, vW, Wlp, offs, grads, bsum, ref
 
 
+@pytest.fixture(params=[None, (256, 128, 2), (256, 128, 3), (128, 128, 2), (64, 128, 4)], ids=lambda c: "tuned" if c is None else "%dx%dr%d" % c)
+def grouped_config(request):
+    """every tile shape / ring depth of the grouped weight-gradient launch, incl. the 8-wave 256 x 128 form (round 6), forced through
+    mebt_debug_grouped_config"""
+    c = request.param
+    lib().mebt_debug_grouped_config(*(c if c else (0, 0, 0)))
+    yield c
+    lib().mebt_debug_grouped_config(0, 0, 0)
+
+
 @pytest.mark.parametrize("items", [[(256, 128, 200), (128, 512, 200), (128, 128, 77)], [(64, 64, 24), (256, 64, 24), (64, 256, 9)],
-                                   [(1024, 1024, 384), (4096, 1024, 384), (1024, 4096, 384), (2048, 1024, 768)]])
-def test_wgrad_grouped_operator(items):
+                                   [(1024, 1024, 384), (4096, 1024, 384), (1024, 4096, 384), (2048, 1024, 768)],
+                                   [(1024, 4096, 448), (4096, 1024, 448), (1024, 1024, 448), (1024, 1024, 448), (2048, 1024, 200),
+                                    (1024, 4096, 136), (4096, 1024, 136), (1024, 1024, 136), (3072, 1024, 136)]])
+def test_wgrad_grouped_operator(items, grouped_config):
     """`mebt_op_wgrad_grouped`: the weight gradients of a block in one launch against fp32 matmuls of the same bf16 operands —
     the stored gradients, the bias gradients added up inside the launch (tile column 0, ones-fragment MFMA), and the
-    optimizer-in-backward form against torch-semantics AdamW on those gradients.  Ragged tiles (64-wide weights under 128-wide
-    tiles) and ragged reductions (tokens not a multiple of the 64-deep k-tile)."""
+    optimizer-in-backward form against torch-semantics AdamW on those gradients.  Ragged tiles (64-wide weights under 128- and 256-wide
+    tiles) and ragged reductions (tokens not a multiple of the 64-deep k-tile); the last case is a PAIR of blocks as the engine launches
+    them since round 6 (9 products in one launch)."""
     gW, biases, W, mW, vW, Wlp, offs, grads, bsum, ref = _grouped_call(items, fused=False)
     for (no, ki, t), o, gr, b, bs in zip(items, offs, grads, biases, bsum):
         got = gW[o:o + no * ki].view(no, ki)
