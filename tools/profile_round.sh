@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export MEBT_GEMM_TUNE_CACHE=$OUT/tune_cache.txt
-ARGS="$ROOT/bench.py --steps 10 --warmup 5 --secondary none --no-cpu-baseline"
+ARGS="$ROOT/bench.py --steps 10 --warmup 5 --windows 1 --secondary none --no-cpu-baseline"      # one window: no clock probe / stream probing kernels in the trace
 cd "$ROOT" && python3 $ARGS > "$OUT/populate.json" 2> "$OUT/populate.err"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 $ARGS > "$OUT/stats.json" 2> "$OUT/stats.err"
