@@ -92,6 +92,8 @@ def cpu_baseline(model_sd, cfg, t, sample_B=6):
     dt, ntg = runs[best]
     return {"value": ntg / dt, "unit": "masked tokens/s", "cores": best, "kind": "port", "os_cpu_count": ncpu,
             "by_threads": {str(k): round(v[1] / v[0], 1) for k, v in runs.items()},
+            "cores_note": f"{best} of {ncpu} hardware threads on purpose: `value` is the FASTEST thread count tried (by_threads); torch's CPU kernels "
+                          "get slower beyond it on these hosts (256 threads: 6.9 masked tokens/s, round 2)",
             "sample": f"best of 2 timed train steps (fwd+CE+bwd+AdamW, after 1 warm-up) per thread count at batch {sample_B}, "
                       f"NC=NT={ntg // sample_B}, fp32, torch {torch.__version__} CPU, {cpu_model_name()} (os.cpu_count() = {ncpu}); "
                       f"{dt:.1f} s per step at {best} threads"}

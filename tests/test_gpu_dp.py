@@ -157,11 +157,12 @@ def test_two_ranks_on_one_gpu_equal_the_oracle_steps(dtype, wire):
     from mebt_amd import presets
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, free_port(), dtype, "sharded", wire, True, ret, True)) for r in range(2)]
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dtype, "sharded", wire, True, ret, True)) for r in range(2)]
     for p in procs:
         p.start()
     try:
-        sd2, loss2, stale, adam2, _ = ret.get(timeout=900)
+        sd2, loss2, stale, adam2, _ = ret.get(timeout=300)
         for p in procs:
             p.join(timeout=120)
             assert p.exitcode == 0
