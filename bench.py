@@ -789,6 +789,37 @@ def main():
             solo[name] = 1e3 * (time.perf_counter() - t1) / K
         model._reducer = reducer
         loop.native.enable_wire_grads(loop.wire_grads)       # the one-rank loops above unbound it
+        # the two ways to exchange a bf16 bucket, timed on this node (a 4-layer bucket: 50.3 M gradients = 100.7 MB per rank): the default
+        # all-to-all (fp32 sum at the owner) against RCCL's reduce-scatter (bf16 sum) - MEBT_DP_EXCHANGE picks; max over ranks, median of 5
+        exchange_probe = None
+        if backend == "nccl":
+            try:
+                nb = 4 * 12 * 1024 * 1024
+                nb -= nb % (4 * world)
+                send = torch.zeros(nb, dtype=torch.bfloat16, device=device)
+                recv = torch.empty(nb, dtype=torch.bfloat16, device=device)
+                out = torch.empty(nb // world, dtype=torch.bfloat16, device=device)
+                exchange_probe = {}
+                for name, fn in (("all_to_all_ms", lambda: dist.all_to_all_single(recv, send)),
+                                 ("reduce_scatter_ms", lambda: dist.reduce_scatter_tensor(out, send, op=dist.ReduceOp.SUM))):
+                    ts_ = []
+                    for it in range(7):
+                        sync()
+                        t1 = time.perf_counter()
+                        fn()
+                        torch.cuda.synchronize()
+                        el = time.perf_counter() - t1
+                        if world > 1:
+                            tt = torch.tensor([el], device=device, dtype=torch.float64)
+                            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                            el = float(tt.item())
+                        if it >= 2:
+                            ts_.append(1e3 * el)
+                    exchange_probe[name] = round(sorted(ts_)[len(ts_) // 2], 3)
+                exchange_probe["bucket_MB"] = round(nb * 2 / 1e6, 1)
+                del send, recv, out
+            except Exception as e:          # noqa: BLE001
+                exchange_probe = {"error": f"{type(e).__name__}: {e}"}
         dp = {"dp_mode": reducer.mode, "wire": reducer.wire if reducer.mode == "sharded" else "fp32",
               "gradient_sum": ("fp32 at the owning rank (bf16 all-to-all of the shards, mebt_adamw_slice_pieces)" if (reducer.mode == "sharded" and reducer.wire == "bf16" and reducer.exchange == "a2a")
                                else "bf16 inside RCCL's reduce-scatter" if (reducer.mode == "sharded" and reducer.wire == "bf16") else "fp32 inside RCCL"),
@@ -807,6 +838,7 @@ def main():
               "scaling_efficiency_note": "per-GPU throughput of this run / per-GPU throughput of ONE rank of this job alone on its GPU (rank 0's figure): "
                                          "against the fused step the N = 1 headline runs (the judged figure), and against gradients stored + streaming AdamW "
                                          "(what a rank computes, minus the sharding)",
+              "exchange_probe": exchange_probe,
               "gemm_table_sync": "one broadcast of rank 0's GEMM tuning table behind the warm-up; further syncs (a host read that drains every rank's "
                                  "queue; every 256 steps in training) are HELD while the windows are timed",
               "comm_env": comm_env()}
