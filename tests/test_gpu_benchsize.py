@@ -684,7 +684,7 @@ def test_c2_ragged_shapes_bf16_engine_vs_fp32_engine(B, t):
     assert not bad, (len(bad), bad[:20])
 
 
-def _replay_steps_prove_ties(m, steps, stream, temperature, max_ties=3, top_k=None, min_ties=1):
+def _replay_steps_prove_ties(m, steps, stream, temperature, max_ties=3, top_k=None, min_ties=1, tie_steps=None):
     """`got != ref` after a sampling loop: replay every recorded step of the ORACLE on the HIP path from the oracle's own state —
     logits within 1e-3, and sampled ids different only where the oracle's own numbers say a logit difference of the measured
     size may flip the draw, after which the two runs legitimately diverge:
@@ -694,7 +694,8 @@ def _replay_steps_prove_ties(m, steps, stream, temperature, max_ties=3, top_k=No
         the other dropped (torch.topk boundary, modules/gpt.py:233-238)."""
     from mebt_amd.transformer import sample_from_logits_scored
     n_tie = 0
-    for s in steps:
+    for si, s in enumerate(steps):
+        n_before = n_tie
         lg, _ = m.reconstruct_mask(s["partial"].to(DEV), s["c"].to(DEV), s["t"].to(DEV))
         d_lg = (lg.cpu() - s["logits"]).abs().max().item()
         assert d_lg < 1e-3
@@ -716,6 +717,8 @@ def _replay_steps_prove_ties(m, steps, stream, temperature, max_ties=3, top_k=No
             assert gap <= 2 * d_lg and (int(ids[b, j]) in edge or int(oid[b, j]) in edge), \
                 ("neither a key tie nor a top-k boundary", b, j, float(top2[0] / top2[1]), gap, d_lg)
             n_tie += 1
+        if tie_steps is not None and n_tie > n_before:
+            tie_steps.append(si)                         # the forwards whose draw has a proven tie: the runs may part ways right behind them
     assert min_ties <= n_tie <= max_ties, n_tie        # a difference must be explained by at least one flipped tie, and ties are rare
     return n_tie
 
@@ -744,7 +747,7 @@ class _MaskOrderRecorder:
     def __exit__(self, *a):
         orc.gumbel_top_k = self._orig
 
-    def prove_order_ties(self, hsteps, max_ties=64, rel=2e-4):
+    def prove_order_ties(self, hsteps, max_ties=64, rel=2e-4, draw_tie_steps=()):
         """`hsteps`: the (c, t, partial) the HIP run really fed to its forwards, in order.  Finds the first forward whose inputs differ
         from the oracle's and proves that difference is a re-ordering of near-equal confidence keys: same context SET, same target
         SET, same token ids so far, and at every position where the target order differs the two elements' oracle keys are within
@@ -754,6 +757,8 @@ class _MaskOrderRecorder:
                 and torch.equal(h["partial"].reshape(-1), o["partial"].reshape(-1))
             if same:
                 continue
+            if i > 0 and (i - 1) in draw_tie_steps and not torch.equal(h["partial"].reshape(-1), o["partial"].reshape(-1)):
+                return i, 0          # the runs part ways at a PROVEN draw tie of forward i - 1 (step-by-step replay): nothing to explain here
             assert i > 0 and (i - 1) in self.rec, ("inputs differ at a step no mask re-ordering precedes", i)
             assert h["c"].shape == o["c"].shape and h["t"].shape == o["t"].shape, (i, h["c"].shape, o["c"].shape)
             assert torch.equal(h["partial"].reshape(-1), o["partial"].reshape(-1)), ("token ids differ before any re-ordering", i)
@@ -873,8 +878,9 @@ def test_c4_bidirect_sample_bootstrap_topk_block8192(ucf):
         np.testing.assert_allclose(log["score"].cpu().numpy(), score.numpy(), rtol=1e-4)
     else:       # every forward replayed from the oracle's state (draw ties), then the first forward whose inputs differ (mask-order ties)
         m.reconstruct_mask = type(m).reconstruct_mask.__get__(m)
-        n_tie = _replay_steps_prove_ties(m, steps, stream, 1.0, max_ties=64, top_k=32, min_ties=0)
-        first, n_swap = mask_rec.prove_order_ties(hsteps)
+        tie_steps = []
+        n_tie = _replay_steps_prove_ties(m, steps, stream, 1.0, max_ties=64, top_k=32, min_ties=0, tie_steps=tie_steps)
+        first, n_swap = mask_rec.prove_order_ties(hsteps, draw_tie_steps=tie_steps)
         assert n_tie + n_swap > 0
     msg = (f"[c4 bidirect_sample block 8192 bootstrap {boot} top_k 32 steps {n_steps}] {len(steps)} forwards; code map == oracle: {same} "
            f"(proven fp ties in the replay: {n_tie} draws, {n_swap} re-ordered targets of near-equal confidence at forward {first}); HIP {t_hip:.1f} s, oracle {t_orc:.1f} s")
@@ -953,8 +959,9 @@ def _drive_both(m, stream, hip_call, oracle_call):
 
 def _explain_difference(m, steps, hsteps, mask_rec, stream, temperature, top_k=None):
     """code maps differ: draw ties (every oracle step replayed on the HIP path) and / or a re-ordering of near-equal confidences"""
-    n_tie = _replay_steps_prove_ties(m, steps, stream, temperature, max_ties=16, top_k=top_k, min_ties=0)
-    first, n_swap = mask_rec.prove_order_ties(hsteps)
+    tie_steps = []
+    n_tie = _replay_steps_prove_ties(m, steps, stream, temperature, max_ties=16, top_k=top_k, min_ties=0, tie_steps=tie_steps)
+    first, n_swap = mask_rec.prove_order_ties(hsteps, draw_tie_steps=tie_steps)
     assert n_tie + n_swap > 0
     return n_tie, n_swap, first
 
