@@ -36,11 +36,18 @@ __device__ __forceinline__ void stage_tile(float (*dst)[HD], const T* src, int l
     }
 }
 
-template <typename T, int HD>
-__global__ __launch_bounds__(64) void attn_fwd_generic(const AttnParams p) {
-    __shared__ __attribute__((aligned(16))) float sK[KT][HD];
-    __shared__ __attribute__((aligned(16))) float sV[KT][HD];
-    const int b = blockIdx.z, h = blockIdx.y, qi = blockIdx.x * 64 + threadIdx.x;
+// NS waves per workgroup share the 64 rows a workgroup owns (one row per lane in EVERY wave) and split the streamed side: wave w
+// takes the tiles w, w + NS, ... through a staging area of its own, and the NS partial results are merged through LDS at the end
+// (round 6: with one wave per workgroup the fp32 engine's attention ran on a third of the SIMDs, one wave each - 256 x 96 / 64 = 384
+// waves for 1024 SIMDs - and was 60 % of the exact-fp32 train step).  Every wave runs the same number of iterations (empty tiles at
+// the end) so that the workgroup barriers match.
+template <typename T, int HD, int NS>
+__global__ __launch_bounds__(64 * NS) void attn_fwd_generic(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float (*sK)[HD] = reinterpret_cast<float (*)[HD]>(smem_raw) + (size_t)wave * 2 * KT;
+    float (*sV)[HD] = sK + KT;
+    const int b = blockIdx.z, h = blockIdx.y, qi = blockIdx.x * 64 + lane;
     const bool valid = qi < p.NQ;
     const float scale = rsqrtf((float)HD);
     float q[HD], o[HD];
@@ -50,37 +57,71 @@ __global__ __launch_bounds__(64) void attn_fwd_generic(const AttnParams p) {
     float m = -INFINITY, l = 0.f;
     const T* kb = reinterpret_cast<const T*>(p.k) + (size_t)b * p.NK * p.ldk + h * HD;
     const T* vb = reinterpret_cast<const T*>(p.v) + (size_t)b * p.NK * p.ldv + h * HD;
-    for (int k0 = 0; k0 < p.NK; k0 += KT) {
-        const int n = min(KT, p.NK - k0);
+    const int ntile = (p.NK + KT - 1) / KT, iters = (ntile + NS - 1) / NS;
+    for (int it = 0; it < iters; ++it) {
+        const int k0 = (it * NS + wave) * KT;
+        const int n = max(0, min(KT, p.NK - k0));
         __syncthreads();
-        stage_tile<T, HD>(sK, kb + (size_t)k0 * p.ldk, p.ldk, n, threadIdx.x, 64);
-        stage_tile<T, HD>(sV, vb + (size_t)k0 * p.ldv, p.ldv, n, threadIdx.x, 64);
-        __syncthreads();
-        float s[KT];
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            float a = 0.f;
-#pragma unroll
-            for (int e = 0; e < HD; ++e) a += q[e] * sK[j][e];
-            s[j] = j < n ? a * scale : -INFINITY;
-            tmax = fmaxf(tmax, s[j]);
+        if (n > 0) {
+            stage_tile<T, HD>(sK, kb + (size_t)k0 * p.ldk, p.ldk, n, lane, 64);
+            stage_tile<T, HD>(sV, vb + (size_t)k0 * p.ldv, p.ldv, n, lane, 64);
         }
-        const float mn = fmaxf(m, tmax);
-        const float alpha = __expf(m - mn);
-        l *= alpha;
-#pragma unroll
-        for (int e = 0; e < HD; ++e) o[e] *= alpha;
+        __syncthreads();
+        if (n <= 0) continue;
+        // groups of four keys: their scores, one rescale of (l, o) to the new running maximum, then the four P V updates.  (The whole
+        // 32-key tile at once - 32 score registers beside q and o, both loops unrolled - spilled 6.8 KB per lane to scratch and made the
+        // forward 8 x slower than the backward kernels: 2.07 ms per launch in the exact-fp32 Sky-16f step, round 6.)
         const uint64_t dbase = (((uint64_t)b * p.H + h) * p.NQ + qi) * p.NK + k0;
+        for (int j0 = 0; j0 < n; j0 += 4) {
+            float s4[4];
+            float tmax = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            float pj = __expf(s[j] - mn);   // exp(-inf) = 0 for padded keys
-            l += pj;
-            if (p.drop.thresh) pj *= drop_keep(p.drop, dbase + j);   // attn_drop acts on the normalised probabilities (gpt.py:135)
+            for (int jj = 0; jj < 4; ++jj) {
+                float a = 0.f;
 #pragma unroll
-            for (int e = 0; e < HD; ++e) o[e] += pj * sV[j][e];
+                for (int e = 0; e < HD; ++e) a += q[e] * sK[j0 + jj][e];        // rows n .. KT-1 of the tile are zero-filled
+                s4[jj] = j0 + jj < n ? a * scale : -INFINITY;
+                tmax = fmaxf(tmax, s4[jj]);
+            }
+            const float mn = fmaxf(m, tmax);                                     // finite: key j0 exists
+            const float alpha = __expf(m - mn);                                  // m = -inf (first group): 0
+            l *= alpha;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) o[e] *= alpha;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                float pj = __expf(s4[jj] - mn);   // exp(-inf) = 0 for padded keys
+                l += pj;
+                if (p.drop.thresh) pj *= drop_keep(p.drop, dbase + j0 + jj);   // attn_drop acts on the normalised probabilities (gpt.py:135)
+#pragma unroll
+                for (int e = 0; e < HD; ++e) o[e] += pj * sV[j0 + jj][e];
+            }
+            m = mn;
         }
-        m = mn;
+    }
+    if (NS > 1) {        // (m, l, o) of waves 1 .. NS-1 -> wave 0, through the staging area
+        constexpr int RL = HD + 2;
+        float* red = reinterpret_cast<float*>(smem_raw);
+        __syncthreads();
+        if (wave > 0) {
+            float* r = red + ((size_t)(wave - 1) * 64 + lane) * RL;
+            r[0] = m; r[1] = l;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) r[2 + e] = o[e];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+        for (int w = 1; w < NS; ++w) {
+            const float* r = red + ((size_t)(w - 1) * 64 + lane) * RL;
+            const float mw = r[0], lw = r[1];
+            if (!(mw > -INFINITY)) continue;             // that wave saw no key
+            const float mn = fmaxf(m, mw);
+            const float a = __expf(m - mn), bw = __expf(mw - mn);     // m = -inf: a = 0
+            l = l * a + lw * bw;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) o[e] = o[e] * a + r[2 + e] * bw;
+            m = mn;
+        }
     }
     if (valid) {
         const float inv = l > 0.f ? 1.f / l : 0.f;    // NK == 0: softmax over an empty axis -> output 0
@@ -90,11 +131,13 @@ __global__ __launch_bounds__(64) void attn_fwd_generic(const AttnParams p) {
 }
 
 // dQ (one query row per lane) + delta = rowsum(dO * O) written for the dK/dV kernel
-template <typename T, int HD>
-__global__ __launch_bounds__(64) void attn_bwd_dq_generic(const AttnParams p) {
-    __shared__ __attribute__((aligned(16))) float sK[KT][HD];
-    __shared__ __attribute__((aligned(16))) float sV[KT][HD];
-    const int b = blockIdx.z, h = blockIdx.y, qi = blockIdx.x * 64 + threadIdx.x;
+template <typename T, int HD, int NS>
+__global__ __launch_bounds__(64 * NS) void attn_bwd_dq_generic(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float (*sK)[HD] = reinterpret_cast<float (*)[HD]>(smem_raw) + (size_t)wave * 2 * KT;
+    float (*sV)[HD] = sK + KT;
+    const int b = blockIdx.z, h = blockIdx.y, qi = blockIdx.x * 64 + lane;
     const bool valid = qi < p.NQ;
     const float scale = rsqrtf((float)HD);
     float q[HD], go[HD], dq[HD];
@@ -109,15 +152,19 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_generic(const AttnParams p) {
 #pragma unroll
         for (int e = 0; e < HD; ++e) delta += go[e] * oo[e];
         lse = p.lse[((size_t)b * p.H + h) * p.NQ + qi];
-        p.delta[((size_t)b * p.H + h) * p.NQ + qi] = delta;
+        if (wave == 0) p.delta[((size_t)b * p.H + h) * p.NQ + qi] = delta;
     }
     const T* kb = reinterpret_cast<const T*>(p.k) + (size_t)b * p.NK * p.ldk + h * HD;
     const T* vb = reinterpret_cast<const T*>(p.v) + (size_t)b * p.NK * p.ldv + h * HD;
-    for (int k0 = 0; k0 < p.NK; k0 += KT) {
-        const int n = min(KT, p.NK - k0);
+    const int ntile = (p.NK + KT - 1) / KT, iters = (ntile + NS - 1) / NS;
+    for (int it = 0; it < iters; ++it) {
+        const int k0 = (it * NS + wave) * KT;
+        const int n = max(0, min(KT, p.NK - k0));
         __syncthreads();
-        stage_tile<T, HD>(sK, kb + (size_t)k0 * p.ldk, p.ldk, n, threadIdx.x, 64);
-        stage_tile<T, HD>(sV, vb + (size_t)k0 * p.ldv, p.ldv, n, threadIdx.x, 64);
+        if (n > 0) {
+            stage_tile<T, HD>(sK, kb + (size_t)k0 * p.ldk, p.ldk, n, lane, 64);
+            stage_tile<T, HD>(sV, vb + (size_t)k0 * p.ldv, p.ldv, n, lane, 64);
+        }
         __syncthreads();
         for (int j = 0; j < n; ++j) {
             float s = 0.f, dp = 0.f;
@@ -130,16 +177,35 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_generic(const AttnParams p) {
             for (int e = 0; e < HD; ++e) dq[e] += ds * sK[j][e];
         }
     }
+    if (NS > 1) {        // partial dQ of waves 1 .. NS-1 -> wave 0
+        float* red = reinterpret_cast<float*>(smem_raw);
+        __syncthreads();
+        if (wave > 0) {
+            float* r = red + ((size_t)(wave - 1) * 64 + lane) * (HD + 1);
+#pragma unroll
+            for (int e = 0; e < HD; ++e) r[e] = dq[e];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+        for (int w = 1; w < NS; ++w) {
+            const float* r = red + ((size_t)(w - 1) * 64 + lane) * (HD + 1);
+#pragma unroll
+            for (int e = 0; e < HD; ++e) dq[e] += r[e];
+        }
+    }
     if (valid) store_row<T, HD>(reinterpret_cast<T*>(p.dq) + ((size_t)b * p.NQ + qi) * p.lddq + h * HD, dq);
 }
 
 // dK, dV (one key row per lane); queries / dO / lse / delta staged per tile
-template <typename T, int HD>
-__global__ __launch_bounds__(64) void attn_bwd_dkv_generic(const AttnParams p) {
-    __shared__ __attribute__((aligned(16))) float sQ[KT][HD];
-    __shared__ __attribute__((aligned(16))) float sG[KT][HD];
-    __shared__ float sL[KT], sD[KT];
-    const int b = blockIdx.z, h = blockIdx.y, ki = blockIdx.x * 64 + threadIdx.x;
+template <typename T, int HD, int NS>
+__global__ __launch_bounds__(64 * NS) void attn_bwd_dkv_generic(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float (*sQ)[HD] = reinterpret_cast<float (*)[HD]>(smem_raw) + (size_t)wave * 2 * KT;
+    float (*sG)[HD] = sQ + KT;
+    float* sL = reinterpret_cast<float*>(smem_raw) + (size_t)NS * 2 * KT * HD + wave * 2 * KT;      // behind every wave's tiles
+    float* sD = sL + KT;
+    const int b = blockIdx.z, h = blockIdx.y, ki = blockIdx.x * 64 + lane;
     const bool valid = ki < p.NK;
     const float scale = rsqrtf((float)HD);
     float k[HD], v[HD], dk[HD], dv[HD];
@@ -153,14 +219,18 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_generic(const AttnParams p) {
     const T* gb = reinterpret_cast<const T*>(p.d_o) + (size_t)b * p.NQ * p.lddo + h * HD;
     const float* lb = p.lse + ((size_t)b * p.H + h) * p.NQ;
     const float* db = p.delta + ((size_t)b * p.H + h) * p.NQ;
-    for (int q0 = 0; q0 < p.NQ; q0 += KT) {
-        const int n = min(KT, p.NQ - q0);
+    const int ntile = (p.NQ + KT - 1) / KT, iters = (ntile + NS - 1) / NS;
+    for (int it = 0; it < iters; ++it) {
+        const int q0 = (it * NS + wave) * KT;
+        const int n = max(0, min(KT, p.NQ - q0));
         __syncthreads();
-        stage_tile<T, HD>(sQ, qb + (size_t)q0 * p.ldq, p.ldq, n, threadIdx.x, 64);
-        stage_tile<T, HD>(sG, gb + (size_t)q0 * p.lddo, p.lddo, n, threadIdx.x, 64);
-        if (threadIdx.x < KT) {
-            sL[threadIdx.x] = threadIdx.x < n ? lb[q0 + threadIdx.x] : 0.f;
-            sD[threadIdx.x] = threadIdx.x < n ? db[q0 + threadIdx.x] : 0.f;
+        if (n > 0) {
+            stage_tile<T, HD>(sQ, qb + (size_t)q0 * p.ldq, p.ldq, n, lane, 64);
+            stage_tile<T, HD>(sG, gb + (size_t)q0 * p.lddo, p.lddo, n, lane, 64);
+            if (lane < KT) {
+                sL[lane] = lane < n ? lb[q0 + lane] : 0.f;
+                sD[lane] = lane < n ? db[q0 + lane] : 0.f;
+            }
         }
         __syncthreads();
         for (int i = 0; i < n; ++i) {
@@ -175,25 +245,66 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_generic(const AttnParams p) {
             for (int e = 0; e < HD; ++e) { dv[e] += pd * sG[i][e]; dk[e] += ds * sQ[i][e]; }
         }
     }
+    if (NS > 1) {        // partial dK, then dV, of waves 1 .. NS-1 -> wave 0 (two rounds through the staging area)
+        float* red = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            __syncthreads();
+            if (wave > 0) {
+                float* r = red + ((size_t)(wave - 1) * 64 + lane) * (HD + 1);
+#pragma unroll
+                for (int e = 0; e < HD; ++e) r[e] = which ? dv[e] : dk[e];
+            }
+            __syncthreads();
+            if (wave == 0)
+                for (int w = 1; w < NS; ++w) {
+                    const float* r = red + ((size_t)(w - 1) * 64 + lane) * (HD + 1);
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) { if (which) dv[e] += r[e]; else dk[e] += r[e]; }
+                }
+        }
+        if (wave > 0) return;
+    }
     if (valid) {
         store_row<T, HD>(reinterpret_cast<T*>(p.dk) + ((size_t)b * p.NK + ki) * p.lddk + h * HD, dk);
         store_row<T, HD>(reinterpret_cast<T*>(p.dv) + ((size_t)b * p.NK + ki) * p.lddv + h * HD, dv);
     }
 }
 
+// waves per workgroup: four where the streamed side has at least four tiles and the staging areas fit 64 KiB (head size <= 64)
+template <int HD> constexpr int split_of() { return HD <= 64 ? 4 : 1; }
+template <int HD, int NS> constexpr int attn_lds_bytes() { return NS * 2 * KT * HD * 4 + NS * 2 * KT * 4; }
+
+// more than 64 KiB of dynamic LDS needs the attribute (once per instantiation)
+template <typename K>
+static bool allow_lds(K kernel, int bytes) {
+    return bytes <= 64 * 1024 || hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+}
+
 template <typename T, int HD>
 int run_fwd(const AttnParams& p, hipStream_t stream) {
     const dim3 grid((p.NQ + 63) / 64, p.H, p.B);
-    hipLaunchKernelGGL((attn_fwd_generic<T, HD>), grid, dim3(64), 0, stream, p);
+    constexpr int NS = split_of<HD>();
+    static const bool ok_lds = allow_lds(&attn_fwd_generic<T, HD, NS>, attn_lds_bytes<HD, NS>());
+    if (!ok_lds) { mebt_set_error("attention: cannot reserve the LDS of the split generic kernel"); return MEBT_EHIP; }
+    static const bool one = [] { const char* e = getenv("MEBT_ATTN_GENERIC_SPLIT"); return e && e[0] == '1'; }();     // A/B: 1 = one wave per workgroup
+    if (NS > 1 && !one && p.NK >= NS * KT) hipLaunchKernelGGL((attn_fwd_generic<T, HD, NS>), grid, dim3(64 * NS), (attn_lds_bytes<HD, NS>()), stream, p);
+    else hipLaunchKernelGGL((attn_fwd_generic<T, HD, 1>), grid, dim3(64), (attn_lds_bytes<HD, 1>()), stream, p);
     return MEBT_OK;
 }
 template <typename T, int HD>
 int run_bwd(const AttnParams& p, hipStream_t stream) {
+    constexpr int NS = split_of<HD>();
+    static const bool one = [] { const char* e = getenv("MEBT_ATTN_GENERIC_SPLIT"); return e && e[0] == '1'; }();
+    static const bool ok_lds = allow_lds(&attn_bwd_dq_generic<T, HD, NS>, attn_lds_bytes<HD, NS>()) && allow_lds(&attn_bwd_dkv_generic<T, HD, NS>, attn_lds_bytes<HD, NS>());
+    if (!ok_lds) { mebt_set_error("attention: cannot reserve the LDS of the split generic kernels"); return MEBT_EHIP; }
     const dim3 gq((p.NQ + 63) / 64, p.H, p.B);
-    hipLaunchKernelGGL((attn_bwd_dq_generic<T, HD>), gq, dim3(64), 0, stream, p);
+    if (NS > 1 && !one && p.NK >= NS * KT) hipLaunchKernelGGL((attn_bwd_dq_generic<T, HD, NS>), gq, dim3(64 * NS), (attn_lds_bytes<HD, NS>()), stream, p);
+    else hipLaunchKernelGGL((attn_bwd_dq_generic<T, HD, 1>), gq, dim3(64), (attn_lds_bytes<HD, 1>()), stream, p);
     if (p.NK > 0) {
         const dim3 gk((p.NK + 63) / 64, p.H, p.B);
-        hipLaunchKernelGGL((attn_bwd_dkv_generic<T, HD>), gk, dim3(64), 0, stream, p);
+        if (NS > 1 && !one && p.NQ >= NS * KT) hipLaunchKernelGGL((attn_bwd_dkv_generic<T, HD, NS>), gk, dim3(64 * NS), (attn_lds_bytes<HD, NS>()), stream, p);
+        else hipLaunchKernelGGL((attn_bwd_dkv_generic<T, HD, 1>), gk, dim3(64), (attn_lds_bytes<HD, 1>()), stream, p);
     }
     return MEBT_OK;
 }

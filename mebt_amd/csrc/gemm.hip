@@ -557,12 +557,29 @@ int launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
             launch_bf16_config(p, tbm, tbn, staging, split, stream);
         }
     } else if (dtype == MEBT_F32) {
-        dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, split);
-#define LAUNCH_F32(AK, BKC) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC>), grid, dim3(256), 0, stream, p)
+        // the largest tile whose grid still fills the chip (256 CUs): 128 x 128, then the longer side halved, then 64 x 64
+        // (MEBT_F32_TILE=128 keeps 128 x 128 everywhere: A/B of round 6)
+        static const int f32_tile = [] { const char* e = getenv("MEBT_F32_TILE"); return e ? atoi(e) : 0; }();
+        int tbm = 128, tbn = 128;
+        auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * split; };
+        if (f32_tile != 128 && wgs(128, 128) < 256) {
+            if (p.M >= p.N) { tbm = 64; tbn = 128; } else { tbm = 128; tbn = 64; }
+            if (wgs(tbm, tbn) < 256) { tbm = 64; tbn = 64; }
+        }
+        dim3 grid((p.N + tbn - 1) / tbn, (p.M + tbm - 1) / tbm, split);
+#define LAUNCH_F32_T(AK, BKC)                                                                                                 \
+        do {                                                                                                                      \
+            if (tbm == 128 && tbn == 128) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 128, 128>), grid, dim3(256), 0, stream, p);   \
+            else if (tbm == 128) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 128, 64>), grid, dim3(256), 0, stream, p);          \
+            else if (tbn == 128) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 64, 128>), grid, dim3(256), 0, stream, p);          \
+            else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 64, 64>), grid, dim3(256), 0, stream, p);                          \
+        } while (0)
+#define LAUNCH_F32(AK, BKC) LAUNCH_F32_T(AK, BKC)
         if (p.a_kc && p.b_kc) LAUNCH_F32(true, true);
         else if (p.a_kc && !p.b_kc) LAUNCH_F32(true, false);
         else if (!p.a_kc && !p.b_kc) LAUNCH_F32(false, false);
         else LAUNCH_F32(false, true);
+#undef LAUNCH_F32_T
 #undef LAUNCH_F32
     } else {
         mebt_set_error("gemm: unsupported dtype");

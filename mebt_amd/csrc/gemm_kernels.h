@@ -1118,32 +1118,35 @@ __global__ __launch_bounds__(NW * 64) void wgrad_grouped_kernel(const GroupedWgr
 // ------------------------------------------------------------------------------------------------
 constexpr int FBK = 16, FLD = 132;   // padded row length (floats)
 
-template <bool KC>
+// ROWS = 128 or 64 tile rows: ROWS * 4 float4 chunks per k-tile, ROWS / 64 per thread
+template <bool KC, int ROWS>
 struct TileLoaderF32 {
-    uint32_t goff[2];
-    bool ok[2];
-    int l0[2], l1[2];
+    static constexpr int NCH = ROWS / 64;
+    uint32_t goff[NCH];
+    bool ok[NCH];
+    int l0[NCH], l1[NCH];
     uint32_t step;
     __amdgpu_buffer_rsrc_t rsrc;
     __device__ __forceinline__ void init(const void* base, int rows, int K, int ld, int r0, int tid) {
         const float* b = reinterpret_cast<const float*>(base);
-        if (KC) {   // tile [128 rows][16 k] : 512 float4 chunks
+        if (KC) {   // tile [ROWS rows][16 k]
             rsrc = make_rsrc(b + (size_t)r0 * ld, (size_t)(rows - r0) * ld * 4);
             step = FBK * 4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NCH; ++i) {
                 const int id = tid + 256 * i, row = id >> 2, c = id & 3;
                 goff[i] = ((uint32_t)row * ld + 4 * c) * 4;
                 ok[i] = true;
                 l0[i] = 4 * c;   // k
                 l1[i] = row;
             }
-        } else {    // tile [16 k][128 rows] : 512 float4 chunks
+        } else {    // tile [16 k][ROWS rows]
+            constexpr int CPR = ROWS / 4;
             rsrc = make_rsrc(b, (size_t)K * ld * 4);
             step = (uint32_t)FBK * ld * 4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int id = tid + 256 * i, krow = id >> 5, c = id & 31;
+            for (int i = 0; i < NCH; ++i) {
+                const int id = tid + 256 * i, krow = id / CPR, c = id % CPR;
                 const int col = r0 + 4 * c;
                 ok[i] = col < rows;
                 goff[i] = ((uint32_t)krow * ld + col) * 4;
@@ -1152,14 +1155,14 @@ struct TileLoaderF32 {
             }
         }
     }
-    __device__ __forceinline__ void load(f32x4 (&r)[2], int kt) const {
+    __device__ __forceinline__ void load(f32x4 (&r)[NCH], int kt) const {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NCH; ++i)
             r[i] = __builtin_bit_cast(f32x4, buf_load16(rsrc, ok[i] ? goff[i] + (uint32_t)kt * step : (uint32_t)MEBT_OOB));
     }
-    __device__ __forceinline__ void store(float* lds, const f32x4 (&r)[2]) const {
+    __device__ __forceinline__ void store(float* lds, const f32x4 (&r)[NCH]) const {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             if (KC) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) lds[(l0[i] + j) * FLD + l1[i]] = r[i][j];
@@ -1170,33 +1173,37 @@ struct TileLoaderF32 {
     }
 };
 
-template <bool A_KC, bool B_KC>
+// TBM, TBN in {128, 64}: 4 waves as 2 x 2, wave tile (TBM / 2) x (TBN / 2) = 1 or 2 MFMA tiles of 32 x 32 each way.  The small tiles exist
+// for outputs that leave CUs idle at 128 x 128 (a 1536 x 1024 product is 96 tiles for 256 CUs; a 1024 x 1024 weight gradient 64): round 6,
+// the exact-fp32 engine is the reference's own arithmetic and its step was 14 x the bf16 step's time.
+template <bool A_KC, bool B_KC, int TBM = 128, int TBN = 128>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) float sA[FBK * FLD];
     __shared__ __attribute__((aligned(16))) float sB[FBK * FLD];
+    constexpr int MI = TBM / 64, NJ = TBN / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
     const int nkt = (p.K + FBK - 1) / FBK;
     const int per = (nkt + gridDim.z - 1) / gridDim.z;
     const int kt0 = blockIdx.z * per;
     const int kt1 = min(nkt, kt0 + per);
     if (kt0 >= kt1) return;
 
-    TileLoaderF32<A_KC> la;
-    TileLoaderF32<B_KC> lb;
+    TileLoaderF32<A_KC, TBM> la;
+    TileLoaderF32<B_KC, TBN> lb;
     la.init(p.A, p.M, p.K, p.lda, m0, tid);
     lb.init(p.B, p.N, p.K, p.ldb, n0, tid);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[2], rb[2];
+    f32x4 ra[TBM / 64], rb[TBN / 64];
     la.load(ra, kt0);
     lb.load(rb, kt0);
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -1210,15 +1217,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
         for (int kk = 0; kk < FBK; kk += 2) {
             const int k = kk + (lane >> 5);
-            float a[2], b[2];
+            float a[MI], b[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = sA[k * FLD + wm * 64 + i * 32 + (lane & 31)];
+            for (int i = 0; i < MI; ++i) a[i] = sA[k * FLD + wm * (TBM / 2) + i * 32 + (lane & 31)];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = sB[k * FLD + wn * 64 + j * 32 + (lane & 31)];
+            for (int j = 0; j < NJ; ++j) b[j] = sB[k * FLD + wn * (TBN / 2) + j * 32 + (lane & 31)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
@@ -1227,13 +1234,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     const bool atomic = gridDim.z > 1;
     const bool add_bias = blockIdx.z == 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (TBM / 2) + i * 32 + (lane & 31);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
+                const int n = n0 + wn * (TBN / 2) + j * 32 + 8 * g + 4 * (lane >> 5);
                 if (m < p.M && n < p.N) {
                     f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                     epilogue_store<float>(p, m, n, v, add_bias, atomic);
