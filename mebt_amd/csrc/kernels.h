@@ -232,7 +232,6 @@ struct AttnParams {
     const int32_t* kidx = nullptr;
     int kidx_rows = 0;
 };
-
 __host__ __device__ static inline int mebt_attn_dmask_tiles(int NK) { return 4 * ((NK + 255) / 256); }
 static inline size_t mebt_attn_dmask_bytes(int B, int H, int NQ, int NK) { return (size_t)B * H * NQ * mebt_attn_dmask_tiles(NK) * 8; }
 int launch_attn_fwd(const AttnParams& p, int dtype, hipStream_t stream);
