@@ -113,6 +113,12 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C mebt_amd/csrc`). mebt_amd has no fallback path without its HIP library.")
+    # torch first: it bundles a HIP runtime of its own, and a process that loads /opt/rocm's libamdhip64 (through this library) BEFORE torch's
+    # ends up with two runtimes and "no ROCm-capable device" at the first HIP call (seen with `build(); smoke()` in one process, round 6)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
