@@ -100,7 +100,7 @@ def write_outputs(args, save_np, all_data, all_code, resolution, codemap_limit=N
             print('no first stage attached (vtokens model): no pixel samples to save, token ids only (--save_codemap)')
             return
         print('saving numpy file to %s...' % save_np)
-        data = np.array(all_data)
+        data = np.concatenate(all_data, 0)               # (the reference stacks with np.array: the same for equal batches, an error for a short last one)
         data = np.transpose(data.reshape(-1, 3, args.total_length, resolution, resolution), (0, 2, 3, 4, 1))      # B T H W C
         n_total = data.shape[0]
         data = (data * 255).astype(np.uint8)[np.random.permutation(n_total)[:args.n_sample]]
