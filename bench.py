@@ -425,8 +425,14 @@ def secondary_c4(args, device, lib):
             tl.step(xt, it, t=0.5)
         dt = timed(lambda: tl.step(xt, it, t=0.5), 5, sync)
         fl = 3 * 4 * forward_flops_per_sample(uo, 4096, 4096)
+        share = gemm_share(lambda: tl.step(xt, it, t=0.5))          # the GEMM family of one more step by HIP events (incl. the fused AdamW epilogues)
         out["c4_train_step"] = {"batch": 4, "NC": 4096, "NT": 4096, "ms_per_step": round(dt * 1e3, 3), "masked_tokens_per_s": round(4 * 4096 / dt, 1),
                                 "tflops": round(fl / dt / 1e12, 1), "frac_of_bf16_mfma_peak": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                "gemm_family": {"bound": "mfma", "achieved": share["gemm_family_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": round(share["gemm_family_tflops"] / PEAK_BF16_TFLOPS, 4), "gemm_ms_by_events": share["gemm_ms_by_events"],
+                                                "gemm_tflop": share["gemm_tflop"], "launches": share["gemm_launches"],
+                                                "note": "the same kernels as the headline at 16 384 rows per product: what the family reaches when the shapes "
+                                                        "allow 256-wide tiles in whole rounds"},
                                 "optimizer": "in-backward" if tl.fused_optimizer else "separate"}
         del tm, tl
         torch.cuda.empty_cache()
