@@ -257,6 +257,13 @@ def test_sampling_command_lines_micro_golden(tmp_path, monkeypatch):
     code = np.load(out + "_codemap.npy")
     assert code.shape == (1, 2, 4, 4) and hooks[0]["k"] == int(g["bi_ndraws"])          # --n_sample 1 of the batch of 2 (:279)
     assert (code == g["bi_code_maps"][:1]).all()
+    # --base_np: `extrapolate` of given code maps (reference :262-273), against the reference script's own output
+    base_np = str(tmp_path / "base_codes.npy")
+    np.save(base_np, g["ex_vq0"])
+    out_ex = sample_cli.main(f"--gpt_ckpt {ckpt} --exp_name micro --dtype f32 --batch_size 2 --n_sample 2 --total_length 16 --step_size 8 --context_size 4 "
+                             f"--temp 1.0 --vid_n_steps 3 --vid_c_temp 2.5 --base_np {base_np} --no_phase --save_codemap --no_np --dataset stl --run 1".split())
+    code_ex = np.load(out_ex + "_codemap.npy")
+    assert hooks[-1]["k"] == int(g["ex_ndraws"]) and (code_ex == g["ex_code_maps"]).all()
     full = str(tmp_path / "VID_n_steps4_maskgit_cosine_ctemp3.0_draft_codemap.npy")
     np.save(full, g["bi_code_maps"])
     out2 = dnr_cli.main(f"--gpt_ckpt {ckpt} --exp_name micro --dtype f32 --batch_size 2 --n_sample 2 --total_length 8 --step_size 8 --context_size 8 "
